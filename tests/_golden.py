@@ -1,0 +1,47 @@
+"""Loader for the committed golden fixtures (tests/golden/*.npz, made by make_golden.py from the
+real reference)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+CASE_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "layers.npz")
+
+
+class Case:
+    def __init__(self, name):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+        self.name = name
+        self.meta = json.loads(str(z["__meta__"]))
+        self.kwargs = self.meta["kwargs"]
+        self.wn = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("wn/")}
+        self.fused = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fused/")}
+        self.io = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("io/")}
+
+    def get(self, k):
+        return self.io.get(k)
+
+
+def oracle_config(kwargs):
+    from oracle.wavenet_oracle import OracleConfig
+    up = kwargs.get("upsample_params", {})
+    return OracleConfig(
+        out_channels=kwargs["out_channels"], layers=kwargs["layers"], stacks=kwargs["stacks"],
+        residual_channels=kwargs["residual_channels"], gate_channels=kwargs["gate_channels"],
+        skip_out_channels=kwargs["skip_out_channels"], kernel_size=kwargs["kernel_size"],
+        cin_channels=kwargs.get("cin_channels", -1), gin_channels=kwargs.get("gin_channels", -1),
+        n_speakers=kwargs.get("n_speakers"),
+        upsample_conditional_features=kwargs.get("upsample_conditional_features", False),
+        upsample_net=kwargs.get("upsample_net", "ConvInUpsampleNetwork"),
+        upsample_scales=list(up.get("upsample_scales", [4, 4, 4, 4])),
+        cin_pad=kwargs.get("cin_pad", 0), scalar_input=kwargs.get("scalar_input", False),
+        use_speaker_embedding=kwargs.get("use_speaker_embedding", False),
+        output_distribution=kwargs.get("output_distribution", "Logistic"))
+
+
+def load_layers():
+    z = np.load(os.path.join(GOLDEN, "layers.npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}

@@ -1,0 +1,64 @@
+"""Noise tapes: the random numbers the sampling stage consumes, generated up front.
+
+The reference draws from torch's global generator inside the sample loop
+(wavenet_vocoder/mixture.py:138,151,247,266; wavenet.py:334-335).  The HIP engine instead reads a
+``(T, B, NZ)`` float32 tape (or runs its own counter-based generator when no tape is given).  This
+module produces a tape by replaying, on the host, exactly the draws the reference would make on CPU, in
+the same order and from the same generator -- so ``torch.manual_seed(s); model.incremental_forward(...)``
+sees the same random numbers the reference's CPU path sees for seed ``s`` (the replay is
+re-verified against the real reference by tests/golden/make_golden.py).
+
+Tape layout per (t, b), NZ floats:
+  Logistic (MoL)        : u1[0..nr_mix) ~ U(1e-5, 1-1e-5) (Gumbel-max), then u2 ~ U(1e-5, 1-1e-5)
+  Normal, C in {2, 3}   : n ~ N(0, 1)
+  Normal, C = 3k > 3    : u1[0..nr_mix), then n ~ N(0, 1)
+  one-hot (categorical) : e[0..C) ~ Exp(1)            (torch.multinomial draws argmax(p / e))
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+__all__ = ["noise_width", "make_noise_tape"]
+
+_EPS = 1e-5
+
+
+def noise_width(scalar_input: bool, output_distribution: str, out_channels: int) -> int:
+    if scalar_input:
+        if output_distribution == "Logistic":
+            assert out_channels % 3 == 0
+            return out_channels // 3 + 1
+        if output_distribution == "Normal":
+            if out_channels in (2, 3):
+                return 1
+            assert out_channels % 3 == 0
+            return out_channels // 3 + 1
+        raise ValueError(f"unknown output_distribution {output_distribution!r}")
+    return out_channels
+
+
+def make_noise_tape(T: int, B: int, *, scalar_input: bool, output_distribution: str,
+                    out_channels: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+    """Replay the reference's per-step CPU draws; returns a CPU float32 tensor (T, B, NZ).
+
+    Per-step calls (not one bulk call) because torch's CPU ``normal_`` switches algorithm with the
+    tensor size, so only same-sized calls reproduce the same stream."""
+    nz = noise_width(scalar_input, output_distribution, out_channels)
+    tape = torch.empty(T, B, nz, dtype=torch.float32)
+    kw = {} if generator is None else {"generator": generator}
+    if scalar_input:
+        mix = nz - 1
+        normal = output_distribution == "Normal"
+        for t in range(T):
+            if mix > 0:
+                tape[t, :, :mix] = torch.empty(B, 1, mix).uniform_(_EPS, 1.0 - _EPS, **kw)[:, 0, :]
+            if normal:
+                tape[t, :, mix] = torch.empty(B, 1).normal_(0.0, 1.0, **kw)[:, 0]
+            else:
+                tape[t, :, mix] = torch.empty(B, 1).uniform_(_EPS, 1.0 - _EPS, **kw)[:, 0]
+    else:
+        for t in range(T):
+            tape[t] = torch.empty(B, out_channels).exponential_(1.0, **kw)
+    return tape
