@@ -1,0 +1,197 @@
+/*
+ * wnv.h -- C ABI of the MI355X-native WaveNet-vocoder synthesis engine (libwnv_hip.so).
+ *
+ * The reference (r9y9/wavenet_vocoder v0.2.0) is pure Python on PyTorch: it has NO native FFI for this
+ * path, so there is no existing binding to mirror symbol-for-symbol.  Each entry point below therefore
+ * names the reference Python function it replaces (file:line under the reference tree); the ctypes stub a
+ * maintainer would add to the reference is shown in INTEGRATION.md and shipped as
+ * wavenet_vocoder_amd/_lib.py.
+ *
+ * Conventions
+ *   - plain C types only: pointers + sizes, no torch types.  "device" pointers are HIP device pointers on
+ *     the device the handle was created for; "host" pointers are ordinary process memory.
+ *   - all tensors are contiguous float32 unless stated.  Shapes are written reference-style.
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream)
+ *     except where it says "synchronous".  The caller owns all in/out buffers; the handle owns packed
+ *     weights, history rings and scratch.
+ *   - every function returns a wnv_status; wnv_last_error() gives the message for the calling thread.
+ *     The Python host maps WNV_ERR_TRAINING_MODE -> RuntimeError('incremental_forward only supports eval
+ *     mode') (reference conv.py:19-20), WNV_ERR_SHAPE -> AssertionError (wavenet.py:276), and so on.
+ *   - not re-entrant per handle (the reference's modules are not either: per-module mutable buffers,
+ *     SURVEY.md section 8b "Threading"); different handles may be used from different threads.
+ */
+#ifndef WNV_H_
+#define WNV_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WNV_ABI_VERSION 1
+#define WNV_MAX_UPSAMPLE_STAGES 8
+
+typedef enum wnv_status {
+    WNV_OK = 0,
+    WNV_ERR_INVALID_ARG = 1,   /* NULL pointer, negative size, unknown enum ...                         */
+    WNV_ERR_NOT_LOADED = 2,    /* a required weight tensor was never loaded                              */
+    WNV_ERR_HIP = 3,           /* a HIP runtime call failed (message carries hipGetErrorString)          */
+    WNV_ERR_SHAPE = 4,         /* upsampled length != T  (reference: `assert c.size(-1) == T`)           */
+    WNV_ERR_UNSUPPORTED = 5,   /* configuration outside what the engine implements                       */
+    WNV_ERR_TIMEOUT = 6,       /* an in-kernel bounded spin gave up (persistent pipeline kernels)        */
+    WNV_ERR_TRAINING_MODE = 7  /* reserved for hosts that track train/eval mode                          */
+} wnv_status;
+
+/* output_distribution: how the head output is turned into the next input.
+ * reference wavenet.py:322-335 */
+typedef enum wnv_dist {
+    WNV_DIST_CATEGORICAL = 0,  /* one-hot input, softmax + OneHotCategorical (scalar_input == 0)          */
+    WNV_DIST_LOGISTIC = 1,     /* mixture of logistics, mixture.py:118-156                                */
+    WNV_DIST_NORMAL = 2        /* (mixture of) Gaussians, mixture.py:221-270                              */
+} wnv_dist;
+
+typedef enum wnv_upsample_kind {
+    WNV_UPSAMPLE_NONE = 0,     /* upsample_conditional_features=False: c arrives at sample rate           */
+    WNV_UPSAMPLE_CONVIN = 1,   /* upsample.ConvInUpsampleNetwork  (upsample.py:69-85)                      */
+    WNV_UPSAMPLE_PLAIN = 2     /* upsample.UpsampleNetwork        (upsample.py:29-66)                      */
+} wnv_upsample_kind;
+
+/* Mirrors the constructor of wavenet_vocoder.WaveNet (wavenet.py:98-111). */
+typedef struct wnv_config {
+    int32_t abi_version;            /* must be WNV_ABI_VERSION                                          */
+    int32_t out_channels;
+    int32_t layers;
+    int32_t stacks;                 /* dilation of layer i = 2 ** (i % (layers / stacks))                 */
+    int32_t residual_channels;
+    int32_t gate_channels;          /* even                                                               */
+    int32_t skip_out_channels;
+    int32_t kernel_size;
+    int32_t cin_channels;           /* <= 0 : no local conditioning                                       */
+    int32_t gin_channels;           /* <= 0 : no global conditioning                                      */
+    int32_t n_speakers;             /* > 0 with use_speaker_embedding: embed_speakers.weight is expected  */
+    int32_t use_speaker_embedding;
+    int32_t scalar_input;           /* 1: first_conv is Conv1d1x1(1, R); 0: Conv1d1x1(out_channels, R)    */
+    int32_t output_distribution;    /* wnv_dist                                                           */
+    int32_t upsample_kind;          /* wnv_upsample_kind                                                  */
+    int32_t n_upsample_scales;
+    int32_t upsample_scales[WNV_MAX_UPSAMPLE_STAGES];
+    int32_t freq_axis_kernel_size;  /* only 1 is implemented (all reference presets)                      */
+    int32_t cin_pad;
+    int32_t reserved[8];
+} wnv_config;
+
+/* One named tensor of a reference state_dict.  `name` is the state_dict key, e.g.
+ * "conv_layers.3.conv.weight_v" or "conv_layers.3.conv.weight"; both the weight-normed (weight_g /
+ * weight_v) and the fused (weight) layouts are accepted and folded by the engine
+ * (w = g * v / ||v||, norm over every dim but 0 == torch remove_weight_norm, wavenet.py:355-361). */
+typedef struct wnv_tensor {
+    const char*  name;
+    const float* data;              /* HOST pointer, contiguous float32                                   */
+    int32_t      ndim;
+    int64_t      shape[4];
+} wnv_tensor;
+
+typedef struct wnv_engine* wnv_handle;
+
+/* ---- life cycle ------------------------------------------------------------------------------ */
+
+/* Replaces WaveNet.__init__ (wavenet.py:98-156).  Synchronous. */
+wnv_status wnv_create(const wnv_config* cfg, int32_t device, wnv_handle* out);
+wnv_status wnv_destroy(wnv_handle h);
+
+/* Replaces load_state_dict + make_generation_fast_ (evaluate.py:145-153, wavenet.py:355-361) and
+ * conv.Conv1d._get_linearized_weight (conv.py:51-62): takes the tensors of a reference state_dict,
+ * folds weight norm, re-lays the weights out for the kernels and uploads them.  Synchronous.
+ * Unknown names -> WNV_ERR_INVALID_ARG; a missing required tensor -> WNV_ERR_NOT_LOADED. */
+wnv_status wnv_load_weights(wnv_handle h, const wnv_tensor* tensors, int32_t n);
+
+/* receptive_field_size (wavenet.py:42-60). */
+int64_t wnv_receptive_field(int32_t layers, int32_t stacks, int32_t kernel_size);
+/* Number of float32 noise values consumed per utterance per step for this configuration
+ * (tape layout: wavenet_vocoder_amd/noise.py; draw order of the reference: SURVEY.md A.3). */
+int32_t wnv_noise_width(const wnv_config* cfg);
+/* Number of output samples the upsampling network produces for Tc_in input frames, or -1. */
+int64_t wnv_upsampled_length(const wnv_config* cfg, int64_t Tc_in);
+
+/* ---- prologue: local-conditioning upsampling ----------------------------------------------------
+ * Replaces ConvInUpsampleNetwork.forward / UpsampleNetwork.forward (upsample.py:83-85, :51-66) and the
+ * transpose at wavenet.py:277-278.
+ *   c      device (B, cin, Tc_in)                       [Tc_in includes the 2*cin_pad context frames]
+ *   c_up   device (B, T, cin)   TIME-MAJOR              [T = wnv_upsampled_length(cfg, Tc_in)]
+ * Returns WNV_ERR_SHAPE when T != T_expected (T_expected < 0 skips the check). */
+wnv_status wnv_upsample(wnv_handle h, const float* c, int32_t B, int64_t Tc_in,
+                        float* c_up, int64_t T_expected, void* stream);
+
+/* ---- the hot loop --------------------------------------------------------------------------------
+ * Replaces WaveNet.incremental_forward (wavenet.py:215-343): clear_buffer, the T-step autoregressive
+ * loop (first_conv, L x ResidualConv1dGLU.incremental_forward, skip sum, head, sampling) and the final
+ * stack/transposes, as ONE launch with no host round trip between samples. */
+typedef struct wnv_generate_args {
+    int32_t B;                 /* utterances in this call                                               */
+    int64_t T;                 /* steps to generate (already max(T, Tt), wavenet.py:255-258)             */
+    const float* c_up;         /* device (B, T, cin) time-major, or NULL                                 */
+    const float* g;            /* device (B, gin) global features, or NULL                               */
+    const int64_t* g_ids;      /* device (B) speaker ids -> embed_speakers (wavenet.py:264-268), or NULL */
+    const float* initial;      /* device (B, Cin) first input, Cin = 1 or out_channels; NULL = zeros /   */
+                               /*   one-hot index 127 (wavenet.py:281-289)                               */
+    const float* teacher;      /* device (B, Tt, Cin) teacher-forcing inputs (test_inputs), or NULL      */
+    int64_t Tt;
+    const float* noise;        /* device (T, B, wnv_noise_width) tape, or NULL = in-kernel Philox(seed)  */
+    uint64_t seed;
+    int32_t softmax;           /* categorical only: apply softmax (wavenet.py:332)                       */
+    int32_t quantize;          /* categorical only: sample a one-hot (wavenet.py:333-335)                */
+    float* out;                /* device (B, C, T): C = 1 scalar samples | out_channels one-hot/probs    */
+    float* params_out;         /* optional device (B, out_channels, T): head output before sampling      */
+    int32_t* index_out;        /* optional device (B, T): sampled class (categorical + quantize)         */
+    int32_t kernel;            /* 0 = auto, 1 = generic single-workgroup kernel, 2 = pipelined ring      */
+    void* stream;
+} wnv_generate_args;
+
+wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* args);
+
+/* WaveNet.clear_buffer (wavenet.py:345-353): the engine re-zeroes its history at the start of every
+ * wnv_generate (as incremental_forward does at :241), so this only releases scratch. */
+wnv_status wnv_reset(wnv_handle h);
+
+/* ---- layer-level drop-ins ------------------------------------------------------------------------
+ * conv.Conv1d.incremental_forward (conv.py:17-46): one step of a queue-cached dilated convolution. */
+typedef struct wnv_qconv* wnv_qconv_handle;
+wnv_status wnv_qconv_create(int32_t cin, int32_t cout, int32_t kernel_size, int32_t dilation,
+                            int32_t device, wnv_qconv_handle* out);
+/* weight host (cout, cin, kernel_size) [nn.Conv1d layout]; bias host (cout) or NULL. */
+wnv_status wnv_qconv_set_weights(wnv_qconv_handle q, const float* weight, const float* bias);
+/* x device (B, cin) -> y device (B, cout).  History is created zeroed on the first step after a reset
+ * (conv.py:34-36) for that B. */
+wnv_status wnv_qconv_step(wnv_qconv_handle q, const float* x, float* y, int32_t B, void* stream);
+wnv_status wnv_qconv_reset(wnv_qconv_handle q);          /* conv.py:48-49 clear_buffer */
+wnv_status wnv_qconv_destroy(wnv_qconv_handle q);
+
+/* ResidualConv1dGLU.incremental_forward (modules.py:112-163): one gated residual layer step. */
+typedef struct wnv_glu* wnv_glu_handle;
+typedef struct wnv_glu_config {
+    int32_t residual_channels, gate_channels, kernel_size, skip_out_channels;
+    int32_t cin_channels, gin_channels, dilation, bias;
+} wnv_glu_config;
+wnv_status wnv_glu_create(const wnv_glu_config* cfg, int32_t device, wnv_glu_handle* out);
+/* names as in ResidualConv1dGLU.state_dict(): "conv.weight[_g|_v]", "conv.bias", "conv1x1c.weight..",
+ * "conv1x1g.weight..", "conv1x1_out.*", "conv1x1_skip.*". */
+wnv_status wnv_glu_load_weights(wnv_glu_handle g, const wnv_tensor* tensors, int32_t n);
+/* x (B,R), c (B,cin)|NULL, gcond (B,gin)|NULL  ->  x_out (B,R), s_out (B,K); all device. */
+wnv_status wnv_glu_step(wnv_glu_handle g, const float* x, const float* c, const float* gcond,
+                        float* x_out, float* s_out, int32_t B, void* stream);
+wnv_status wnv_glu_reset(wnv_glu_handle g);              /* modules.py:165-169 clear_buffer */
+wnv_status wnv_glu_destroy(wnv_glu_handle g);
+
+/* ---- misc --------------------------------------------------------------------------------------- */
+const char* wnv_last_error(void);
+int32_t wnv_abi_version(void);
+/* Introspection used by bench.py's roofline: algorithmic bytes moved per time step of a B-utterance
+ * group (weights once + ring taps + conditioning row + output) and MACs per sample. */
+int64_t wnv_bytes_per_step(wnv_handle h, int32_t B);
+int64_t wnv_macs_per_sample(wnv_handle h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WNV_H_ */

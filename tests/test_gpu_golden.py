@@ -1,0 +1,161 @@
+"""-m gpu: the HIP engine (through the C ABI / the drop-in WaveNet) against the golden fixtures generated
+from the real reference.  Tolerance 1e-4 on teacher-forced outputs and distribution parameters (the
+tolerance the reference's own online==offline tests state, tests/test_model.py:361-366); sampled classes of
+the categorical models must be EXACT under the shared noise tape."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import wavenet_vocoder_amd as wnv
+from wavenet_vocoder_amd.conv import Conv1d
+from wavenet_vocoder_amd.modules import ResidualConv1dGLU
+from tests._golden import CASE_NAMES, Case, load_layers
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+KERNELS = [1]          # 1 = generic single-workgroup kernel; the ring kernel has its own file
+
+
+def model_on_gpu(c, layout="wn"):
+    m = wnv.WaveNet(**c.kwargs).eval()
+    m.load_state_dict(getattr(c, layout))
+    return m.to("cuda")
+
+
+def cuda(t):
+    return None if t is None else t.to("cuda")
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_teacher_forced_matches_reference(name, kernel):
+    c = Case(name)
+    m = model_on_gpu(c)
+    m.kernel, m.capture_params = kernel, True
+    scalar = c.kwargs.get("scalar_input", False)
+    x = c.get("x")
+    torch.manual_seed(c.meta["seed"] + 1)      # replay mode: same noise the reference consumed
+    y = m.incremental_forward(test_inputs=cuda(x), c=cuda(c.get("c_tf")), g=cuda(c.get("g_tf")),
+                              T=x.size(-1), softmax=True, quantize=False)
+    y = y.cpu()
+    assert y.shape == c.get("tf_out").shape
+    if scalar:
+        p = m.last_params.cpu()
+        err = (p - c.get("tf_params")).abs().max().item()
+        assert err < TOL, f"distribution parameters differ by {err}"
+        # samples: same noise, so they agree unless a Gumbel argmax flipped on a near tie
+        d = (y - c.get("tf_out")).abs()
+        assert (d < TOL).float().mean().item() > 0.98, d.max()
+        # batch forward of the reference == our incremental parameters (online == offline)
+        assert (p - c.get("fwd")).abs().max().item() < TOL
+    else:
+        err = (y - c.get("tf_out")).abs().max().item()
+        assert err < TOL, f"probabilities differ by {err}"
+        assert (y - c.get("fwd")).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("name", CASE_NAMES)
+def test_free_running_with_shared_tape(name, kernel):
+    c = Case(name)
+    m = model_on_gpu(c, "fused")
+    m.kernel, m.capture_params = kernel, True
+    want = c.get("fr_out")
+    torch.manual_seed(c.meta["seed"] + 2)
+    y = m.incremental_forward(initial_input=cuda(c.get("fr_init")), c=cuda(c.get("c_fr")), g=cuda(c.get("g_fr")),
+                              T=want.size(-1), softmax=True, quantize=True).cpu()
+    assert y.shape == want.shape
+    if c.kwargs.get("scalar_input", False):
+        # free running is chaotic in principle; on these short horizons the trajectories must still agree
+        err = (y - want).abs().max().item()
+        assert err < 5e-4, err
+        assert (m.last_params.cpu() - c.get("fr_params")).abs().max().item() < 5e-4
+    else:
+        assert torch.equal(y.argmax(1), want.argmax(1)), "sampled classes differ"
+        assert torch.equal(y, want)
+
+
+def test_default_start_is_index_127():
+    c = Case("onehot_nocond")
+    m = model_on_gpu(c)
+    m.kernel = 1
+    want = c.get("fr0_out")
+    torch.manual_seed(c.meta["seed"] + 3)
+    y = m.incremental_forward(T=want.size(-1)).cpu()
+    assert torch.equal(y, want)
+
+
+@pytest.mark.parametrize("name", [n for n in CASE_NAMES if "upsample" in n])
+def test_upsample_kernel(name):
+    c = Case(name)
+    m = model_on_gpu(c)
+    eng = m._get_engine()
+    got = eng.upsample(cuda(c.get("c_tf"))).cpu()            # (B, T, cin) time-major
+    want = c.get("c_up_tf").transpose(1, 2)
+    assert got.shape == want.shape
+    assert (got - want).abs().max().item() < 1e-5
+    with pytest.raises(AssertionError):
+        eng.upsample(cuda(c.get("c_tf")), T_expected=want.shape[1] + 1)   # wavenet.py:276
+
+
+def test_mixed_teacher_then_free_run():
+    """test_inputs shorter than T: forced for the first steps, then free running (wavenet.py:255-258,297-301)."""
+    c = Case("mol_upsample_convin")
+    m = model_on_gpu(c)
+    m.kernel = 1
+    x = c.get("x")[:, :, :16]
+    T = c.get("c_tf").shape[-1] - 2 * c.kwargs["cin_pad"]
+    T *= int(np.prod(c.kwargs["upsample_params"]["upsample_scales"]))
+    torch.manual_seed(5)
+    y = m.incremental_forward(test_inputs=cuda(x), c=cuda(c.get("c_tf")), T=T).cpu()
+    # oracle on the same tape
+    from oracle.wavenet_oracle import Oracle
+    from tests._golden import oracle_config
+    from wavenet_vocoder_amd.noise import make_noise_tape
+    torch.manual_seed(5)
+    tape = make_noise_tape(T, x.shape[0], scalar_input=True, output_distribution="Logistic", out_channels=30)
+    o = Oracle(oracle_config(c.kwargs), c.wn)
+    want = o.incremental_forward(test_inputs=x, c=c.get("c_tf"), T=T, noise=tape)
+    assert (y - want).abs().max().item() < 5e-4
+
+
+@pytest.mark.parametrize("tag", ["glu_cg", "glu_plain", "glu_k2"])
+def test_layer_level_glu(tag):
+    z = load_layers()
+    kw = json.loads(str(z[f"{tag}/kwargs"]))
+    m = ResidualConv1dGLU(**kw).eval()
+    m.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(v) for k, v in z.items() if k.startswith(f"{tag}/wn/")})
+    m = m.to("cuda")
+    x = torch.from_numpy(z[f"{tag}/x"]).cuda()
+    c = torch.from_numpy(z[f"{tag}/c"]).cuda() if f"{tag}/c" in z else None
+    g = torch.from_numpy(z[f"{tag}/g"]).cuda() if f"{tag}/g" in z else None
+    for rep in range(2):                                   # second pass checks clear_buffer()
+        m.clear_buffer()
+        xs, ss = [], []
+        for t in range(x.size(1)):
+            xo, so = m.incremental_forward(x[:, t:t + 1], None if c is None else c[:, t:t + 1],
+                                           None if g is None else g[:, t:t + 1])
+            assert xo.shape == (x.size(0), 1, kw["residual_channels"])
+            xs.append(xo)
+            ss.append(so)
+        assert np.abs(torch.cat(xs, 1).cpu().numpy() - z[f"{tag}/x_out"]).max() < 2e-5
+        assert np.abs(torch.cat(ss, 1).cpu().numpy() - z[f"{tag}/s_out"]).max() < 2e-5
+
+
+@pytest.mark.parametrize("tag", ["conv_d3", "conv_k1", "conv_k4"])
+def test_layer_level_queue_conv(tag):
+    z = load_layers()
+    ci, co, k, d = [int(v) for v in z[f"{tag}/meta"]]
+    m = Conv1d(ci, co, k, dilation=d, padding=(k - 1) * d).eval()
+    m.load_state_dict({"weight": torch.from_numpy(z[f"{tag}/weight"]), "bias": torch.from_numpy(z[f"{tag}/bias"])})
+    m = m.to("cuda")
+    x = torch.from_numpy(z[f"{tag}/x"]).cuda()
+    for rep in range(2):
+        m.clear_buffer()
+        y = torch.cat([m.incremental_forward(x[:, t:t + 1]) for t in range(x.size(1))], 1)
+        assert np.abs(y.cpu().numpy() - z[f"{tag}/y"]).max() < 2e-5
+    m.train()
+    with pytest.raises(RuntimeError, match="only supports eval mode"):
+        m.incremental_forward(x[:, :1])

@@ -1,0 +1,148 @@
+"""CPU-side checks of the host layer: checkpoint compatibility, the batch ``forward`` against the golden
+fixtures, that libwnv_hip.so loads and exports everything include/wnv.h declares, the pure-host C entry
+points, and that the product never touches the oracle."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import wavenet_vocoder_amd as wnv
+from wavenet_vocoder_amd import _lib
+from wavenet_vocoder_amd.engine import make_config
+from wavenet_vocoder_amd.noise import make_noise_tape, noise_width
+from tests._golden import CASE_NAMES, Case, load_layers
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+torch.set_num_threads(1)
+
+
+def build_model(kwargs):
+    kw = dict(kwargs)
+    return wnv.WaveNet(**kw).eval()
+
+
+@pytest.mark.parametrize("name", CASE_NAMES)
+@pytest.mark.parametrize("layout", ["wn", "fused"])
+def test_checkpoint_loads_and_batch_forward_matches_reference(name, layout):
+    c = Case(name)
+    m = build_model(c.kwargs)
+    missing = m.load_state_dict(getattr(c, layout), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    # state_dict layout == the reference's after make_generation_fast_()
+    sd = m.state_dict()
+    assert set(sd) == set(c.fused)
+    for k in sd:
+        assert sd[k].shape == c.fused[k].shape, k
+        assert torch.allclose(sd[k], c.fused[k], atol=1e-6, rtol=1e-6), k
+    scalar = c.kwargs.get("scalar_input", False)
+    with torch.no_grad():
+        y = m(c.get("x"), c=c.get("c_tf"), g=c.get("g_tf"), softmax=not scalar)
+    assert torch.allclose(y, c.get("fwd"), atol=5e-6), (y - c.get("fwd")).abs().max()
+
+
+def test_strict_loading_rejects_unknown_and_missing_keys():
+    c = Case("mol_local_global")
+    m = build_model(c.kwargs)
+    bad = dict(c.wn)
+    bad["conv_layers.0.bogus.weight"] = torch.zeros(1)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+    bad = dict(c.fused)
+    del bad["first_conv.bias"]
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(bad)
+
+
+def test_reference_surface():
+    m = wnv.WaveNet(out_channels=30, layers=24, stacks=4, residual_channels=128, gate_channels=256,
+                    skip_out_channels=128, cin_channels=80, scalar_input=True, dropout=0.0,
+                    upsample_conditional_features=True,
+                    upsample_params=dict(upsample_scales=[4, 4, 4, 4], cin_channels=80, cin_pad=2), cin_pad=2)
+    for attr in ("first_conv", "conv_layers", "last_conv_layers", "embed_speakers", "upsample_net",
+                 "receptive_field", "scalar_input", "out_channels", "cin_channels", "output_distribution"):
+        assert hasattr(m, attr)
+    assert m.receptive_field == 505 and not m.has_speaker_embedding() and m.local_conditioning_enabled()
+    assert sum(v.numel() for v in m.state_dict().values()) == 3702210
+    assert m.make_generation_fast_() is None
+    m.clear_buffer()
+    m.train()
+    with pytest.raises(RuntimeError, match="only supports eval mode"):
+        m.incremental_forward(c=torch.zeros(1, 80, 8), T=1024)
+    m.eval()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.incremental_forward(c=torch.zeros(1, 80, 8), T=1024)
+
+
+def test_receptive_field_known_answers():
+    assert wnv.receptive_field_size(30, 3, 3) == 6139
+    assert wnv.receptive_field_size(24, 4, 3) == 505
+    assert wnv.receptive_field_size(12, 2, 3) == 253
+    assert wnv.receptive_field_size(30, 1, 3, dilation=lambda x: 1) == 61
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "wnv.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(wnv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = header_functions()
+    assert len(names) >= 20
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"{n} declared in include/wnv.h but not exported"
+    assert sorted(_lib.EXPORTED_SYMBOLS) == names
+    assert _lib.lib().wnv_abi_version() == _lib.WNV_ABI_VERSION
+
+
+def test_pure_host_entry_points():
+    L = _lib.lib()
+    assert L.wnv_receptive_field(30, 3, 3) == 6139 and L.wnv_receptive_field(24, 4, 3) == 505
+    assert L.wnv_receptive_field(12, 2, 3) == 253 and L.wnv_receptive_field(5, 2, 3) == -1
+    base = dict(layers=4, stacks=2, residual_channels=8, gate_channels=8, skip_out_channels=8, kernel_size=3,
+                cin_channels=4, gin_channels=-1, n_speakers=None, use_speaker_embedding=False,
+                freq_axis_kernel_size=1)
+    cfg = make_config(out_channels=30, scalar_input=True, output_distribution="Logistic",
+                      upsample_net="ConvInUpsampleNetwork", upsample_scales=[4, 4, 4, 4], cin_pad=2, **base)
+    assert L.wnv_noise_width(ctypes.byref(cfg)) == 11 == noise_width(True, "Logistic", 30)
+    assert L.wnv_upsampled_length(ctypes.byref(cfg), 94 + 4) == 94 * 256
+    assert L.wnv_upsampled_length(ctypes.byref(cfg), 3) == -1
+    cfg = make_config(out_channels=2, scalar_input=True, output_distribution="Normal",
+                      upsample_net="UpsampleNetwork", upsample_scales=[2, 2, 2], cin_pad=1, **base)
+    assert L.wnv_noise_width(ctypes.byref(cfg)) == 1 == noise_width(True, "Normal", 2)
+    assert L.wnv_upsampled_length(ctypes.byref(cfg), 7) == 7 * 8 - 2 * 8
+    cfg = make_config(out_channels=256, scalar_input=False, output_distribution="Logistic",
+                      upsample_net=None, upsample_scales=[], cin_pad=0, **base)
+    assert L.wnv_noise_width(ctypes.byref(cfg)) == 256 == noise_width(False, "Logistic", 256)
+    assert L.wnv_upsampled_length(ctypes.byref(cfg), 123) == 123
+
+
+def test_noise_tape_replays_the_reference_stream():
+    """The fixtures carry tapes made by this same function at generation time, checked there against the
+    real reference's samplers; here: determinism under the seed and layout."""
+    c = Case("mol_local_global")
+    torch.manual_seed(c.meta["seed"] + 2)
+    tape = make_noise_tape(c.meta["Tf"], c.get("fr_tape").shape[1], scalar_input=True,
+                           output_distribution="Logistic", out_channels=30)
+    assert torch.equal(tape, c.get("fr_tape"))
+    c = Case("onehot_nocond")
+    torch.manual_seed(c.meta["seed"] + 2)
+    tape = make_noise_tape(c.meta["Tf"], 1, scalar_input=False, output_distribution="Logistic", out_channels=256)
+    assert torch.equal(tape, c.get("fr_tape"))
+    assert tape.min() > 0
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "wavenet_vocoder_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "wavenet_oracle" not in txt, f
+                assert "/root/reference" not in txt, f

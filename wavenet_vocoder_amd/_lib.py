@@ -1,0 +1,131 @@
+"""ctypes binding of ``libwnv_hip.so`` (the C ABI declared in ``include/wnv.h``).
+
+This is the whole "FFI stub" a maintainer of the reference would need (INTEGRATION.md shows it grafted
+into ``wavenet_vocoder/wavenet.py``).  There is deliberately no fallback: if the shared library is
+missing or was built for another ABI the import of the engine raises, it never silently runs on CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+__all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "LIB_PATH",
+           "WNV_ABI_VERSION", "DIST", "UPSAMPLE"]
+
+WNV_ABI_VERSION = 1
+WNV_MAX_UPSAMPLE_STAGES = 8
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwnv_hip.so")
+
+DIST = {"categorical": 0, "Logistic": 1, "Normal": 2}
+UPSAMPLE = {None: 0, "none": 0, "ConvInUpsampleNetwork": 1, "UpsampleNetwork": 2}
+
+# status codes -> Python exceptions (include/wnv.h "Conventions")
+_STATUS_EXC = {
+    1: ValueError,          # WNV_ERR_INVALID_ARG
+    2: RuntimeError,        # WNV_ERR_NOT_LOADED
+    3: RuntimeError,        # WNV_ERR_HIP
+    4: AssertionError,      # WNV_ERR_SHAPE         (reference: assert c.size(-1) == T, wavenet.py:276)
+    5: NotImplementedError, # WNV_ERR_UNSUPPORTED
+    6: TimeoutError,        # WNV_ERR_TIMEOUT
+    7: RuntimeError,        # WNV_ERR_TRAINING_MODE (reference: conv.py:19-20)
+}
+
+
+class WnvError(RuntimeError):
+    pass
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("out_channels", C.c_int32), ("layers", C.c_int32), ("stacks", C.c_int32),
+        ("residual_channels", C.c_int32), ("gate_channels", C.c_int32), ("skip_out_channels", C.c_int32),
+        ("kernel_size", C.c_int32), ("cin_channels", C.c_int32), ("gin_channels", C.c_int32),
+        ("n_speakers", C.c_int32), ("use_speaker_embedding", C.c_int32), ("scalar_input", C.c_int32),
+        ("output_distribution", C.c_int32), ("upsample_kind", C.c_int32), ("n_upsample_scales", C.c_int32),
+        ("upsample_scales", C.c_int32 * WNV_MAX_UPSAMPLE_STAGES), ("freq_axis_kernel_size", C.c_int32),
+        ("cin_pad", C.c_int32), ("reserved", C.c_int32 * 8),
+    ]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class GenerateArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int64), ("c_up", C.c_void_p), ("g", C.c_void_p), ("g_ids", C.c_void_p),
+        ("initial", C.c_void_p), ("teacher", C.c_void_p), ("Tt", C.c_int64), ("noise", C.c_void_p),
+        ("seed", C.c_uint64), ("softmax", C.c_int32), ("quantize", C.c_int32), ("out", C.c_void_p),
+        ("params_out", C.c_void_p), ("index_out", C.c_void_p), ("kernel", C.c_int32), ("stream", C.c_void_p),
+    ]
+
+
+class GluConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("residual_channels", "gate_channels", "kernel_size",
+                                         "skip_out_channels", "cin_channels", "gin_channels", "dilation",
+                                         "bias")]
+
+
+_PROTOS = {
+    # name: (restype, argtypes)
+    "wnv_abi_version": (C.c_int32, []),
+    "wnv_last_error": (C.c_char_p, []),
+    "wnv_create": (C.c_int, [C.POINTER(Config), C.c_int32, C.POINTER(C.c_void_p)]),
+    "wnv_destroy": (C.c_int, [C.c_void_p]),
+    "wnv_load_weights": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.c_int32]),
+    "wnv_receptive_field": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "wnv_noise_width": (C.c_int32, [C.POINTER(Config)]),
+    "wnv_upsampled_length": (C.c_int64, [C.POINTER(Config), C.c_int64]),
+    "wnv_upsample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
+    "wnv_generate": (C.c_int, [C.c_void_p, C.POINTER(GenerateArgs)]),
+    "wnv_reset": (C.c_int, [C.c_void_p]),
+    "wnv_qconv_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "wnv_qconv_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wnv_qconv_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "wnv_qconv_reset": (C.c_int, [C.c_void_p]),
+    "wnv_qconv_destroy": (C.c_int, [C.c_void_p]),
+    "wnv_glu_create": (C.c_int, [C.POINTER(GluConfig), C.c_int32, C.POINTER(C.c_void_p)]),
+    "wnv_glu_load_weights": (C.c_int, [C.c_void_p, C.POINTER(Tensor), C.c_int32]),
+    "wnv_glu_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "wnv_glu_reset": (C.c_int, [C.c_void_p]),
+    "wnv_glu_destroy": (C.c_int, [C.c_void_p]),
+    "wnv_bytes_per_step": (C.c_int64, [C.c_void_p, C.c_int32]),
+    "wnv_macs_per_sample": (C.c_int64, [C.c_void_p]),
+}
+
+EXPORTED_SYMBOLS = tuple(sorted(_PROTOS))
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WnvError(
+            f"{LIB_PATH} is missing: the HIP engine has not been built.  Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or `python -m wavenet_vocoder_amd.build`) "
+            f"at the repo root.  There is no CPU fallback for the synthesis path.")
+    handle = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _PROTOS.items():
+        try:
+            fn = getattr(handle, name)
+        except AttributeError as e:  # pragma: no cover
+            raise WnvError(f"{LIB_PATH} does not export {name}; rebuild it") from e
+        fn.restype = res
+        fn.argtypes = args
+    if handle.wnv_abi_version() != WNV_ABI_VERSION:
+        raise WnvError(f"{LIB_PATH} has ABI {handle.wnv_abi_version()}, this package needs {WNV_ABI_VERSION}")
+    _lib = handle
+    return handle
+
+
+def check(status: int) -> None:
+    if status == 0:
+        return
+    msg = lib().wnv_last_error()
+    msg = msg.decode("utf-8", "replace") if msg else f"wnv status {status}"
+    raise _STATUS_EXC.get(status, WnvError)(msg)

@@ -1,0 +1,454 @@
+// wnv_host.cpp -- the C ABI of include/wnv.h: handle life cycle, state_dict ingestion (weight-norm fold,
+// conv.py:51-62 linearisation, K-major re-layout), scratch management and kernel dispatch.
+// Compiled by hipcc together with the kernel translation units into libwnv_hip.so; no torch dependency.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/wnv.h"
+#include "wnv_internal.h"
+#include "wnv_store.h"
+#include "wnv_ring.h"
+
+#include "wnv_hostutil.h"
+
+struct wnv_engine {
+    wnv_config cfg{};
+    int device = 0;
+    TensorStore store;
+    bool packed = false;
+    // generic-kernel pack
+    WnvModelDev m{};
+    std::vector<WnvLayerDev> layers;
+    float* d_W = nullptr;
+    WnvLayerDev* d_layers = nullptr;
+    size_t w_floats = 0;
+    // upsampler weights (device): conv_in then the per-stage FIRs
+    float* d_up = nullptr;
+    std::vector<long long> up_off;     // offsets: [0] conv_in (or -1), [1+i] stage i
+    long long embed_off = -1;          // inside d_W
+    int64_t core_weights = 0;          // unpadded parameter count of the sample-loop network (with biases)
+    int64_t core_macs = 0;
+    Scratch ring, zbias, upA, upB;
+    WnvRingState* ring_state = nullptr;   // pipelined kernel (wnv_ring.hip), built lazily
+};
+
+static std::vector<int> dilations_of(const wnv_config& c) {
+    std::vector<int> d(c.layers);
+    const int per = c.layers / c.stacks;
+    for (int i = 0; i < c.layers; ++i) d[i] = 1 << (i % per);      // wavenet.py:125-126
+    return d;
+}
+
+static std::vector<Expect> expected_tensors(const wnv_config& c) {
+    std::vector<Expect> e;
+    const int64_t R = c.residual_channels, G = c.gate_channels, K = c.skip_out_channels, O = c.out_channels;
+    const int64_t kw = c.kernel_size, cin1 = c.scalar_input ? 1 : O;
+    e.push_back({"first_conv.weight", {R, cin1, 1}});
+    e.push_back({"first_conv.bias", {R}});
+    for (int l = 0; l < c.layers; ++l) {
+        const std::string p = "conv_layers." + std::to_string(l) + ".";
+        e.push_back({p + "conv.weight", {G, R, kw}});
+        e.push_back({p + "conv.bias", {G}});
+        if (c.cin_channels > 0) e.push_back({p + "conv1x1c.weight", {G, c.cin_channels, 1}});
+        if (c.gin_channels > 0) e.push_back({p + "conv1x1g.weight", {G, c.gin_channels, 1}});
+        e.push_back({p + "conv1x1_out.weight", {R, G / 2, 1}});
+        e.push_back({p + "conv1x1_out.bias", {R}});
+        e.push_back({p + "conv1x1_skip.weight", {K, G / 2, 1}});
+        e.push_back({p + "conv1x1_skip.bias", {K}});
+    }
+    e.push_back({"last_conv_layers.1.weight", {K, K, 1}});
+    e.push_back({"last_conv_layers.1.bias", {K}});
+    e.push_back({"last_conv_layers.3.weight", {O, K, 1}});
+    e.push_back({"last_conv_layers.3.bias", {O}});
+    if (c.gin_channels > 0 && c.use_speaker_embedding)
+        e.push_back({"embed_speakers.weight", {c.n_speakers, c.gin_channels}});
+    if (c.upsample_kind != WNV_UPSAMPLE_NONE && c.cin_channels > 0) {
+        std::string pre = "upsample_net.up_layers.";
+        if (c.upsample_kind == WNV_UPSAMPLE_CONVIN) {
+            e.push_back({"upsample_net.conv_in.weight", {c.cin_channels, c.cin_channels, 2 * c.cin_pad + 1}});
+            pre = "upsample_net.upsample.up_layers.";
+        }
+        for (int i = 0; i < c.n_upsample_scales; ++i)
+            e.push_back({pre + std::to_string(2 * i + 1) + ".weight",
+                         {1, 1, c.freq_axis_kernel_size, 2 * c.upsample_scales[i] + 1}});
+    }
+    return e;
+}
+
+static wnv_status validate_config(const wnv_config* c) {
+    if (!c) return fail(WNV_ERR_INVALID_ARG, "config is NULL");
+    if (c->abi_version != WNV_ABI_VERSION) return fail(WNV_ERR_INVALID_ARG, "abi_version %d != %d", c->abi_version, WNV_ABI_VERSION);
+    if (c->layers <= 0 || c->stacks <= 0 || c->layers % c->stacks != 0)
+        return fail(WNV_ERR_INVALID_ARG, "layers (%d) must be a positive multiple of stacks (%d)", c->layers, c->stacks);
+    if (c->layers > WNV_MAX_LAYERS) return fail(WNV_ERR_UNSUPPORTED, "layers %d > %d", c->layers, WNV_MAX_LAYERS);
+    if (c->layers / c->stacks > 24) return fail(WNV_ERR_UNSUPPORTED, "dilation 2^%d is too large", c->layers / c->stacks - 1);
+    if (c->residual_channels <= 0 || c->gate_channels <= 0 || c->gate_channels % 2 || c->skip_out_channels <= 0 || c->out_channels <= 0)
+        return fail(WNV_ERR_INVALID_ARG, "channel counts must be positive and gate_channels even");
+    if (c->kernel_size < 1 || c->kernel_size > 16) return fail(WNV_ERR_UNSUPPORTED, "kernel_size %d outside [1,16]", c->kernel_size);
+    if (c->output_distribution < 0 || c->output_distribution > 2) return fail(WNV_ERR_INVALID_ARG, "unknown output_distribution %d", c->output_distribution);
+    if (c->scalar_input && c->output_distribution == WNV_DIST_CATEGORICAL)
+        return fail(WNV_ERR_INVALID_ARG, "scalar_input requires Logistic or Normal output");   // wavenet.py:330 assert False
+    if (!c->scalar_input && c->output_distribution != WNV_DIST_CATEGORICAL)
+        ;  // the reference ignores output_distribution for one-hot input (wavenet.py:331-335)
+    if (c->scalar_input) {
+        const int O = c->out_channels;
+        if (c->output_distribution == WNV_DIST_LOGISTIC && O % 3) return fail(WNV_ERR_INVALID_ARG, "Logistic needs out_channels %% 3 == 0 (mixture.py:130)");
+        if (c->output_distribution == WNV_DIST_NORMAL && O != 2 && O % 3) return fail(WNV_ERR_INVALID_ARG, "Normal needs out_channels == 2 or %% 3 == 0 (mixture.py:234)");
+    }
+    if (c->residual_channels + c->skip_out_channels > WNV_GENERIC_THREADS || c->gate_channels / 2 > WNV_GENERIC_THREADS ||
+        c->out_channels > WNV_GENERIC_THREADS)
+        return fail(WNV_ERR_UNSUPPORTED, "residual+skip, gate/2 and out channels must each be <= %d", WNV_GENERIC_THREADS);
+    if (c->upsample_kind < 0 || c->upsample_kind > 2) return fail(WNV_ERR_INVALID_ARG, "unknown upsample_kind");
+    if (c->upsample_kind != WNV_UPSAMPLE_NONE) {
+        if (c->n_upsample_scales < 0 || c->n_upsample_scales > WNV_MAX_UPSAMPLE_STAGES) return fail(WNV_ERR_INVALID_ARG, "n_upsample_scales");
+        if (c->freq_axis_kernel_size != 1) return fail(WNV_ERR_UNSUPPORTED, "freq_axis_kernel_size != 1 is not implemented");
+        for (int i = 0; i < c->n_upsample_scales; ++i)
+            if (c->upsample_scales[i] < 1) return fail(WNV_ERR_INVALID_ARG, "upsample scale < 1");
+    }
+    if (c->gin_channels > 0 && c->use_speaker_embedding && c->n_speakers <= 0)
+        return fail(WNV_ERR_INVALID_ARG, "use_speaker_embedding needs n_speakers (wavenet.py:144)");
+    return WNV_OK;
+}
+
+extern "C" int32_t wnv_abi_version(void) { return WNV_ABI_VERSION; }
+thread_local std::string wnv_g_err;
+extern "C" const char* wnv_last_error(void) { return wnv_g_err.c_str(); }
+
+extern "C" int64_t wnv_receptive_field(int32_t layers, int32_t stacks, int32_t kernel_size) {
+    if (layers <= 0 || stacks <= 0 || layers % stacks) return -1;
+    const int per = layers / stacks;
+    int64_t sum = 0;
+    for (int i = 0; i < layers; ++i) sum += (int64_t)1 << (i % per);
+    return (int64_t)(kernel_size - 1) * sum + 1;                               // wavenet.py:42-60
+}
+
+extern "C" int32_t wnv_noise_width(const wnv_config* c) {
+    if (!c) return -1;
+    if (!c->scalar_input) return c->out_channels;
+    if (c->output_distribution == WNV_DIST_LOGISTIC) return c->out_channels / 3 + 1;
+    if (c->output_distribution == WNV_DIST_NORMAL) return (c->out_channels == 2 || c->out_channels == 3) ? 1 : c->out_channels / 3 + 1;
+    return -1;
+}
+
+extern "C" int64_t wnv_upsampled_length(const wnv_config* c, int64_t Tc_in) {
+    if (!c || Tc_in < 0) return -1;
+    if (c->upsample_kind == WNV_UPSAMPLE_NONE) return Tc_in;
+    int64_t total = 1;
+    for (int i = 0; i < c->n_upsample_scales; ++i) total *= c->upsample_scales[i];
+    if (c->upsample_kind == WNV_UPSAMPLE_CONVIN) {
+        const int64_t frames = Tc_in - 2 * c->cin_pad;                         // valid conv, k = 2*cin_pad+1
+        return frames <= 0 ? -1 : frames * total;
+    }
+    const int64_t t = Tc_in * total - 2 * (int64_t)c->cin_pad * total;        // upsample.py:36,64-65
+    return t <= 0 ? -1 : t;
+}
+
+extern "C" wnv_status wnv_create(const wnv_config* cfg, int32_t device, wnv_handle* out) {
+    if (!out) return fail(WNV_ERR_INVALID_ARG, "out handle is NULL");
+    *out = nullptr;
+    wnv_status st = validate_config(cfg);
+    if (st != WNV_OK) return st;
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(WNV_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
+    wnv_engine* h = new wnv_engine();
+    h->cfg = *cfg;
+    h->device = device;
+    *out = h;
+    return WNV_OK;
+}
+
+static void free_dev(wnv_engine* h) {
+    if (h->d_W) (void)hipFree(h->d_W);
+    if (h->d_layers) (void)hipFree(h->d_layers);
+    if (h->d_up) (void)hipFree(h->d_up);
+    h->d_W = nullptr; h->d_layers = nullptr; h->d_up = nullptr;
+    if (h->ring_state) { wnv_ring_destroy(h->ring_state); h->ring_state = nullptr; }
+    h->packed = false;
+}
+
+extern "C" wnv_status wnv_destroy(wnv_handle h) {
+    if (!h) return WNV_OK;
+    DeviceGuard g(h->device);
+    free_dev(h);
+    h->ring.release(); h->zbias.release(); h->upA.release(); h->upB.release();
+    delete h;
+    return WNV_OK;
+}
+
+extern "C" wnv_status wnv_reset(wnv_handle h) {
+    if (!h) return fail(WNV_ERR_INVALID_ARG, "handle is NULL");
+    DeviceGuard g(h->device);
+    HIP_TRY(hipDeviceSynchronize());
+    h->ring.release(); h->zbias.release(); h->upA.release(); h->upB.release();
+    return WNV_OK;
+}
+
+static wnv_status pack(wnv_engine* h) {
+    const wnv_config& c = h->cfg;
+    const auto exp = expected_tensors(c);
+    for (const auto& e : exp) {
+        const HostTensor* t = h->store.get(e.name);
+        if (!t) return fail(WNV_ERR_NOT_LOADED, "missing tensor '%s'", e.name.c_str());
+        if (!shape_eq(t->shape, e.shape)) {
+            std::string got, want;
+            for (auto s : t->shape) got += std::to_string(s) + ",";
+            for (auto s : e.shape) want += std::to_string(s) + ",";
+            return fail(WNV_ERR_INVALID_ARG, "size mismatch for %s: got (%s) expected (%s)", e.name.c_str(), got.c_str(), want.c_str());
+        }
+    }
+    DeviceGuard g(h->device);
+    free_dev(h);
+    const int R = c.residual_channels, G = c.gate_channels, K = c.skip_out_channels, O = c.out_channels;
+    const int kw = c.kernel_size, cin = c.cin_channels > 0 ? c.cin_channels : 0, gin = c.gin_channels > 0 ? c.gin_channels : 0;
+    const int cin1 = c.scalar_input ? 1 : O, L = c.layers, H = G / 2;
+    WnvModelDev& m = h->m;
+    memset(&m, 0, sizeof m);
+    m.L = L; m.R = R; m.G = G; m.K = K; m.O = O; m.kw = kw; m.cin = cin; m.gin = gin; m.cin1 = cin1;
+    m.scalar_input = c.scalar_input; m.dist = c.scalar_input ? c.output_distribution : WNV_DIST_CATEGORICAL;
+    m.Rp = pad4(R); m.Gp = pad4(G); m.NOSp = pad4(R + K); m.Kp = pad4(K); m.Op = pad4(O);
+    m.nr_mix = (c.scalar_input && O % 3 == 0) ? O / 3 : 0;
+    m.skip_scale = (float)std::sqrt(1.0 / L);
+    Blob b;
+    auto T = [&](const std::string& n) -> const HostTensor& { return *h->store.get(n); };
+    m.w_first = b.alloc((size_t)cin1 * m.Rp);
+    put_kmajor(b, m.w_first, m.Rp, 0, T("first_conv.weight"), 0);
+    m.b_first = b.alloc(m.Rp);
+    std::copy(T("first_conv.bias").data.begin(), T("first_conv.bias").data.end(), b.v.begin() + m.b_first);
+    const auto dil = dilations_of(c);
+    h->layers.assign(L, WnvLayerDev{});
+    long long ring_off = 0;
+    int64_t weights = (int64_t)R * cin1 + R, macs = (int64_t)R * cin1;
+    for (int l = 0; l < L; ++l) {
+        const std::string p = "conv_layers." + std::to_string(l) + ".";
+        WnvLayerDev& Ld = h->layers[l];
+        Ld.dilation = dil[l];
+        Ld.ring_rows = (kw - 1) * dil[l];
+        Ld.ring_off = ring_off;
+        ring_off += (long long)Ld.ring_rows * R;
+        const int Kin = kw * R + cin;
+        Ld.w_in = b.alloc((size_t)Kin * m.Gp);
+        put_kmajor(b, Ld.w_in, m.Gp, 0, T(p + "conv.weight"), 0);
+        if (cin > 0) put_kmajor(b, Ld.w_in, m.Gp, 0, T(p + "conv1x1c.weight"), kw * R);
+        Ld.b_in = b.alloc(m.Gp);
+        std::copy(T(p + "conv.bias").data.begin(), T(p + "conv.bias").data.end(), b.v.begin() + Ld.b_in);
+        Ld.w_g = -1;
+        if (gin > 0) {
+            Ld.w_g = b.alloc((size_t)gin * m.Gp);
+            put_kmajor(b, Ld.w_g, m.Gp, 0, T(p + "conv1x1g.weight"), 0);
+        }
+        Ld.w_os = b.alloc((size_t)H * m.NOSp);
+        put_kmajor(b, Ld.w_os, m.NOSp, 0, T(p + "conv1x1_out.weight"), 0);
+        put_kmajor(b, Ld.w_os, m.NOSp, R, T(p + "conv1x1_skip.weight"), 0);
+        Ld.b_os = b.alloc(m.NOSp);
+        std::copy(T(p + "conv1x1_out.bias").data.begin(), T(p + "conv1x1_out.bias").data.end(), b.v.begin() + Ld.b_os);
+        std::copy(T(p + "conv1x1_skip.bias").data.begin(), T(p + "conv1x1_skip.bias").data.end(), b.v.begin() + Ld.b_os + R);
+        weights += (int64_t)G * R * kw + G + (int64_t)G * cin + (int64_t)G * gin + (int64_t)R * H + R + (int64_t)K * H + K;
+        macs += (int64_t)G * R * kw + (int64_t)G * cin + (int64_t)R * H + (int64_t)K * H;   // Wg.g is hoisted
+    }
+    m.ring_floats = ring_off;
+    m.w_h1 = b.alloc((size_t)K * m.Kp);
+    put_kmajor(b, m.w_h1, m.Kp, 0, T("last_conv_layers.1.weight"), 0);
+    m.b_h1 = b.alloc(m.Kp);
+    std::copy(T("last_conv_layers.1.bias").data.begin(), T("last_conv_layers.1.bias").data.end(), b.v.begin() + m.b_h1);
+    m.w_h2 = b.alloc((size_t)K * m.Op);
+    put_kmajor(b, m.w_h2, m.Op, 0, T("last_conv_layers.3.weight"), 0);
+    m.b_h2 = b.alloc(m.Op);
+    std::copy(T("last_conv_layers.3.bias").data.begin(), T("last_conv_layers.3.bias").data.end(), b.v.begin() + m.b_h2);
+    weights += (int64_t)K * K + K + (int64_t)O * K + O;
+    macs += (int64_t)K * K + (int64_t)O * K;
+    h->embed_off = -1;
+    if (gin > 0 && c.use_speaker_embedding) {
+        const HostTensor& e = T("embed_speakers.weight");
+        h->embed_off = b.alloc(e.data.size());
+        std::copy(e.data.begin(), e.data.end(), b.v.begin() + h->embed_off);
+    }
+    h->core_weights = weights;
+    h->core_macs = macs;
+    // LDS carve for the generic kernel
+    const int nz = wnv_noise_width(&c);
+    m.lds_xin = pad4(kw * R + cin);
+    m.lds_u = pad4(std::max(H, K));
+    m.lds_o = pad4(std::max(O, 4));
+    m.lds_vin = pad4(std::max(cin1, 4));
+    m.lds_nz = pad4(std::max(nz, 4));
+    m.lds_part_stride = std::max(std::max(m.Gp, m.NOSp), std::max(std::max(m.Rp, m.Kp), m.Op));
+    m.lds_taps = L * (kw - 1) * R;
+    m.taps_in_lds = 1;
+    if (wnv_generic_lds_bytes(m) > 150 * 1024) { m.lds_taps = 0; m.taps_in_lds = 0; }
+    m.lds_taps = pad4(m.lds_taps);
+    if (wnv_generic_lds_bytes(m) > 160 * 1024)
+        return fail(WNV_ERR_UNSUPPORTED, "configuration needs %zu bytes of LDS (> 160 KiB)", wnv_generic_lds_bytes(m));
+    // upload
+    h->w_floats = b.v.size();
+    HIP_TRY(hipMalloc((void**)&h->d_W, std::max<size_t>(b.v.size(), 4) * sizeof(float)));
+    HIP_TRY(hipMemcpy(h->d_W, b.v.data(), b.v.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&h->d_layers, L * sizeof(WnvLayerDev)));
+    HIP_TRY(hipMemcpy(h->d_layers, h->layers.data(), L * sizeof(WnvLayerDev), hipMemcpyHostToDevice));
+    // upsampler
+    h->up_off.clear();
+    if (c.upsample_kind != WNV_UPSAMPLE_NONE && cin > 0) {
+        std::vector<float> u;
+        std::string pre = "upsample_net.up_layers.";
+        if (c.upsample_kind == WNV_UPSAMPLE_CONVIN) {
+            const HostTensor& w = T("upsample_net.conv_in.weight");
+            h->up_off.push_back(0);
+            u.insert(u.end(), w.data.begin(), w.data.end());
+            pre = "upsample_net.upsample.up_layers.";
+        } else {
+            h->up_off.push_back(-1);
+        }
+        for (int i = 0; i < c.n_upsample_scales; ++i) {
+            const HostTensor& w = T(pre + std::to_string(2 * i + 1) + ".weight");
+            h->up_off.push_back((long long)u.size());
+            u.insert(u.end(), w.data.begin(), w.data.end());
+        }
+        HIP_TRY(hipMalloc((void**)&h->d_up, std::max<size_t>(u.size(), 4) * sizeof(float)));
+        HIP_TRY(hipMemcpy(h->d_up, u.data(), u.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    h->packed = true;
+    return WNV_OK;
+}
+
+extern "C" wnv_status wnv_load_weights(wnv_handle h, const wnv_tensor* tensors, int32_t n) {
+    if (!h || (!tensors && n > 0) || n < 0) return fail(WNV_ERR_INVALID_ARG, "bad arguments to wnv_load_weights");
+    const auto exp = expected_tensors(h->cfg);
+    for (int i = 0; i < n; ++i) {
+        const wnv_tensor& t = tensors[i];
+        if (!t.name || !t.data || t.ndim < 1 || t.ndim > 4) return fail(WNV_ERR_INVALID_ARG, "tensor %d is malformed", i);
+        std::string name = t.name;
+        std::string base = name;
+        if (ends_with(name, "weight_g") || ends_with(name, "weight_v")) base = name.substr(0, name.size() - 2);
+        bool known = false;
+        for (const auto& e : exp) if (e.name == base) { known = true; break; }
+        if (!known) return fail(WNV_ERR_INVALID_ARG, "unexpected key '%s' in state_dict", t.name);
+        h->store.put(t);
+    }
+    return pack(h);
+}
+
+extern "C" int64_t wnv_bytes_per_step(wnv_handle h, int32_t B) {
+    if (!h || !h->packed) return -1;
+    const wnv_config& c = h->cfg;
+    const int64_t cin = c.cin_channels > 0 ? c.cin_channels : 0;
+    // every weight once per step per utterance group + per utterance the kw ring taps read and the
+    // one row written per layer, the conditioning row and the emitted sample
+    int64_t wbytes = h->core_weights;
+    if (c.gin_channels > 0) wbytes -= (int64_t)c.layers * c.gate_channels * c.gin_channels;   // hoisted out of the loop
+    return wbytes * 4 + (int64_t)B * ((int64_t)c.layers * (c.kernel_size + 1) * c.residual_channels * 4 + cin * 4 + 4);
+}
+
+extern "C" int64_t wnv_macs_per_sample(wnv_handle h) { return (h && h->packed) ? h->core_macs : -1; }
+
+// ------------------------------------------------------------------------------------------------
+// upsampling prologue
+// ------------------------------------------------------------------------------------------------
+extern "C" wnv_status wnv_upsample(wnv_handle h, const float* c_in, int32_t B, int64_t Tc_in, float* c_up,
+                                   int64_t T_expected, void* stream) {
+    if (!h || !c_in || !c_up || B <= 0 || Tc_in <= 0) return fail(WNV_ERR_INVALID_ARG, "bad arguments to wnv_upsample");
+    if (!h->packed) return fail(WNV_ERR_NOT_LOADED, "weights are not loaded");
+    const wnv_config& c = h->cfg;
+    if (c.cin_channels <= 0) return fail(WNV_ERR_INVALID_ARG, "model has no local conditioning");
+    const int64_t T = wnv_upsampled_length(&c, Tc_in);
+    if (T <= 0) return fail(WNV_ERR_SHAPE, "conditioning of %lld frames is too short", (long long)Tc_in);
+    if (T_expected >= 0 && T != T_expected)
+        return fail(WNV_ERR_SHAPE, "upsampled conditioning length %lld != T %lld (wavenet.py:276)", (long long)T, (long long)T_expected);
+    DeviceGuard g(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int cin = c.cin_channels;
+    if (c.upsample_kind == WNV_UPSAMPLE_NONE) {
+        HIP_TRY(wnv_launch_transpose_bct(c_in, c_up, B, cin, Tc_in, s));
+        return WNV_OK;
+    }
+    const float* cur = c_in;
+    int64_t Tcur = Tc_in;
+    float* bufs[2];
+    // largest intermediate: the input of the last stage
+    int64_t total = 1;
+    for (int i = 0; i < c.n_upsample_scales; ++i) total *= c.upsample_scales[i];
+    const size_t inter = (size_t)B * cin * (size_t)(Tc_in * total) * sizeof(float);
+    HIP_TRY(h->upA.ensure(inter));
+    HIP_TRY(h->upB.ensure(inter));
+    bufs[0] = (float*)h->upA.p; bufs[1] = (float*)h->upB.p;
+    int which = 0;
+    if (c.upsample_kind == WNV_UPSAMPLE_CONVIN) {
+        const int ks = 2 * c.cin_pad + 1;
+        HIP_TRY(wnv_launch_conv_in(cur, h->d_up + h->up_off[0], bufs[which], B, cin, (int)Tcur, ks, s));
+        cur = bufs[which]; which ^= 1;
+        Tcur = Tcur - ks + 1;
+    }
+    if (c.n_upsample_scales == 0) {
+        HIP_TRY(wnv_launch_transpose_bct(cur, c_up, B, cin, Tcur, s));
+        return WNV_OK;
+    }
+    for (int i = 0; i < c.n_upsample_scales; ++i) {
+        const bool last = i == c.n_upsample_scales - 1;
+        const int sc = c.upsample_scales[i];
+        const long long indent = (last && c.upsample_kind == WNV_UPSAMPLE_PLAIN) ? (long long)c.cin_pad * total : 0;
+        float* dst = last ? c_up : bufs[which];
+        HIP_TRY(wnv_launch_stretch_fir(cur, h->d_up + h->up_off[1 + i], dst, B, cin, Tcur, sc, last ? 1 : 0, indent, s));
+        cur = dst; which ^= 1;
+        Tcur *= sc;
+    }
+    return WNV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the hot loop
+// ------------------------------------------------------------------------------------------------
+extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
+    if (!h || !a) return fail(WNV_ERR_INVALID_ARG, "NULL handle or args");
+    if (!h->packed) return fail(WNV_ERR_NOT_LOADED, "weights are not loaded");
+    const wnv_config& c = h->cfg;
+    const WnvModelDev& m = h->m;
+    if (a->B <= 0 || a->T <= 0 || a->T > 0x7fffffffLL) return fail(WNV_ERR_INVALID_ARG, "B and T must be positive (T < 2^31)");
+    if (!a->out) return fail(WNV_ERR_INVALID_ARG, "out is NULL");
+    if (m.cin > 0 && !a->c_up) return fail(WNV_ERR_INVALID_ARG, "model has local conditioning but c_up is NULL");
+    if (m.cin == 0 && a->c_up) return fail(WNV_ERR_INVALID_ARG, "c_up given but the model has no local conditioning");
+    if (m.gin > 0 && !a->g && !a->g_ids) return fail(WNV_ERR_INVALID_ARG, "model has global conditioning but neither g nor g_ids is given");
+    if (m.gin == 0 && (a->g || a->g_ids)) return fail(WNV_ERR_INVALID_ARG, "g given but the model has no global conditioning");
+    if (a->g_ids && !a->g && h->embed_off < 0) return fail(WNV_ERR_INVALID_ARG, "g_ids given but the model has no speaker embedding");
+    if (a->Tt < 0 || a->Tt > a->T || (a->Tt > 0 && !a->teacher)) return fail(WNV_ERR_INVALID_ARG, "bad teacher-forcing arguments");
+    if (a->kernel < 0 || a->kernel > 2) return fail(WNV_ERR_INVALID_ARG, "unknown kernel selector %d", a->kernel);
+    DeviceGuard g(h->device);
+    hipStream_t s = (hipStream_t)a->stream;
+    const bool has_g = m.gin > 0;
+    const int Bz = has_g ? a->B : 1;
+    HIP_TRY(h->zbias.ensure((size_t)Bz * m.L * m.Gp * sizeof(float)));
+    HIP_TRY(wnv_launch_zbias(m, h->d_layers, h->d_W, has_g ? a->g : nullptr, (has_g && !a->g) ? (const long long*)a->g_ids : nullptr,
+                             h->embed_off >= 0 ? h->d_W + h->embed_off : nullptr, Bz, (float*)h->zbias.p, s));
+    if (!c.scalar_input && a->quantize)
+        HIP_TRY(hipMemsetAsync(a->out, 0, (size_t)a->B * m.O * (size_t)a->T * sizeof(float), s));
+
+    WnvGenArgs ga{};
+    ga.B = a->B; ga.T = a->T; ga.Tt = a->teacher ? a->Tt : 0;
+    ga.c_up = a->c_up; ga.initial = a->initial; ga.teacher = a->teacher; ga.noise = a->noise;
+    ga.zbias = (const float*)h->zbias.p; ga.zbias_bstride = has_g ? (long long)m.L * m.Gp : 0;
+    ga.seed = a->seed; ga.softmax = a->softmax; ga.quantize = c.scalar_input ? 1 : a->quantize;
+    ga.nz = wnv_noise_width(&c);
+    ga.out = a->out; ga.params_out = a->params_out; ga.index_out = a->index_out;
+
+    int kernel = a->kernel;
+    if (kernel == 0) kernel = wnv_ring_supported(c, a->B) ? 2 : 1;
+    if (kernel == 2) {
+        if (!wnv_ring_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the pipelined ring kernel does not cover this configuration: %s", wnv_ring_why_not(c, a->B));
+        std::string err;
+        wnv_status st = wnv_ring_generate(&h->ring_state, h->device, c, h->store, ga, s, err);
+        if (st != WNV_OK) return fail(st, "%s", err.c_str());
+        return WNV_OK;
+    }
+    const size_t ring_bytes = std::max<size_t>((size_t)a->B * m.ring_floats * sizeof(float), 16);
+    HIP_TRY(h->ring.ensure(ring_bytes));
+    HIP_TRY(hipMemsetAsync(h->ring.p, 0, ring_bytes, s));                       // history before t = 0 is zero (conv.py:34-36)
+    ga.ring = (float*)h->ring.p;
+    HIP_TRY(wnv_launch_generate_generic(m, h->d_layers, h->d_W, ga, s));
+    return WNV_OK;
+}

@@ -1,0 +1,19 @@
+// wnv_ring.h -- host interface of the pipelined ring kernel (wnv_ring.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/wnv.h"
+#include "wnv_dev.h"
+#include "wnv_store.h"
+
+struct WnvRingState;
+
+// Can the ring kernel run this configuration with B utterances in flight?
+bool wnv_ring_supported(const wnv_config& c, int B);
+const char* wnv_ring_why_not(const wnv_config& c, int B);
+// Builds (once) the ring-specific weight images from the fused host tensors and runs the whole loop.
+wnv_status wnv_ring_generate(WnvRingState** st, int device, const wnv_config& c, const TensorStore& store,
+                             const WnvGenArgs& ga, hipStream_t s, std::string& err);
+void wnv_ring_destroy(WnvRingState* st);

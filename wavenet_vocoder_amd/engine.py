@@ -1,0 +1,240 @@
+"""Thin object wrappers over the C ABI handles (``include/wnv.h``): ``Engine`` (whole network),
+``QueueConv`` (conv.Conv1d.incremental_forward) and ``GluLayer`` (ResidualConv1dGLU.incremental_forward).
+
+torch is used here for exactly three things: owning device memory (``tensor.data_ptr()``), naming the
+HIP stream to launch on, and moving weights to the host once.  All arithmetic happens in libwnv_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import Config, GenerateArgs, GluConfig, Tensor, check
+
+__all__ = ["Engine", "QueueConv", "GluLayer", "make_config", "require_gpu_tensor"]
+
+
+def require_gpu_tensor(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what} lives on {t.device}: the MI355X engine only runs on a HIP device (model.to('cuda')); "
+            f"there is no CPU fallback for the incremental path")
+
+
+def make_config(*, out_channels, layers, stacks, residual_channels, gate_channels, skip_out_channels,
+                kernel_size, cin_channels, gin_channels, n_speakers, use_speaker_embedding, scalar_input,
+                output_distribution, upsample_net: Optional[str], upsample_scales: Sequence[int],
+                freq_axis_kernel_size: int, cin_pad: int) -> Config:
+    cfg = Config()
+    cfg.abi_version = _lib.WNV_ABI_VERSION
+    cfg.out_channels = out_channels
+    cfg.layers = layers
+    cfg.stacks = stacks
+    cfg.residual_channels = residual_channels
+    cfg.gate_channels = gate_channels
+    cfg.skip_out_channels = skip_out_channels
+    cfg.kernel_size = kernel_size
+    cfg.cin_channels = cin_channels
+    cfg.gin_channels = gin_channels
+    cfg.n_speakers = int(n_speakers or 0)
+    cfg.use_speaker_embedding = int(bool(use_speaker_embedding))
+    cfg.scalar_input = int(bool(scalar_input))
+    if scalar_input:
+        if output_distribution not in ("Logistic", "Normal"):
+            raise AssertionError(f"unknown output_distribution {output_distribution!r}")   # wavenet.py:330
+        cfg.output_distribution = _lib.DIST[output_distribution]
+    else:
+        cfg.output_distribution = _lib.DIST["categorical"]
+    if upsample_net not in _lib.UPSAMPLE:
+        raise NotImplementedError(f"upsample_net {upsample_net!r}")
+    cfg.upsample_kind = _lib.UPSAMPLE[upsample_net]
+    scales = list(upsample_scales or [])
+    if len(scales) > _lib.WNV_MAX_UPSAMPLE_STAGES:
+        raise NotImplementedError("too many upsample stages")
+    cfg.n_upsample_scales = len(scales)
+    for i, s in enumerate(scales):
+        cfg.upsample_scales[i] = int(s)
+    cfg.freq_axis_kernel_size = int(freq_axis_kernel_size)
+    cfg.cin_pad = int(cin_pad)
+    return cfg
+
+
+def _tensor_table(named: Dict[str, torch.Tensor]):
+    """state_dict -> (ctypes array of wnv_tensor, keep-alive list).  Host fp32 contiguous copies."""
+    keep = []
+    arr = (Tensor * len(named))()
+    for i, (name, t) in enumerate(named.items()):
+        h = t.detach().to(device="cpu", dtype=torch.float32).contiguous()
+        nm = name.encode()
+        keep.append((h, nm))
+        arr[i].name = nm
+        arr[i].data = h.data_ptr()
+        arr[i].ndim = h.dim()
+        for d in range(h.dim()):
+            arr[i].shape[d] = h.shape[d]
+    return arr, keep
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class Engine:
+    """One ``wnv_handle``: packed weights + scratch for one model on one device."""
+
+    def __init__(self, cfg: Config, device: torch.device):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("Engine needs a HIP ('cuda') device")
+        self._h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        check(_lib.lib().wnv_create(C.byref(cfg), idx, C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            _lib.lib().wnv_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def load_weights(self, state: Dict[str, torch.Tensor]) -> None:
+        arr, keep = _tensor_table(state)
+        check(_lib.lib().wnv_load_weights(self._h, arr, len(state)))
+        del keep
+
+    def noise_width(self) -> int:
+        return int(_lib.lib().wnv_noise_width(C.byref(self.cfg)))
+
+    def upsampled_length(self, tc_in: int) -> int:
+        return int(_lib.lib().wnv_upsampled_length(C.byref(self.cfg), int(tc_in)))
+
+    def bytes_per_step(self, B: int) -> int:
+        return int(_lib.lib().wnv_bytes_per_step(self._h, int(B)))
+
+    def macs_per_sample(self) -> int:
+        return int(_lib.lib().wnv_macs_per_sample(self._h))
+
+    def upsample(self, c: torch.Tensor, T_expected: int = -1) -> torch.Tensor:
+        """(B, cin, Tc_in) device -> (B, T, cin) device, time-major."""
+        require_gpu_tensor(c, "c")
+        c = c.detach().to(torch.float32).contiguous()
+        B, cin, tc = c.shape
+        T = self.upsampled_length(tc)
+        if T <= 0:
+            raise AssertionError(f"conditioning of {tc} frames is too short for the upsampling network")
+        out = torch.empty(B, T, cin, device=c.device, dtype=torch.float32)
+        check(_lib.lib().wnv_upsample(self._h, c.data_ptr(), B, tc, out.data_ptr(), int(T_expected),
+                                      _stream(c.device)))
+        return out
+
+    def generate(self, *, B: int, T: int, c_up=None, g=None, g_ids=None, initial=None, teacher=None,
+                 noise=None, seed: int = 0, softmax: bool = True, quantize: bool = True,
+                 want_params: bool = False, want_index: bool = False, kernel: int = 0):
+        """Runs the whole autoregressive loop.  Returns (out (B,C,T), params (B,O,T)|None, index (B,T)|None)."""
+        dev = self.device
+        cfg = self.cfg
+        C_out = 1 if cfg.scalar_input else cfg.out_channels
+        out = torch.empty(B, C_out, T, device=dev, dtype=torch.float32)
+        params = torch.empty(B, cfg.out_channels, T, device=dev, dtype=torch.float32) if want_params else None
+        index = torch.empty(B, T, device=dev, dtype=torch.int32) if want_index else None
+        a = GenerateArgs()
+        a.B, a.T = B, T
+        a.c_up, a.g, a.g_ids = _ptr(c_up), _ptr(g), _ptr(g_ids)
+        a.initial, a.teacher = _ptr(initial), _ptr(teacher)
+        a.Tt = 0 if teacher is None else teacher.shape[1]
+        a.noise = _ptr(noise)
+        a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        a.softmax, a.quantize = int(bool(softmax)), int(bool(quantize))
+        a.out, a.params_out, a.index_out = out.data_ptr(), _ptr(params), _ptr(index)
+        a.kernel = int(kernel)
+        a.stream = _stream(dev)
+        check(_lib.lib().wnv_generate(self._h, C.byref(a)))
+        return out, params, index
+
+
+class QueueConv:
+    """conv.Conv1d.incremental_forward state machine on the device (reference conv.py:17-49)."""
+
+    def __init__(self, cin: int, cout: int, kernel_size: int, dilation: int, device: torch.device):
+        self.device = torch.device(device)
+        self._h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        self.cin, self.cout = cin, cout
+        check(_lib.lib().wnv_qconv_create(cin, cout, kernel_size, dilation, idx, C.byref(self._h)))
+
+    def set_weights(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        b = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+        check(_lib.lib().wnv_qconv_set_weights(self._h, w.data_ptr(), _ptr(b)))
+
+    def step(self, x: torch.Tensor) -> torch.Tensor:
+        """x (B, cin) -> (B, cout)."""
+        x = x.detach().to(torch.float32).contiguous()
+        y = torch.empty(x.shape[0], self.cout, device=x.device, dtype=torch.float32)
+        check(_lib.lib().wnv_qconv_step(self._h, x.data_ptr(), y.data_ptr(), x.shape[0], _stream(x.device)))
+        return y
+
+    def reset(self):
+        check(_lib.lib().wnv_qconv_reset(self._h))
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self._h.value:
+                _lib.lib().wnv_qconv_destroy(self._h)
+        except Exception:
+            pass
+
+
+class GluLayer:
+    """ResidualConv1dGLU.incremental_forward state machine on the device (reference modules.py:112-169)."""
+
+    def __init__(self, *, residual_channels, gate_channels, kernel_size, skip_out_channels, cin_channels,
+                 gin_channels, dilation, bias, device):
+        self.device = torch.device(device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        cfg = GluConfig(residual_channels, gate_channels, kernel_size, skip_out_channels,
+                        cin_channels, gin_channels, dilation, int(bool(bias)))
+        self.R, self.K = residual_channels, skip_out_channels
+        self._h = C.c_void_p()
+        check(_lib.lib().wnv_glu_create(C.byref(cfg), idx, C.byref(self._h)))
+
+    def load_weights(self, state: Dict[str, torch.Tensor]):
+        arr, keep = _tensor_table(state)
+        check(_lib.lib().wnv_glu_load_weights(self._h, arr, len(state)))
+        del keep
+
+    def step(self, x, c=None, g=None):
+        x = x.detach().to(torch.float32).contiguous()
+        c = None if c is None else c.detach().to(torch.float32).contiguous()
+        g = None if g is None else g.detach().to(torch.float32).contiguous()
+        B = x.shape[0]
+        xo = torch.empty(B, self.R, device=x.device, dtype=torch.float32)
+        so = torch.empty(B, self.K, device=x.device, dtype=torch.float32)
+        check(_lib.lib().wnv_glu_step(self._h, x.data_ptr(), _ptr(c), _ptr(g), xo.data_ptr(), so.data_ptr(), B,
+                                      _stream(x.device)))
+        return xo, so
+
+    def reset(self):
+        check(_lib.lib().wnv_glu_reset(self._h))
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self._h.value:
+                _lib.lib().wnv_glu_destroy(self._h)
+        except Exception:
+            pass

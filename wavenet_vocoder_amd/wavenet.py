@@ -1,0 +1,241 @@
+"""``WaveNet`` with the reference's constructor, attributes, ``state_dict`` layout and
+``incremental_forward`` contract (wavenet_vocoder/wavenet.py:63-361) -- the drop-in boundary of this
+package.  ``incremental_forward`` hands the whole autoregressive loop to the HIP engine
+(``wnv_upsample`` + ``wnv_generate`` in include/wnv.h): one launch, no host round trip between samples.
+
+What is kept from the reference's behaviour (and where it is pinned):
+  * argument layouts and the auto-transposes of ``initial_input`` / ``test_inputs`` (wavenet.py:246-252,
+    291-292), ``T = max(T, test_inputs.size(1))`` (:255-258), teacher forcing then free running (:297-301),
+    implicit start = zeros / one-hot index 127 (:281-289), output ``(B, C, T)`` / ``(B, 1, T)`` (:338-340);
+  * errors: ``RuntimeError('incremental_forward only supports eval mode')`` (conv.py:19-20),
+    ``AssertionError`` when the upsampled conditioning length != T (wavenet.py:276);
+  * random numbers: by default the sampling noise is the stream torch's CPU generator would have given
+    the reference for the current seed (``rng = "replay"``, see noise.py), so a seeded call reproduces the
+    reference's CPU run; ``rng = "philox"`` switches to the in-kernel counter-based generator.
+What is deliberately more general: the batch size is inferred from any of test_inputs / c /
+initial_input / g (the reference only looks at test_inputs and c, wavenet.py:242,253,273, so its own
+batched free-running calls with ``g`` fail).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import upsample
+from .engine import Engine, make_config, require_gpu_tensor
+from .modules import Conv1d1x1, Embedding, ResidualConv1dGLU
+from .noise import make_noise_tape
+
+__all__ = ["WaveNet", "receptive_field_size"]
+
+
+def receptive_field_size(total_layers, num_cycles, kernel_size, dilation=lambda x: 2 ** x):
+    """(kernel_size - 1) * sum(dilations) + 1, reference wavenet.py:42-60 (known answers: tests/test_misc.py)."""
+    assert total_layers % num_cycles == 0
+    per_cycle = total_layers // num_cycles
+    return (kernel_size - 1) * sum(dilation(i % per_cycle) for i in range(total_layers)) + 1
+
+
+def _expand_global_features(B, T, g, bct=True):
+    """(B, C) or (B, C, 1) -> (B, C, T) [bct] or (B, T, C); reference wavenet.py:19-39."""
+    if g is None:
+        return None
+    g = g.unsqueeze(-1) if g.dim() == 2 else g
+    e = g.expand(B, -1, T)
+    return e.contiguous() if bct else e.transpose(1, 2).contiguous()
+
+
+class WaveNet(nn.Module):
+    def __init__(self, out_channels=256, layers=20, stacks=2, residual_channels=512, gate_channels=512,
+                 skip_out_channels=512, kernel_size=3, dropout=1 - 0.95, cin_channels=-1, gin_channels=-1,
+                 n_speakers=None, upsample_conditional_features=False,
+                 upsample_net="ConvInUpsampleNetwork",
+                 upsample_params={"upsample_scales": [4, 4, 4, 4]}, scalar_input=False,
+                 use_speaker_embedding=False, output_distribution="Logistic", cin_pad=0):
+        super().__init__()
+        self.scalar_input = scalar_input
+        self.out_channels = out_channels
+        self.cin_channels = cin_channels
+        self.gin_channels = gin_channels
+        self.output_distribution = output_distribution
+        self.kernel_size = kernel_size
+        self.layers, self.stacks = layers, stacks
+        assert layers % stacks == 0
+        per_stack = layers // stacks
+        self.first_conv = Conv1d1x1(1 if scalar_input else out_channels, residual_channels)
+        self.conv_layers = nn.ModuleList([
+            ResidualConv1dGLU(residual_channels, gate_channels, kernel_size=kernel_size,
+                              skip_out_channels=skip_out_channels, bias=True,
+                              dilation=2 ** (i % per_stack), dropout=dropout,
+                              cin_channels=cin_channels, gin_channels=gin_channels)
+            for i in range(layers)])
+        self.last_conv_layers = nn.ModuleList([
+            nn.ReLU(inplace=True), Conv1d1x1(skip_out_channels, skip_out_channels),
+            nn.ReLU(inplace=True), Conv1d1x1(skip_out_channels, out_channels)])
+        if gin_channels > 0 and use_speaker_embedding:
+            assert n_speakers is not None
+            self.embed_speakers = Embedding(n_speakers, gin_channels, padding_idx=None, std=0.1)
+        else:
+            self.embed_speakers = None
+        if upsample_conditional_features:
+            self.upsample_net = getattr(upsample, upsample_net)(**upsample_params)
+            self._upsample_kind = upsample_net
+            self._upsample_scales = list(upsample_params.get("upsample_scales", []))
+            self._upsample_cin_pad = int(upsample_params.get("cin_pad", 0))
+            self._freq_k = int(upsample_params.get("freq_axis_kernel_size", 1))
+        else:
+            self.upsample_net = None
+            self._upsample_kind, self._upsample_scales, self._upsample_cin_pad, self._freq_k = None, [], 0, 1
+        self.receptive_field = receptive_field_size(layers, stacks, kernel_size)
+        self._cfg_kwargs = dict(
+            out_channels=out_channels, layers=layers, stacks=stacks, residual_channels=residual_channels,
+            gate_channels=gate_channels, skip_out_channels=skip_out_channels, kernel_size=kernel_size,
+            cin_channels=cin_channels, gin_channels=gin_channels, n_speakers=n_speakers,
+            use_speaker_embedding=self.embed_speakers is not None, scalar_input=scalar_input,
+            output_distribution=output_distribution, upsample_net=self._upsample_kind,
+            upsample_scales=self._upsample_scales, freq_axis_kernel_size=self._freq_k,
+            cin_pad=self._upsample_cin_pad)
+        # engine state (not part of the module state)
+        self.rng = "replay"          # "replay": reference CPU stream of the current torch seed | "philox"
+        self.kernel = 0              # 0 auto, 1 generic single-workgroup kernel, 2 pipelined ring kernel
+        self._engine: Optional[Engine] = None
+        self._engine_key = None
+        self.last_params = None      # head outputs (B, O, T) of the last call when ``capture_params``
+        self.capture_params = False
+
+    # ---- reference API ---------------------------------------------------------------------------
+    def has_speaker_embedding(self):
+        return self.embed_speakers is not None
+
+    def local_conditioning_enabled(self):
+        return self.cin_channels > 0
+
+    def make_generation_fast_(self):
+        """The reference strips weight norm here (wavenet.py:355-361); this package stores the fused weights
+        from the start (load_state_dict folds weight_g/weight_v), so there is nothing left to do."""
+        return None
+
+    def clear_buffer(self):
+        """wavenet.py:345-353.  The engine re-zeroes its history at the start of every incremental_forward
+        (as the reference does at :241); this drops layer-level histories too."""
+        self.first_conv.clear_buffer()
+        for f in self.conv_layers:
+            f.clear_buffer()
+        for f in self.last_conv_layers:
+            if hasattr(f, "clear_buffer"):
+                f.clear_buffer()
+
+    def forward(self, x, c=None, g=None, softmax=False):
+        """Teacher-forced batch evaluation (B,C,T) -> (B,out_channels,T), reference wavenet.py:164-213.
+        torch ops on whatever device the module lives on; it is the online==offline parity oracle
+        (reference tests/test_model.py:147-366) and not part of the accelerated path."""
+        B, _, T = x.size()
+        if g is not None and self.embed_speakers is not None:
+            g = self.embed_speakers(g.view(B, -1)).transpose(1, 2)
+            assert g.dim() == 3
+        g_bct = _expand_global_features(B, T, g, bct=True)
+        if c is not None and self.upsample_net is not None:
+            c = self.upsample_net(c)
+            assert c.size(-1) == x.size(-1)
+        x = self.first_conv(x)
+        skips = 0
+        for f in self.conv_layers:
+            x, h = f(x, c, g_bct)
+            skips = skips + h
+        x = skips * math.sqrt(1.0 / len(self.conv_layers))
+        for f in self.last_conv_layers:
+            x = f(x)
+        return F.softmax(x, dim=1) if softmax else x
+
+    # ---- engine plumbing ---------------------------------------------------------------------------
+    def _get_engine(self) -> Engine:
+        params = list(self.parameters())
+        require_gpu_tensor(params[0], "WaveNet parameters")
+        dev = params[0].device
+        key = tuple((p.device, p.data_ptr(), p._version) for p in params)
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            eng = Engine(make_config(**self._cfg_kwargs), dev)
+            eng.load_weights(self.state_dict())
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
+    def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None,
+                            tqdm=lambda x: x, softmax=True, quantize=True, log_scale_min=-50.0):
+        """Autoregressive generation; same signature and return layout as reference wavenet.py:215-343.
+        ``tqdm`` is accepted and ignored (there is no per-sample host iteration to wrap); ``log_scale_min``
+        is accepted and unused exactly as in the reference (mixture.py:147-148: clamp_log_scale=False)."""
+        if self.training:
+            raise RuntimeError('incremental_forward only supports eval mode')     # conv.py:19-20
+        eng = self._get_engine()
+        dev = eng.device
+        C_in = 1 if self.scalar_input else self.out_channels
+
+        def prep(t):
+            return None if t is None else t.detach().to(device=dev)
+
+        initial_input, c, g, test_inputs = prep(initial_input), prep(c), prep(g), prep(test_inputs)
+        B = 1
+        if test_inputs is not None:                                               # wavenet.py:245-258
+            if self.scalar_input:
+                if test_inputs.size(1) == 1:
+                    test_inputs = test_inputs.transpose(1, 2)
+            elif test_inputs.size(1) == self.out_channels:
+                test_inputs = test_inputs.transpose(1, 2)
+            test_inputs = test_inputs.float().contiguous()                        # (B, Tt, C)
+            B = test_inputs.size(0)
+            T = test_inputs.size(1) if T is None else max(int(T), test_inputs.size(1))
+        T = int(T)
+        if c is not None:
+            B = c.shape[0]
+        elif test_inputs is None:
+            if initial_input is not None:
+                B = initial_input.size(0)
+            elif g is not None:
+                B = g.size(0)
+        # global conditioning (wavenet.py:262-269): ids -> embedding, or external float features
+        g_ids = g_feat = None
+        if g is not None:
+            if self.embed_speakers is not None:
+                g_ids = g.reshape(B, -1)[:, 0].to(torch.int64).contiguous()
+            else:
+                g_feat = g.float().reshape(B, -1).contiguous()
+                assert g_feat.size(1) == self.gin_channels
+        # local conditioning (wavenet.py:272-278)
+        c_up = None
+        if c is not None:
+            c = c.float()
+            if self.upsample_net is not None:
+                c_up = eng.upsample(c.contiguous(), T_expected=T)                 # asserts length == T
+            elif c.size(-1) == T:
+                c_up = c.transpose(1, 2).contiguous()
+            else:
+                c_up = c.contiguous()                                             # already (B, T, cin)
+            assert c_up.shape == (B, T, self.cin_channels), (tuple(c_up.shape), (B, T, self.cin_channels))
+        # first input (wavenet.py:281-292)
+        init = None
+        if initial_input is not None:
+            if initial_input.size(1) == self.out_channels and not self.scalar_input:
+                initial_input = initial_input.transpose(1, 2)
+            init = initial_input.float().reshape(B, -1).contiguous()
+            assert init.size(1) == C_in, (tuple(init.shape), C_in)
+        # noise
+        noise, seed = None, 0
+        if self.rng == "replay":
+            tape = make_noise_tape(T, B, scalar_input=self.scalar_input,
+                                   output_distribution=self.output_distribution, out_channels=self.out_channels)
+            noise = tape.to(dev, non_blocking=False).contiguous()
+        elif self.rng == "philox":
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        else:
+            raise ValueError(f"unknown rng mode {self.rng!r}")
+        out, params, _ = eng.generate(B=B, T=T, c_up=c_up, g=g_feat, g_ids=g_ids, initial=init,
+                                      teacher=test_inputs, noise=noise, seed=seed, softmax=softmax,
+                                      quantize=quantize, want_params=self.capture_params, kernel=self.kernel)
+        self.last_params = params
+        return out
