@@ -326,9 +326,14 @@ class Oracle:
 
     # -- wavenet.py:215-343 --------------------------------------------------------------------
     def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None,
-                            softmax=True, quantize=True, noise=None, return_params=False):
+                            softmax=True, quantize=True, noise=None, return_params=False,
+                            max_seconds=None):
         """Same contract as the reference; ``noise`` is the (T, B, noise_width) tape that replaces
-        the generator.  With ``return_params`` also returns the pre-sampling head output (B, O, T)."""
+        the generator.  With ``return_params`` also returns the pre-sampling head output (B, O, T).
+        ``max_seconds`` (bench.py's bounded CPU-baseline sample) stops the loop after that much wall time;
+        ``self.last_steps`` / ``self.last_seconds`` then tell how far it got."""
+        import time as _time
+        _t0 = _time.perf_counter()
         cfg = self.cfg
         self.clear_buffer()
         B = 1
@@ -361,7 +366,13 @@ class Oracle:
         cur = initial_input.float()
         outs, params = [], []
         scale = math.sqrt(1.0 / len(self.layers))
+        self.last_steps, self.last_seconds = 0, 0.0
         for t in range(T):
+            if max_seconds is not None and t > 0 and (t & 15) == 0:
+                self.last_seconds = _time.perf_counter() - _t0
+                if self.last_seconds > max_seconds:
+                    break
+            self.last_steps = t + 1
             if test_inputs is not None and t < test_inputs.size(1):          # wavenet.py:297-301
                 cur = test_inputs[:, t, :].unsqueeze(1).float()
             elif t > 0:
@@ -391,6 +402,7 @@ class Oracle:
                     idx = sample_categorical(x, nz)
                     x = torch.zeros_like(x).scatter_(1, idx.unsqueeze(-1), 1.0)
             outs.append(x.reshape(B, 1, -1))
+        self.last_seconds = _time.perf_counter() - _t0
         y = torch.stack([o.view(B, -1) for o in outs])                       # T x B x C
         y = y.transpose(0, 1).transpose(1, 2).contiguous()                   # B x C x T
         self.clear_buffer()

@@ -1,21 +1,32 @@
 #!/bin/bash
 # One GPU-box round trip: parity tests, smoke, bench, rocprofv3 kernel stats.  Everything under its own
-# `timeout` so a hung kernel cannot hold the box; outputs go to gpurun_out/.
-# usage: scripts/gpu_round.sh [tag] [pytest-extra-args]
+# `timeout` so a hung kernel cannot hold the box; outputs go to gpurun_out/<tag>/.
+# usage: scripts/gpu_round.sh <tag> <what: all|tests|ring|bench|prof> [bench args]
 set -u
 TAG=${1:-r01}
-shift || true
+WHAT=${2:-all}
+shift; shift || true
 OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-echo "== rocm-smi" ; rocm-smi --showproductname 2>/dev/null | head -8
-echo "== pytest -m gpu"
-timeout 900 python -m pytest tests -m gpu -x -q "$@" 2>&1 | tail -40 | tee $OUT/pytest.log
-echo "== smoke"
-timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.log
-echo "== bench"
-timeout 600 python bench.py --steps 2 --warmup 1 2>&1 | tail -3 | tee $OUT/bench.log
-echo "== rocprofv3 kernel stats (short bench)"
-( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o wnv -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0 > $GRAFT_REPO_ROOT/$OUT/prof_bench.log 2>&1 )
-find $OUT/prof -name "*kernel_stats*" | head -3
-for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do head -12 $f | cut -c1-220; done
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+if [[ $WHAT == all || $WHAT == tests ]]; then
+  echo "== pytest -m gpu"
+  timeout 1200 python -m pytest tests -m gpu -x -q --durations=8 2>&1 | tail -40 | tee $OUT/pytest.log
+  echo "== smoke"
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5 | tee $OUT/smoke.log
+fi
+if [[ $WHAT == ring ]]; then
+  echo "== pytest ring"
+  timeout 900 python -m pytest tests/test_gpu_ring.py -m gpu -x -q --durations=8 -s 2>&1 | tail -40 | tee $OUT/pytest_ring.log
+fi
+if [[ $WHAT == all || $WHAT == bench || $WHAT == ring ]]; then
+  echo "== bench $*"
+  timeout 600 python bench.py "$@" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $OUT/bench.log
+fi
+if [[ $WHAT == all || $WHAT == prof ]]; then
+  echo "== rocprofv3 kernel stats"
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o wnv -- python $ROOT/bench.py --steps 2 --warmup 1 --cpu-steps 0 "$@" > $ROOT/$OUT/prof_bench.log 2>&1 )
+  grep '^{' $OUT/prof_bench.log | tail -1
+  for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do echo $f; head -12 $f | cut -c1-240; done
+fi

@@ -1,0 +1,143 @@
+"""-m gpu: the pipelined ring kernel (csrc/wnv_ring.hip, kernel=2) against the CPU oracle, against the generic
+single-workgroup kernel (kernel=1) on the same inputs, and through size-independent properties."""
+import pytest
+import torch
+
+import wavenet_vocoder_amd as wnv
+from oracle.wavenet_oracle import Oracle
+from tests._configs import CONFIGS, build, inputs, tame_head_
+from tests._golden import oracle_config
+from wavenet_vocoder_amd.noise import make_noise_tape
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def tape_for(kw, T, B, seed):
+    return make_noise_tape(T, B, scalar_input=True, output_distribution=kw.get("output_distribution", "Logistic"),
+                           out_channels=kw["out_channels"], generator=torch.Generator().manual_seed(seed))
+
+
+def run(eng, kernel, B, T, c_up=None, teacher=None, tape=None, g_ids=None, seed=0):
+    return eng.generate(B=B, T=T, c_up=c_up, teacher=teacher, noise=tape, g_ids=g_ids, seed=seed,
+                        want_params=True, kernel=kernel)
+
+
+@pytest.mark.parametrize("name", ["cfg2_mol", "cfg3_gaussian"])
+def test_ring_teacher_forced_vs_oracle(name):
+    kw = CONFIGS[name]
+    B, T = 3, 256
+    m = build(name)
+    o = Oracle(oracle_config(kw), m.state_dict())
+    c, _ = inputs(name, B, T)
+    x = torch.tanh(torch.randn(B, 1, T, generator=torch.Generator().manual_seed(3)) * 0.5)
+    tape = tape_for(kw, T, B, 2)
+    torch.set_num_threads(8)
+    want, wparams = o.incremental_forward(test_inputs=x, c=c, T=T, noise=tape, return_params=True)
+    m = m.to("cuda")
+    eng = m._get_engine()
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    out, params, _ = run(eng, 2, B, T, c_up, x.transpose(1, 2).contiguous().cuda(), tape.cuda())
+    err = (params.cpu() - wparams).abs().max().item()
+    assert err < TOL, f"{name}: ring head outputs differ from the oracle by {err}"
+    d = (out.cpu() - want).abs()
+    assert (d < TOL).float().mean().item() > 0.98
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 8, 11, 16])
+def test_ring_equals_generic_kernel(B):
+    name = "cfg2_mol"
+    kw = CONFIGS[name]
+    T = 512
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    c, _ = inputs(name, B, T)
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    tape = tape_for(kw, T, B, 7).cuda()
+    x = torch.tanh(torch.randn(B, 128, 1, generator=torch.Generator().manual_seed(5)) * 0.5).cuda()   # 128 forced steps
+    o1, p1, _ = run(eng, 1, B, T, c_up, x, tape)
+    o2, p2, _ = run(eng, 2, B, T, c_up, x, tape)
+    # teacher-forced part: same inputs, only the association order of the dot products differs
+    assert (p1[:, :, :128] - p2[:, :, :128]).abs().max().item() < 2e-5
+    # free-running part: trajectories stay together over this horizon
+    d = (o1 - o2).abs()
+    assert d.max().item() < 1e-3, d.max().item()
+    # determinism
+    o3, _, _ = run(eng, 2, B, T, c_up, x, tape)
+    assert torch.equal(o2, o3)
+
+
+def test_ring_free_run_vs_oracle():
+    name = "cfg2_mol"
+    kw = CONFIGS[name]
+    B, T = 2, 256
+    m = build(name)
+    o = Oracle(oracle_config(kw), m.state_dict())
+    c, _ = inputs(name, B, T)
+    tape = tape_for(kw, T, B, 4)
+    torch.set_num_threads(8)
+    want = o.incremental_forward(c=c, T=T, noise=tape)
+    m = m.to("cuda")
+    eng = m._get_engine()
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    out, _, _ = run(eng, 2, B, T, c_up, None, tape.cuda())
+    d = (out.cpu() - want).abs()[:, 0]
+    bad = (d > 1e-3).nonzero()
+    first = T if bad.numel() == 0 else int(bad[:, 1].min())
+    print(f"ring free-run agrees with the oracle to 1e-3 for {first}/{T} steps (max {d.max():.2e})")
+    assert first >= 128
+
+
+@pytest.mark.parametrize("variant", ["k2_s3", "nocond", "global", "k4"])
+def test_ring_shape_variants_vs_generic(variant):
+    base = dict(out_channels=30, residual_channels=128, gate_channels=256, skip_out_channels=128, dropout=0.0,
+                scalar_input=True, output_distribution="Logistic")
+    if variant == "k2_s3":
+        kw = dict(layers=6, stacks=3, kernel_size=2, cin_channels=20, **base)
+    elif variant == "nocond":
+        kw = dict(layers=4, stacks=2, kernel_size=3, **base)
+    elif variant == "global":
+        kw = dict(layers=8, stacks=2, kernel_size=3, cin_channels=16, gin_channels=8, n_speakers=5,
+                  use_speaker_embedding=True, **base)
+    else:
+        kw = dict(layers=4, stacks=1, kernel_size=4, cin_channels=80, **base)
+        kw["out_channels"], kw["output_distribution"] = 2, "Normal"
+    torch.manual_seed(11)
+    m = tame_head_(wnv.WaveNet(**kw).eval()).to("cuda")
+    eng = m._get_engine()
+    B, T = 3, 300
+    g = torch.Generator().manual_seed(1)
+    cin = kw.get("cin_channels", -1)
+    c_up = torch.randn(B, T, cin, generator=g).cuda() if cin > 0 else None
+    gids = torch.randint(0, 5, (B,), generator=g).cuda() if kw.get("gin_channels", -1) > 0 else None
+    tape = tape_for(kw, T, B, 3).cuda()
+    x = torch.tanh(torch.randn(B, 200, 1, generator=g) * 0.5).cuda()
+    o1, p1, _ = run(eng, 1, B, T, c_up, x, tape, gids)
+    o2, p2, _ = run(eng, 2, B, T, c_up, x, tape, gids)
+    assert (p1[:, :, :200] - p2[:, :, :200]).abs().max().item() < 2e-5
+    assert (o1 - o2).abs().max().item() < 1e-3
+
+
+def test_ring_properties_at_length():
+    name = "cfg2_mol"
+    kw = CONFIGS[name]
+    B, T = 8, 8192
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    c, _ = inputs(name, B, T)
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    tape = tape_for(kw, T, B, 9).cuda()
+    full, _, _ = run(eng, 2, B, T, c_up, None, tape)
+    T2 = 2048
+    pre, _, _ = run(eng, 2, B, T2, c_up[:, :T2].contiguous(), None, tape[:T2].contiguous())
+    assert torch.equal(pre, full[:, :, :T2]), "prefix property"
+    solo, _, _ = run(eng, 2, 1, T2, c_up[5:6, :T2].contiguous(), None, tape[:T2, 5:6].contiguous())
+    assert torch.equal(solo[0], full[5, :, :T2]), "batch members must be independent"
+    assert torch.isfinite(full).all() and float(full.abs().max()) <= 1.0 and float(full.std()) > 1e-3
+
+
+def test_unsupported_configs_say_so():
+    m = build("cfg0_mulaw256_small").to("cuda")
+    eng = m._get_engine()
+    with pytest.raises(NotImplementedError, match="ring kernel"):
+        eng.generate(B=1, T=16, kernel=2)

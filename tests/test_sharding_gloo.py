@@ -1,0 +1,93 @@
+"""N > 1 path on CPU: two processes, gloo backend, utterance sharding + gather (no data-path collective)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from wavenet_vocoder_amd.sharding import (broadcast_weights, lpt_assign, pack_groups, pad_group,
+                                          synthesize_sharded)
+
+HOP, PAD = 4, 2
+
+
+def fake_synth(c, idx):
+    """Stand-in for the GPU engine: a deterministic function of each utterance's own mel only."""
+    B, cin, fr = c.shape
+    frames = fr - 2 * PAD
+    body = c[:, :, PAD:PAD + frames]
+    return body.mean(1).repeat_interleave(HOP, dim=1) + torch.tensor(idx, dtype=torch.float32).view(-1, 1)
+
+
+def make_mels(n=13, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(5, int(torch.randint(3, 40, (1,), generator=g)), generator=g) for _ in range(n)]
+
+
+def expected(mels):
+    return [m.mean(0).repeat_interleave(HOP) + i for i, m in enumerate(mels)]
+
+
+def test_lpt_and_packing():
+    lengths = [10, 200, 30, 40, 50, 60, 70, 5, 90]
+    bins = lpt_assign(lengths, 3)
+    assert sorted(sum(bins, [])) == list(range(9))
+    loads = [sum(lengths[i] for i in b) for b in bins]
+    assert max(loads) <= 200 + 5            # the long utterance dominates; the rest balances
+    groups = pack_groups(range(9), lengths, 4)
+    assert [len(g) for g in groups] == [4, 4, 1]
+    assert lengths[groups[0][0]] == 200 and all(
+        lengths[a] >= lengths[b] for g in groups for a, b in zip(g, g[1:]))
+    c = pad_group([torch.ones(2, 3), 2 * torch.ones(2, 5)], cin_pad=2)
+    assert c.shape == (2, 2, 9)
+    assert c[0, 0].tolist() == [1, 1, 1, 1, 1, 0, 0, 0, 0] and c[1, 0].tolist() == [2] * 9
+
+
+def test_single_process_matches():
+    mels = make_mels()
+    got = synthesize_sharded(mels, fake_synth, hop_size=HOP, cin_pad=PAD, group_size=3)
+    for a, b in zip(got, expected(mels)):
+        assert torch.allclose(a, b, atol=1e-6)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lin = torch.nn.Linear(7, 3)
+        if rank != 0:
+            with torch.no_grad():
+                for p in lin.parameters():
+                    p.zero_()
+        ref = [p.detach().clone() for p in lin.parameters()] if rank == 0 else None
+        broadcast_weights(lin, src=0)
+        mels = make_mels()
+        got = synthesize_sharded(mels, fake_synth, hop_size=HOP, cin_pad=PAD, group_size=3, gather_to=0)
+        every = synthesize_sharded(mels, fake_synth, hop_size=HOP, cin_pad=PAD, group_size=3, gather_to=None)
+        ok = all(torch.allclose(a, b, atol=1e-6) for a, b in zip(every, expected(mels)))
+        if rank == 0:
+            ok = ok and all(torch.allclose(a, b, atol=1e-6) for a, b in zip(got, expected(mels)))
+            ok = ok and all(torch.equal(a, b.detach()) for a, b in zip(ref, lin.parameters()))
+        else:
+            ok = ok and got is None and float(sum(p.abs().sum() for p in lin.parameters())) > 0
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_two_ranks_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=100) for _ in procs)
+    for p in procs:
+        p.join(30)
+    assert res == {0: True, 1: True}

@@ -15,95 +15,13 @@
 //   sample_from_mix_gaussian             mixture.py:221-270 -> sample_scalar()
 //   softmax + OneHotCategorical          wavenet.py:332-335 -> sample_categorical()
 #include "wnv_internal.h"
+#include "wnv_matvec.h"
+#include "wnv_sample.h"
 
 namespace {
 
 constexpr int NW = WNV_GENERIC_WAVES;
 constexpr int NT = WNV_GENERIC_THREADS;
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-// argmax with first-index tie break (torch.max / argmax semantics on CPU)
-__device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o, 64);
-        const int oi = __shfl_xor(i, o, 64);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
-}
-
-// y_partial[wave][0..Np) = sum over this wave's K-slice of Wt[k][0..Np) * x[k]
-// Wt is K-major ([K][Np], Np % 4 == 0); a lane owns 4 consecutive outputs; waves split K.
-__device__ __noinline__ void matvec_partial(const float* __restrict__ Wt, int K, int Np,
-                                               const float* __restrict__ x, float* __restrict__ part,
-                                               int pstride, int wave, int lane) {
-    const int kper = (K + NW - 1) / NW;
-    const int k0 = wave * kper;
-    int k1 = k0 + kper;
-    if (k1 > K) k1 = K;
-    for (int n0 = lane * 4; n0 < Np; n0 += 256) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k0 < K) {
-            const float* wp = Wt + (size_t)k0 * Np + n0;
-            int k = k0;
-            for (; k + 8 <= k1; k += 8) {
-                float4 w[8];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) w[j] = *reinterpret_cast<const float4*>(wp + (size_t)j * Np);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float xv = x[k + j];
-                    acc.x = fmaf(w[j].x, xv, acc.x);
-                    acc.y = fmaf(w[j].y, xv, acc.y);
-                    acc.z = fmaf(w[j].z, xv, acc.z);
-                    acc.w = fmaf(w[j].w, xv, acc.w);
-                }
-                wp += (size_t)8 * Np;
-            }
-            if (k + 4 <= k1) {
-                float4 w[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const float4*>(wp + (size_t)j * Np);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float xv = x[k + j];
-                    acc.x = fmaf(w[j].x, xv, acc.x);
-                    acc.y = fmaf(w[j].y, xv, acc.y);
-                    acc.z = fmaf(w[j].z, xv, acc.z);
-                    acc.w = fmaf(w[j].w, xv, acc.w);
-                }
-                wp += (size_t)4 * Np;
-                k += 4;
-            }
-            for (; k < k1; ++k) {
-                const float4 w = *reinterpret_cast<const float4*>(wp);
-                const float xv = x[k];
-                acc.x = fmaf(w.x, xv, acc.x);
-                acc.y = fmaf(w.y, xv, acc.y);
-                acc.z = fmaf(w.z, xv, acc.z);
-                acc.w = fmaf(w.w, xv, acc.w);
-                wp += Np;
-            }
-        }
-        *reinterpret_cast<float4*>(part + (size_t)wave * pstride + n0) = acc;
-    }
-}
-
-__device__ __forceinline__ float reduce_part(const float* part, int pstride, int n, float init) {
-    float v = init;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) v += part[w * pstride + n];
-    return v;
-}
 
 // One ResidualConv1dGLU step (modules.py:127-163) on the vector held in xin = [taps | h | c_t].
 // Thread n = tid gets back: n < R -> new h (also stored to xin[hoff+n]); R <= n < R+K -> skip output s.
@@ -119,19 +37,19 @@ __device__ __forceinline__ float glu_layer(const float* __restrict__ W, const Wn
     float za = 0.f, zbv = 0.f, bo = 0.f;       // biases fetched ahead of the weight stream
     if (tid < H) { za = zb[tid]; zbv = zb[H + tid]; }
     if (tid < R + K) bo = W[Ld.b_os + tid];
-    matvec_partial(W + Ld.w_in, Kin, m.Gp, xin, part, ps, wave, lane);
+    matvec_partial<NW>(W + Ld.w_in, Kin, m.Gp, xin, part, ps, wave, lane);
     __syncthreads();
     if (tid < H) {
-        const float a = reduce_part(part, ps, tid, za);
-        const float b = reduce_part(part, ps, H + tid, zbv);
+        const float a = reduce_part<NW>(part, ps, tid, za);
+        const float b = reduce_part<NW>(part, ps, H + tid, zbv);
         ubuf[tid] = tanhf(a) * wnv_sigmoid(b);                                  // modules.py:154
     }
     __syncthreads();
-    matvec_partial(W + Ld.w_os, H, m.NOSp, ubuf, part, ps, wave, lane);
+    matvec_partial<NW>(W + Ld.w_os, H, m.NOSp, ubuf, part, ps, wave, lane);
     __syncthreads();
     float ret = 0.f;
     if (tid < R + K) {
-        const float o = reduce_part(part, ps, tid, bo);
+        const float o = reduce_part<NW>(part, ps, tid, bo);
         if (tid < R) {
             ret = (o + xin[hoff + tid]) * 0.70710678118654752440f;             // modules.py:162
             xin[hoff + tid] = ret;
@@ -164,64 +82,6 @@ __device__ __forceinline__ Lds carve(float* smem, const WnvModelDev& m) {
 __device__ __forceinline__ float tape_or_gen(const WnvGenArgs& a, int t, int b, int j, int kind) {
     if (a.noise) return a.noise[((size_t)t * a.B + b) * a.nz + j];
     return wnv_noise_gen(a.seed, t, b, j, kind);
-}
-
-// ---- sampling (wave 0 only) ----------------------------------------------------------------------
-// scalar outputs: mixture of logistics / Gaussians.  obuf = head output [O]; nzv = this step's noise.
-__device__ __forceinline__ float sample_scalar(const WnvModelDev& m, const float* obuf, const float* nzv,
-                                               int lane) {
-    const int O = m.O;
-    float mean, ls;
-    int nmix = 0;
-    if (m.dist == 2 && O == 2) { mean = obuf[0]; ls = obuf[1]; }                // mixture.py:258-259
-    else if (m.dist == 2 && O == 3) { mean = obuf[1]; ls = obuf[2]; }           // mixture.py:260-261
-    else {
-        nmix = O / 3;
-        // Gumbel-max over the mixture logits (mixture.py:138-140 / :247-249)
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int i = lane; i < nmix; i += 64) {
-            const float v = obuf[i] - logf(-logf(nzv[i]));
-            if (v > best) { best = v; bi = i; }
-        }
-        wave_argmax(best, bi);
-        mean = obuf[nmix + bi];                                                 // mixture.py:143-146
-        ls = obuf[2 * nmix + bi];
-    }
-    const float r = nzv[nmix];
-    float x;
-    if (m.dist == 1) x = mean + expf(ls) * (logf(r) - logf(1.0f - r));          // mixture.py:151-152
-    else x = r * expf(ls) + mean;                                               // mixture.py:265-267
-    return fminf(fmaxf(x, -1.0f), 1.0f);                                        // mixture.py:154 / :269
-}
-
-// categorical outputs.  Turns obuf into probabilities in place (when softmax) and returns the sampled
-// class (when quantize), else -1.
-__device__ __forceinline__ int sample_categorical(const WnvModelDev& m, float* obuf, const float* nzv,
-                                                  int softmax, int quantize, int lane) {
-    const int O = m.O;
-    if (softmax) {                                                              // wavenet.py:332
-        float mx = -INFINITY;
-        for (int n = lane; n < O; n += 64) mx = fmaxf(mx, obuf[n]);
-        mx = wave_max(mx);
-        float s = 0.f;
-        for (int n = lane; n < O; n += 64) { const float e = expf(obuf[n] - mx); obuf[n] = e; s += e; }
-        s = wave_sum(s);
-        for (int n = lane; n < O; n += 64) obuf[n] = obuf[n] / s;
-    }
-    if (!quantize) return -1;
-    // OneHotCategorical(p).sample(): Categorical renormalises, multinomial takes argmax(p_hat / e)
-    float s2 = 0.f;
-    for (int n = lane; n < O; n += 64) s2 += obuf[n];
-    s2 = wave_sum(s2);
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-    for (int n = lane; n < O; n += 64) {
-        const float q = (obuf[n] / s2) / nzv[n];
-        if (q > best) { best = q; bi = n; }
-    }
-    wave_argmax(best, bi);
-    return bi;
 }
 
 // ---- the whole autoregressive loop for one utterance ------------------------------------------------
@@ -290,9 +150,9 @@ __global__ void __launch_bounds__(NT) wnv_generate_generic_kernel(const WnvModel
                 if (dense) { for (int i = tid; i < m.cin1; i += NT) s.vin[i] = dense[i]; }
                 else { for (int i = tid; i < m.cin1; i += NT) s.vin[i] = s.obuf[i]; }   // fed-back probabilities
                 __syncthreads();
-                matvec_partial(W + m.w_first, m.cin1, m.Rp, s.vin, s.part, m.lds_part_stride, wave, lane);
+                matvec_partial<NW>(W + m.w_first, m.cin1, m.Rp, s.vin, s.part, m.lds_part_stride, wave, lane);
                 __syncthreads();
-                if (tid < R) s.xin[hoff + tid] = reduce_part(s.part, m.lds_part_stride, tid, W[m.b_first + tid]);
+                if (tid < R) s.xin[hoff + tid] = reduce_part<NW>(s.part, m.lds_part_stride, tid, W[m.b_first + tid]);
             }
         }
         // prologue LDS writes (taps, c_t, noise) and h must be visible to every wave
@@ -330,14 +190,14 @@ __global__ void __launch_bounds__(NT) wnv_generate_generic_kernel(const WnvModel
         if (tid < K) bh1 = W[m.b_h1 + tid];
         if (tid < O) bh2 = W[m.b_h2 + tid];
         __syncthreads();
-        matvec_partial(W + m.w_h1, K, m.Kp, s.ubuf, s.part, m.lds_part_stride, wave, lane);
+        matvec_partial<NW>(W + m.w_h1, K, m.Kp, s.ubuf, s.part, m.lds_part_stride, wave, lane);
         __syncthreads();
-        if (tid < K) s.ubuf[tid] = fmaxf(reduce_part(s.part, m.lds_part_stride, tid, bh1), 0.f);
+        if (tid < K) s.ubuf[tid] = fmaxf(reduce_part<NW>(s.part, m.lds_part_stride, tid, bh1), 0.f);
         __syncthreads();
-        matvec_partial(W + m.w_h2, K, m.Op, s.ubuf, s.part, m.lds_part_stride, wave, lane);
+        matvec_partial<NW>(W + m.w_h2, K, m.Op, s.ubuf, s.part, m.lds_part_stride, wave, lane);
         __syncthreads();
         if (tid < O) {
-            const float o = reduce_part(s.part, m.lds_part_stride, tid, bh2);
+            const float o = reduce_part<NW>(s.part, m.lds_part_stride, tid, bh2);
             s.obuf[tid] = o;
             if (a.params_out) a.params_out[((size_t)b * O + tid) * T + t] = o;
         }
@@ -345,10 +205,10 @@ __global__ void __launch_bounds__(NT) wnv_generate_generic_kernel(const WnvModel
         // ---- sampling (wavenet.py:322-336) ---------------------------------------------------------
         if (wave == 0) {
             if (m.scalar_input) {
-                const float x = sample_scalar(m, s.obuf, s.nz, lane);
+                const float x = sample_scalar(m.dist, m.O, s.obuf, s.nz, lane);
                 if (lane == 0) { a.out[(size_t)b * T + t] = x; s.flt[0] = x; }
             } else {
-                const int idx = sample_categorical(m, s.obuf, s.nz, a.softmax, a.quantize, lane);
+                const int idx = sample_categorical(m.O, s.obuf, s.nz, a.softmax, a.quantize, lane);
                 if (a.quantize) {
                     if (lane == 0) {
                         a.out[((size_t)b * O + idx) * T + t] = 1.0f;             // out is pre-zeroed
@@ -438,9 +298,9 @@ __global__ void __launch_bounds__(NT) wnv_qconv_step_kernel(const WnvQconvDev q,
         xin[idx] = v;
     }
     __syncthreads();
-    matvec_partial(W + q.w, Kin, q.coutp, xin, part, q.coutp, wave, lane);
+    matvec_partial<NW>(W + q.w, Kin, q.coutp, xin, part, q.coutp, wave, lane);
     __syncthreads();
-    for (int n = tid; n < q.cout; n += NT) y[(size_t)b * q.cout + n] = reduce_part(part, q.coutp, n, W[q.b + n]);
+    for (int n = tid; n < q.cout; n += NT) y[(size_t)b * q.cout + n] = reduce_part<NW>(part, q.coutp, n, W[q.b + n]);
 }
 
 }  // namespace

@@ -437,7 +437,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     ga.out = a->out; ga.params_out = a->params_out; ga.index_out = a->index_out;
 
     int kernel = a->kernel;
-    if (kernel == 0) kernel = wnv_ring_supported(c, a->B) ? 2 : 1;
+    if (kernel == 0) kernel = (wnv_ring_supported(c, a->B) && wnv_ring_default()) ? 2 : 1;
     if (kernel == 2) {
         if (!wnv_ring_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the pipelined ring kernel does not cover this configuration: %s", wnv_ring_why_not(c, a->B));
         std::string err;

@@ -13,6 +13,8 @@ struct WnvRingState;
 // Can the ring kernel run this configuration with B utterances in flight?
 bool wnv_ring_supported(const wnv_config& c, int B);
 const char* wnv_ring_why_not(const wnv_config& c, int B);
+// Is the ring kernel the automatic choice (kernel == 0)?  WNV_RING=0/1 in the environment overrides.
+bool wnv_ring_default();
 // Builds (once) the ring-specific weight images from the fused host tensors and runs the whole loop.
 wnv_status wnv_ring_generate(WnvRingState** st, int device, const wnv_config& c, const TensorStore& store,
                              const WnvGenArgs& ga, hipStream_t s, std::string& err);

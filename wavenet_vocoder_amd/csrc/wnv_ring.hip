@@ -1,12 +1,592 @@
-// wnv_ring.hip -- pipelined, weight-stationary ring kernel (placeholder until the first GPU round trip
-// of the generic kernel is green; see DESIGN.md section 5 for the design it will hold).
+// wnv_ring.hip -- the pipelined, weight-stationary sample-loop kernel for gfx950 ("ring" kernel).
+//
+// WHY.  One autoregressive step is a chain of L gated layers; for 8 utterances the per-step cost is the latency
+// of that chain, not bandwidth or FLOPs.  A single CU cannot hold the 4.6 MB of weights
+// on the chain (W_cur = the newest conv tap, 128->256, and conv1x1_out, 128->128, per layer), and streaming them
+// every step costs more than the chain itself.  So every utterance (or small group) gets a RING of persistent
+// workgroups, one per CU, each owning two consecutive layers with the chain weights resident on chip:
+//
+//     head -> stage 0 (layers 0,1) -> stage 1 (layers 2,3) -> ... -> stage S-1 -> head -> ...
+//
+//   * W_cur of both layers lives in VGPRs (64 floats per thread per layer), conv1x1_out in LDS (128 KiB);
+//   * the activation vector (128 floats) hops CU -> CU through L2 as 128 data-tagged 8-byte granules
+//     {tag = t+1, value}: ONE write-through (sc1) store per value, the consumer re-reads until every tag
+//     matches -- no flags, no fences, placement-independent (MI355X_MICROARCH.md "handoff-1to1", ~1 us);
+//   * everything that does not sit on the chain is DEFERRED until after the activation has been sent on:
+//     the skip 1x1 (accumulated stage to stage in the reference's layer order through a second granule
+//     mailbox), the history-ring update, and next step's  W_old-taps . h[t+1-k*d] + W_c . c[t+1] + bias, whose
+//     inputs are all known one step early.  Deferred weights are streamed from L2 (K-major rows, 16 B/lane);
+//     a stage has a whole ring trip (~25 us) of slack to do it;
+//   * the head workgroup owns the output MLP (registers), the sampler and first_conv.
+//
+// One launch runs all T steps; the only global synchronisation is the data flow itself.  Every wait is bounded:
+// a spin that exceeds its budget writes a code to `status` and every workgroup drains out (WNV_ERR_TIMEOUT).
+//
+// Reference semantics: wavenet.py:296-336 (loop), modules.py:127-163 (layer), conv.py:33-45 (history taps),
+// mixture.py:118-156 / 221-270 (samplers).  Numerics: fp32 throughout; only the association order of the
+// dot products differs from ATen's (covered by the 1e-4 parity tolerance).
 #include "wnv_ring.h"
 
-bool wnv_ring_supported(const wnv_config&, int) { return false; }
-const char* wnv_ring_why_not(const wnv_config&, int) { return "ring kernel not built in this revision"; }
-wnv_status wnv_ring_generate(WnvRingState**, int, const wnv_config&, const TensorStore&, const WnvGenArgs&,
-                             hipStream_t, std::string& err) {
-    err = "ring kernel not built in this revision";
-    return WNV_ERR_UNSUPPORTED;
+#ifndef WNV_RING_IS_DEFAULT
+#define WNV_RING_IS_DEFAULT 0   // flipped to 1 once the GPU parity suite of the ring kernel is green
+#endif
+
+#include <algorithm>
+#include <cstdlib>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "wnv_matvec.h"
+#include "wnv_sample.h"
+
+namespace {
+
+constexpr int RT = 512;            // threads per workgroup
+constexpr int RW = 8;              // waves per workgroup
+constexpr int RC = 128;            // residual channels this kernel is specialised for
+constexpr int GC = 256;            // gate channels
+constexpr int QS = 36;             // LDS stride of one 32-float quarter (+4 pad: the 4 quarters hit disjoint banks)
+constexpr unsigned SPIN_LIMIT = 1u << 21;
+
+struct RingParams {
+    int n_rings, S, L, B, T, Tt, upr;
+    int K, Kp, O, cin, kw, kpre, nz, dist;
+    int pstride;                       // LDS partial stride (floats) = max(256, Kp)
+    int hist_floats;
+    float skip_scale;
+    const float *w2img, *woimg, *bo, *wpre, *wskip, *bskip;
+    const float *wh1img, *bh1, *wh2img, *bh2, *wfirst, *bfirst;
+    const float* zbias;
+    long long zbias_bstride;
+    const int *lay_dil, *lay_histoff;
+    unsigned long long *hmail, *smail;
+    float* hist;
+    const float *c_up, *initial, *teacher, *noise;
+    unsigned long long seed;
+    float *out, *params_out;
+    unsigned int* status;
+};
+
+using u64 = unsigned long long;
+
+__device__ __forceinline__ u64 ld_granule(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-void wnv_ring_destroy(WnvRingState*) {}
+__device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v) {
+    __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One wave waits until the granule of every ACTIVE lane carries `tag`; returns false on abort/timeout.
+__device__ __forceinline__ bool wave_recv(const u64* g, bool active, unsigned tag, float& v, unsigned int* status,
+                                          unsigned code, int lane) {
+    unsigned spins = 0;
+    for (;;) {
+        bool ok = true;
+        if (active) {
+            const u64 x = ld_granule(g);
+            v = __uint_as_float((unsigned)x);
+            ok = (unsigned)(x >> 32) == tag;
+        }
+        if (__all(ok)) return true;
+        ++spins;
+        if ((spins & 127u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) {
+                if (lane == 0) atomicCAS(status, 0u, code);
+                return false;
+            }
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+// sum over the four lanes l, l^16, l^32, l^48 (the four K-quarters of one output channel)
+__device__ __forceinline__ float quad_allreduce(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+__device__ __forceinline__ void lds_read32(const float* p, float (&x)[32]) {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 v = reinterpret_cast<const float4*>(p)[c];
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+    }
+}
+__device__ __forceinline__ float dot32(const float (&w)[32], const float (&x)[32]) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; k += 4) {
+        a0 = fmaf(w[k], x[k], a0);
+        a1 = fmaf(w[k + 1], x[k + 1], a1);
+        a2 = fmaf(w[k + 2], x[k + 2], a2);
+        a3 = fmaf(w[k + 3], x[k + 3], a3);
+    }
+    return (a0 + a1) + (a2 + a3);
+}
+__device__ __forceinline__ int qidx(int i) { return QS * (i >> 5) + (i & 31); }   // channel -> strided LDS slot
+
+struct StageLds {
+    float4* wo;      // [2][8][512] conv1x1_out images
+    float* hs[3];    // strided activations: input of layer 0, of layer 1, output
+    float* us;       // strided gate output of the layer in flight
+    float* hcont;    // [2][128] layer inputs, contiguous (history / deferred work)
+    float* ucont;    // [2][128] gate outputs, contiguous (skip 1x1)
+    float* xin;      // [512] deferred mat-vec input
+    float* part;     // [8][pstride]
+    float* pre;      // [upr][2][256] next step's tap/conditioning pre-activations
+    int* flags;
+};
+
+__device__ __forceinline__ StageLds carve_stage(float* smem, const RingParams& p) {
+    StageLds s;
+    s.wo = reinterpret_cast<float4*>(smem);
+    float* f = smem + 2 * 8 * RT * 4;
+    s.hs[0] = f; s.hs[1] = f + 4 * QS; s.hs[2] = f + 8 * QS;
+    s.us = f + 12 * QS;
+    s.hcont = f + 16 * QS;              // 576
+    s.ucont = s.hcont + 2 * RC;
+    s.xin = s.ucont + 2 * RC;
+    s.part = s.xin + 512;
+    s.pre = s.part + (size_t)RW * p.pstride;
+    s.flags = reinterpret_cast<int*>(s.pre + (size_t)p.upr * 2 * GC);
+    return s;
+}
+
+// Deferred: pre-activation of layer l for step tp (>= 0) of utterance b, from the history ring and c[tp]:
+//   pre[n] = b_in[n] (+ Wg.g) + sum_{k<kw-1} W[:, :, k] . h_l[tp - (kw-1-k)*d] + W_c . c[tp]       (conv.py:33-45)
+// When t_prev >= 0 the layer input of step t_prev (= tp - 1) is first pushed into the ring.
+__device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds& s, int b, int j, int J, int l,
+                                             int t_prev, int tp, int tid, int wave, int lane) {
+    const int d = p.lay_dil[l];
+    const int rows = (p.kw - 1) * d;
+    float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
+    const int hoff = (p.kw - 1) * RC;
+    if (rows > 0) {
+        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hcont[J * RC + tid];
+        __syncthreads();
+        for (int idx = tid; idx < hoff; idx += RT) {
+            const int k = idx / RC, r = idx - k * RC;
+            s.xin[idx] = hist[(size_t)((tp + k * d) % rows) * RC + r];
+        }
+    }
+    for (int c = tid; c < p.cin; c += RT) s.xin[hoff + c] = p.c_up[((size_t)b * p.T + tp) * p.cin + c];
+    float zb = 0.f;
+    if (tid < GC) zb = p.zbias[(size_t)b * p.zbias_bstride + (size_t)l * GC + tid];
+    __syncthreads();
+    matvec_partial<RW>(p.wpre + (size_t)l * p.kpre * GC, p.kpre, GC, s.xin, s.part, p.pstride, wave, lane);
+    __syncthreads();
+    if (tid < GC) s.pre[((size_t)j * 2 + J) * GC + tid] = reduce_part<RW>(s.part, p.pstride, tid, zb);
+    __syncthreads();
+}
+
+__device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
+    const StageLds s = carve_stage(smem, p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int il = lane & 15, q = lane >> 4, i = wave * 16 + il;
+    const int l0 = 2 * sidx;
+    const bool last_stage = sidx == p.S - 1;
+    const int S1 = p.S + 1;
+
+    // ---- resident weights: newest conv tap in registers, conv1x1_out in LDS ------------------------------
+    float w2a[2][32], w2b[2][32], bo_r[2];
+#pragma unroll
+    for (int J = 0; J < 2; ++J) {
+        const float4* src = reinterpret_cast<const float4*>(p.w2img) + (size_t)(l0 + J) * 16 * RT;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 va = src[(size_t)c * RT + tid], vb = src[(size_t)(8 + c) * RT + tid];
+            w2a[J][4 * c] = va.x; w2a[J][4 * c + 1] = va.y; w2a[J][4 * c + 2] = va.z; w2a[J][4 * c + 3] = va.w;
+            w2b[J][4 * c] = vb.x; w2b[J][4 * c + 1] = vb.y; w2b[J][4 * c + 2] = vb.z; w2b[J][4 * c + 3] = vb.w;
+        }
+        const float4* wsrc = reinterpret_cast<const float4*>(p.woimg) + (size_t)(l0 + J) * 8 * RT;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) s.wo[(size_t)(J * 8 + c) * RT + tid] = wsrc[(size_t)c * RT + tid];
+        bo_r[J] = p.bo[(size_t)(l0 + J) * RC + i];
+    }
+    if (tid == 0) s.flags[0] = 0;
+    __syncthreads();
+
+    // ---- prologue: pre-activations of step 0 (all taps are zero history) ------------------------------------
+    for (int j = 0; j < p.upr; ++j) {
+        const int b = ring + j * p.n_rings;
+        if (b >= p.B) continue;
+#pragma unroll
+        for (int J = 0; J < 2; ++J) deferred_pre(p, s, b, j, J, l0 + J, -1, 0, tid, wave, lane);
+    }
+
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        for (int j = 0; j < p.upr; ++j) {
+            const int b = ring + j * p.n_rings;
+            if (b >= p.B) continue;
+            // ---- receive the activation vector of (b, t) ------------------------------------------------
+            if (wave < 2) {
+                float v = 0.f;
+                const bool ok = wave_recv(p.hmail + ((size_t)b * S1 + sidx) * RC + tid, true, tag, v, p.status,
+                                          0x100u + (unsigned)sidx, lane);
+                if (!ok) s.flags[0] = 1;
+                s.hs[0][qidx(tid)] = v;
+                s.hcont[tid] = v;
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+            // ---- the chain: two gated layers ---------------------------------------------------------------
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                float x[32];
+                lds_read32(s.hs[J] + QS * q, x);
+                float a = dot32(w2a[J], x), g = dot32(w2b[J], x);
+                if (q == 0) {
+                    a += s.pre[((size_t)j * 2 + J) * GC + i];
+                    g += s.pre[((size_t)j * 2 + J) * GC + RC + i];
+                }
+                a = quad_allreduce(a);
+                g = quad_allreduce(g);
+                const float u = tanhf(a) * wnv_sigmoid(g);                      // modules.py:154
+                if (q == 0) { s.us[qidx(i)] = u; s.ucont[J * RC + i] = u; }
+                __syncthreads();
+                if (!(last_stage && J == 1)) {      // the last layer's residual output is never used (wavenet.py:310-313)
+                    float xu[32], wo[32];
+                    lds_read32(s.us + QS * q, xu);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) {
+                        const float4 v = s.wo[(size_t)(J * 8 + c) * RT + tid];
+                        wo[4 * c] = v.x; wo[4 * c + 1] = v.y; wo[4 * c + 2] = v.z; wo[4 * c + 3] = v.w;
+                    }
+                    float o = quad_allreduce(dot32(wo, xu));
+                    const float hn = (o + bo_r[J] + s.hs[J][qidx(i)]) * 0.70710678118654752440f;   // modules.py:162
+                    if (q == 0) {
+                        if (J == 1) st_granule(p.hmail + ((size_t)b * S1 + sidx + 1) * RC + i, tag, hn);   // send on
+                        s.hs[J + 1][qidx(i)] = hn;
+                        if (J == 0) s.hcont[RC + i] = hn;
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- deferred 1: skip 1x1 of both layers, accumulated in the reference's layer order --------------
+            float acc = 0.f;
+            if (sidx > 0 && wave * 64 < p.K) {
+                const bool ok = wave_recv(p.smail + ((size_t)b * S1 + sidx) * p.Kp + tid, tid < p.K, tag, acc, p.status,
+                                          0x200u + (unsigned)sidx, lane);
+                if (!ok) s.flags[0] = 1;
+            }
+#pragma unroll
+            for (int J = 0; J < 2; ++J) {
+                const int l = l0 + J;
+                float bs = 0.f;
+                if (tid < p.K) bs = p.bskip[(size_t)l * p.Kp + tid];
+                matvec_partial<RW>(p.wskip + (size_t)l * RC * p.Kp, RC, p.Kp, s.ucont + J * RC, s.part, p.pstride, wave, lane);
+                __syncthreads();
+                if (s.flags[0]) return;
+                if (tid < p.K) acc += reduce_part<RW>(s.part, p.pstride, tid, bs);               // wavenet.py:312
+                __syncthreads();
+            }
+            if (tid < p.K) st_granule(p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + tid, tag, acc);
+            // ---- deferred 2: history push + next step's pre-activations ----------------------------------------
+            if (t + 1 < p.T) {
+#pragma unroll
+                for (int J = 0; J < 2; ++J) deferred_pre(p, s, b, j, J, l0 + J, t, t + 1, tid, wave, lane);
+            }
+        }
+    }
+}
+
+struct HeadLds {
+    float* vs;     // strided relu(skip * scale)
+    float* hid;    // strided hidden
+    float* obuf;   // [128] head output
+    float* nz;     // [64] noise of this step
+    float* prevx;  // [upr]
+    int* flags;
+};
+
+__device__ void run_head(const RingParams& p, int ring, float* smem) {
+    HeadLds s;
+    s.vs = smem; s.hid = smem + 4 * QS; s.obuf = smem + 8 * QS; s.nz = s.obuf + 128; s.prevx = s.nz + 64;
+    s.flags = reinterpret_cast<int*>(s.prevx + 64);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int il = lane & 15, q = lane >> 4, i = wave * 16 + il;
+    const int S1 = p.S + 1;
+    float wh1[32], wh2[32];
+    {
+        const float4* a = reinterpret_cast<const float4*>(p.wh1img);
+        const float4* c2 = reinterpret_cast<const float4*>(p.wh2img);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float4 va = a[(size_t)c * RT + tid], vb = c2[(size_t)c * RT + tid];
+            wh1[4 * c] = va.x; wh1[4 * c + 1] = va.y; wh1[4 * c + 2] = va.z; wh1[4 * c + 3] = va.w;
+            wh2[4 * c] = vb.x; wh2[4 * c + 1] = vb.y; wh2[4 * c + 2] = vb.z; wh2[4 * c + 3] = vb.w;
+        }
+    }
+    const float bh1 = p.bh1[i], bh2 = p.bh2[i];
+    float wf = 0.f, bf = 0.f;
+    if (tid < RC) { wf = p.wfirst[tid]; bf = p.bfirst[tid]; }
+    if (tid == 0) s.flags[0] = 0;
+    if (tid < 64) s.prevx[tid] = 0.f;
+    __syncthreads();
+
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = (unsigned)t + 1u;
+        for (int j = 0; j < p.upr; ++j) {
+            const int b = ring + j * p.n_rings;
+            if (b >= p.B) continue;
+            // ---- first_conv on this step's input (wavenet.py:297-308) ----------------------------------------
+            float xs;
+            if (t < p.Tt) xs = p.teacher[(size_t)b * p.Tt + t];
+            else if (t == 0) xs = p.initial ? p.initial[b] : 0.f;
+            else xs = s.prevx[j];
+            if (tid < RC) st_granule(p.hmail + ((size_t)b * S1) * RC + tid, tag, fmaf(wf, xs, bf));
+            // noise of this step (independent of the network)
+            if (tid < p.nz) {
+                int kind = 0;
+                if (p.dist == 2 && tid == p.nz - 1) kind = 1;
+                s.nz[tid] = p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, b, tid, kind);
+            }
+            // ---- wait for the accumulated skip vector of (b, t) -----------------------------------------------
+            if (wave < 2) {
+                float v = 0.f;
+                const bool ok = wave_recv(p.smail + ((size_t)b * S1 + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane);
+                if (!ok) s.flags[0] = 1;
+                s.vs[qidx(tid)] = fmaxf(v * p.skip_scale, 0.f);                  // wavenet.py:313-316
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+            float x[32];
+            lds_read32(s.vs + QS * q, x);
+            const float h1 = fmaxf(quad_allreduce(dot32(wh1, x)) + bh1, 0.f);   // wavenet.py:317-318
+            if (q == 0) s.hid[qidx(i)] = h1;
+            __syncthreads();
+            lds_read32(s.hid + QS * q, x);
+            const float o = quad_allreduce(dot32(wh2, x)) + bh2;                  // wavenet.py:319
+            if (q == 0 && i < p.O) {
+                s.obuf[i] = o;
+                if (p.params_out) p.params_out[((size_t)b * p.O + i) * p.T + t] = o;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                const float xo = sample_scalar(p.dist, p.O, s.obuf, s.nz, lane);   // wavenet.py:322-330
+                if (lane == 0) { p.out[(size_t)b * p.T + t] = xo; s.prevx[j] = xo; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // block i -> XCD i % 8 (observed, speed only): ring r lives on one XCD when n_rings == 8
+    const int ring = blockIdx.x % p.n_rings;
+    const int pos = blockIdx.x / p.n_rings;
+    if (pos < p.S) run_stage(p, ring, pos, smem);
+    else run_head(p, ring, smem);
+}
+
+}  // namespace
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct WnvRingState {
+    int device = 0;
+    int L = 0, S = 0, K = 0, Kp = 0, O = 0, cin = 0, kw = 0, kpre = 0;
+    float* d_w = nullptr;          // one blob, offsets below (floats)
+    size_t o_w2 = 0, o_wo = 0, o_bo = 0, o_wpre = 0, o_wskip = 0, o_bskip = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0,
+           o_bh2 = 0, o_wf = 0, o_bf = 0;
+    int* d_dil = nullptr;
+    int* d_histoff = nullptr;
+    int hist_floats = 0;
+    void* d_state = nullptr;       // mailboxes + history + status
+    size_t state_cap = 0;
+};
+
+static const char* why_not(const wnv_config& c, int B) {
+    if (!c.scalar_input) return "one-hot input models run on the generic kernel";
+    if (c.residual_channels != RC || c.gate_channels != GC) return "needs residual_channels == 128 and gate_channels == 256";
+    if (c.skip_out_channels != 128) return "needs skip_out_channels == 128 (head kept in registers)";
+    if (c.out_channels > 128) return "needs out_channels <= 128";
+    if (c.layers % 2 || c.layers < 2) return "needs an even number of layers";
+    if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
+    if (c.cin_channels > 512 - (c.kernel_size - 1) * RC) return "too many local-conditioning channels";
+    if (B > 32) return "more than 32 utterances per call";
+    return nullptr;
+}
+bool wnv_ring_supported(const wnv_config& c, int B) { return why_not(c, B) == nullptr; }
+bool wnv_ring_default() {
+    const char* e = getenv("WNV_RING");
+    if (e && *e) return e[0] != '0';
+    return WNV_RING_IS_DEFAULT != 0;
+}
+const char* wnv_ring_why_not(const wnv_config& c, int B) { const char* w = why_not(c, B); return w ? w : "supported"; }
+
+void wnv_ring_destroy(WnvRingState* st) {
+    if (!st) return;
+    if (st->d_w) (void)hipFree(st->d_w);
+    if (st->d_dil) (void)hipFree(st->d_dil);
+    if (st->d_histoff) (void)hipFree(st->d_histoff);
+    if (st->d_state) (void)hipFree(st->d_state);
+    delete st;
+}
+
+#define RING_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) { err = std::string(#expr) + " failed: " + hipGetErrorString(e__); return WNV_ERR_HIP; } \
+    } while (0)
+
+// thread tid of a 512-thread workgroup owns channel i = 16*(tid>>6) + (tid&15) and K-quarter q = (tid&63)>>4
+static inline void tid_map(int tid, int& i, int& q) { i = 16 * (tid >> 6) + (tid & 15); q = (tid & 63) >> 4; }
+
+// image of a (rows x 128) matrix M (row-major, M[o][k]) for the (o, q) register mapping:
+// chunk c (0..7) of thread tid = M[row_of(tid)][32q + 4c .. +4]
+static void put_image(std::vector<float>& blob, size_t off, const float* M, int row_offset, int n_rows) {
+    for (int tid = 0; tid < RT; ++tid) {
+        int i, q;
+        tid_map(tid, i, q);
+        const int row = row_offset + i;
+        for (int c = 0; c < 8; ++c)
+            for (int e = 0; e < 4; ++e)
+                blob[off + ((size_t)c * RT + tid) * 4 + e] = row < n_rows ? M[(size_t)row * RC + 32 * q + 4 * c + e] : 0.f;
+    }
+}
+
+static wnv_status build_state(WnvRingState** out, int device, const wnv_config& c, const TensorStore& store,
+                              std::string& err) {
+    WnvRingState* st = new WnvRingState();
+    st->device = device;
+    const int L = c.layers, kw = c.kernel_size, cin = c.cin_channels > 0 ? c.cin_channels : 0;
+    const int K = c.skip_out_channels, Kp = (K + 3) & ~3, O = c.out_channels;
+    st->L = L; st->S = L / 2; st->K = K; st->Kp = Kp; st->O = O; st->cin = cin; st->kw = kw;
+    st->kpre = (kw - 1) * RC + cin;
+    std::vector<float> blob;
+    auto alloc = [&](size_t n) { size_t o = (blob.size() + 3) & ~(size_t)3; blob.resize(o + n, 0.f); return o; };
+    auto T = [&](const std::string& n) -> const HostTensor& { return *store.get(n); };
+    st->o_w2 = alloc((size_t)L * 16 * RT * 4);
+    st->o_wo = alloc((size_t)L * 8 * RT * 4);
+    st->o_bo = alloc((size_t)L * RC);
+    st->o_wpre = alloc((size_t)L * st->kpre * GC);
+    st->o_wskip = alloc((size_t)L * RC * Kp);
+    st->o_bskip = alloc((size_t)L * Kp);
+    std::vector<int> dil(L), hoff(L);
+    int hist = 0;
+    const int per = L / c.stacks;
+    std::vector<float> cur((size_t)GC * RC);
+    for (int l = 0; l < L; ++l) {
+        const std::string pfx = "conv_layers." + std::to_string(l) + ".";
+        const HostTensor& wc = T(pfx + "conv.weight");                 // (G, R, kw)
+        // newest tap (k = kw-1) as a (256 x 128) matrix
+        for (int o = 0; o < GC; ++o)
+            for (int ii = 0; ii < RC; ++ii) cur[(size_t)o * RC + ii] = wc.data[((size_t)o * RC + ii) * kw + (kw - 1)];
+        put_image(blob, st->o_w2 + (size_t)l * 16 * RT * 4, cur.data(), 0, GC);                       // tanh half
+        put_image(blob, st->o_w2 + (size_t)l * 16 * RT * 4 + (size_t)8 * RT * 4, cur.data(), RC, GC); // sigmoid half
+        const HostTensor& wo = T(pfx + "conv1x1_out.weight");          // (R, G/2, 1)
+        put_image(blob, st->o_wo + (size_t)l * 8 * RT * 4, wo.data.data(), 0, RC);
+        const HostTensor& bo = T(pfx + "conv1x1_out.bias");
+        std::copy(bo.data.begin(), bo.data.end(), blob.begin() + st->o_bo + (size_t)l * RC);
+        // deferred: older taps (oldest first) then local conditioning, K-major [kpre][256]
+        float* wp = blob.data() + st->o_wpre + (size_t)l * st->kpre * GC;
+        for (int k = 0; k < kw - 1; ++k)
+            for (int ii = 0; ii < RC; ++ii)
+                for (int o = 0; o < GC; ++o) wp[(size_t)(k * RC + ii) * GC + o] = wc.data[((size_t)o * RC + ii) * kw + k];
+        if (cin > 0) {
+            const HostTensor& wcc = T(pfx + "conv1x1c.weight");        // (G, cin, 1)
+            for (int jx = 0; jx < cin; ++jx)
+                for (int o = 0; o < GC; ++o) wp[(size_t)((kw - 1) * RC + jx) * GC + o] = wcc.data[(size_t)o * cin + jx];
+        }
+        const HostTensor& ws = T(pfx + "conv1x1_skip.weight");         // (K, G/2, 1)
+        float* wsk = blob.data() + st->o_wskip + (size_t)l * RC * Kp;
+        for (int ii = 0; ii < RC; ++ii)
+            for (int m = 0; m < K; ++m) wsk[(size_t)ii * Kp + m] = ws.data[(size_t)m * RC + ii];
+        const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
+        std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bskip + (size_t)l * Kp);
+        dil[l] = 1 << (l % per);
+        hoff[l] = hist;
+        hist += (kw - 1) * dil[l] * RC;
+    }
+    st->hist_floats = hist;
+    // head (K == 128): both 1x1s in the (o, q) register mapping, the second zero-padded to 128 rows
+    st->o_wh1 = alloc((size_t)8 * RT * 4);
+    put_image(blob, st->o_wh1, T("last_conv_layers.1.weight").data.data(), 0, K);
+    st->o_bh1 = alloc(RC);
+    std::copy(T("last_conv_layers.1.bias").data.begin(), T("last_conv_layers.1.bias").data.end(), blob.begin() + st->o_bh1);
+    st->o_wh2 = alloc((size_t)8 * RT * 4);
+    put_image(blob, st->o_wh2, T("last_conv_layers.3.weight").data.data(), 0, O);
+    st->o_bh2 = alloc(RC);
+    std::copy(T("last_conv_layers.3.bias").data.begin(), T("last_conv_layers.3.bias").data.end(), blob.begin() + st->o_bh2);
+    st->o_wf = alloc(RC);
+    std::copy(T("first_conv.weight").data.begin(), T("first_conv.weight").data.end(), blob.begin() + st->o_wf);   // (R,1,1)
+    st->o_bf = alloc(RC);
+    std::copy(T("first_conv.bias").data.begin(), T("first_conv.bias").data.end(), blob.begin() + st->o_bf);
+    *out = st;
+    RING_HIP(hipMalloc((void**)&st->d_w, blob.size() * sizeof(float)));
+    RING_HIP(hipMemcpy(st->d_w, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    RING_HIP(hipMalloc((void**)&st->d_dil, L * sizeof(int)));
+    RING_HIP(hipMemcpy(st->d_dil, dil.data(), L * sizeof(int), hipMemcpyHostToDevice));
+    RING_HIP(hipMalloc((void**)&st->d_histoff, L * sizeof(int)));
+    RING_HIP(hipMemcpy(st->d_histoff, hoff.data(), L * sizeof(int), hipMemcpyHostToDevice));
+    return WNV_OK;
+}
+
+wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c, const TensorStore& store,
+                             const WnvGenArgs& ga, hipStream_t stream, std::string& err) {
+    if (!*pst) {
+        wnv_status st0 = build_state(pst, device, c, store, err);
+        if (st0 != WNV_OK) { wnv_ring_destroy(*pst); *pst = nullptr; return st0; }
+    }
+    WnvRingState* st = *pst;
+    const int B = ga.B;
+    const int n_rings = std::min(B, 8);
+    const int upr = (B + n_rings - 1) / n_rings;
+    RingParams p{};
+    p.n_rings = n_rings; p.S = st->S; p.L = st->L; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.upr = upr;
+    p.K = st->K; p.Kp = st->Kp; p.O = st->O; p.cin = st->cin; p.kw = st->kw; p.kpre = st->kpre; p.nz = ga.nz;
+    p.dist = c.output_distribution;
+    p.pstride = std::max(GC, st->Kp);
+    p.hist_floats = st->hist_floats;
+    p.skip_scale = (float)std::sqrt(1.0 / st->L);
+    const float* w = st->d_w;
+    p.w2img = w + st->o_w2; p.woimg = w + st->o_wo; p.bo = w + st->o_bo; p.wpre = w + st->o_wpre;
+    p.wskip = w + st->o_wskip; p.bskip = w + st->o_bskip; p.wh1img = w + st->o_wh1; p.bh1 = w + st->o_bh1;
+    p.wh2img = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf;
+    p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride;
+    p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
+    // state: [status 64 B][hmail B*(S+1)*128 u64][smail B*(S+1)*Kp u64][hist B*hist_floats f32]
+    const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
+    const size_t bytes = 64 + (n_h + n_s) * sizeof(u64) + (size_t)B * st->hist_floats * sizeof(float);
+    if (bytes > st->state_cap) {
+        if (st->d_state) { RING_HIP(hipFree(st->d_state)); st->d_state = nullptr; st->state_cap = 0; }
+        RING_HIP(hipMalloc(&st->d_state, bytes));
+        st->state_cap = bytes;
+    }
+    RING_HIP(hipMemsetAsync(st->d_state, 0, bytes, stream));     // tags 0 = "nothing sent", history = zeros
+    char* base = (char*)st->d_state;
+    p.status = (unsigned int*)base;
+    p.hmail = (u64*)(base + 64);
+    p.smail = p.hmail + n_h;
+    p.hist = (float*)(p.smail + n_s);
+    p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
+    p.out = ga.out; p.params_out = ga.params_out;
+    // LDS: the stage carve is the larger one
+    const size_t lds = ((size_t)2 * 8 * RT * 4 + 16 * QS + 4 * RC + 512 + (size_t)RW * p.pstride + (size_t)upr * 2 * GC + 16) * sizeof(float);
+    if (lds > 160 * 1024) { err = "ring kernel needs too much LDS for this many utterances per ring"; return WNV_ERR_UNSUPPORTED; }
+    RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int grid = n_rings * (st->S + 1);
+    int ncu = 0;
+    RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, st->device));
+    if (grid > ncu) { err = "ring kernel needs one CU per workgroup"; return WNV_ERR_UNSUPPORTED; }
+    hipLaunchKernelGGL(wnv_ring_kernel, dim3(grid), dim3(RT), lds, stream, p);
+    RING_HIP(hipGetLastError());
+    // the ring path is synchronous: a bounded spin that gave up must be reported to the caller
+    unsigned int status = 0;
+    RING_HIP(hipMemcpyAsync(&status, p.status, sizeof status, hipMemcpyDeviceToHost, stream));
+    RING_HIP(hipStreamSynchronize(stream));
+    if (status != 0) {
+        char buf[128];
+        snprintf(buf, sizeof buf, "ring kernel gave up waiting (code 0x%x: 0x1ss = activation into stage ss, 0x2ss = skip into stage ss, 0x300 = head)", status);
+        err = buf;
+        return WNV_ERR_TIMEOUT;
+    }
+    return WNV_OK;
+}

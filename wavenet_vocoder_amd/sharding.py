@@ -1,0 +1,99 @@
+"""Utterance-level sharding of a synthesis job over the GPUs of one node.
+
+Utterances share only read-only weights and the sample loop of one utterance never talks to another, so
+the path shards with NO data-path collective: one process per GPU (torch.distributed, backend "nccl" =
+RCCL over xGMI on the GPU box, "gloo" in the CPU tests), every rank
+  1. holds a replica of the weights (loaded from the checkpoint, or broadcast once from rank 0),
+  2. takes its share of the utterances (longest-processing-time-first over total samples),
+  3. packs them into groups of ``group_size`` of similar length (a group runs to its longest member,
+     exactly like the reference's zero-padded batches, evaluate.py:55-57,215),
+  4. synthesises group by group, trims every waveform to its true length,
+and the results are gathered to rank 0 (variable-length, one object gather at the very end).
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Sequence
+
+import torch
+
+__all__ = ["lpt_assign", "pack_groups", "pad_group", "broadcast_weights", "synthesize_sharded"]
+
+
+def lpt_assign(lengths: Sequence[int], n_bins: int) -> List[List[int]]:
+    """Longest-processing-time-first: utterance indices per bin, balanced on total length."""
+    bins: List[List[int]] = [[] for _ in range(n_bins)]
+    load = [0] * n_bins
+    for i in sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i)):
+        k = min(range(n_bins), key=lambda k: (load[k], k))
+        bins[k].append(i)
+        load[k] += int(lengths[i])
+    return bins
+
+
+def pack_groups(indices: Sequence[int], lengths: Sequence[int], group_size: int) -> List[List[int]]:
+    """Groups of at most ``group_size`` utterances of neighbouring length (descending)."""
+    order = sorted(indices, key=lambda i: (-int(lengths[i]), i))
+    return [order[k:k + group_size] for k in range(0, len(order), group_size)]
+
+
+def pad_group(mels: Sequence[torch.Tensor], cin_pad: int) -> torch.Tensor:
+    """Stack (cin, frames_i) mels into (B, cin, max_frames + 2*cin_pad): zero-pad to the longest
+    (evaluate.py:55-57) then replicate-pad ``cin_pad`` context frames at both ends (evaluate.py:163-164)."""
+    fmax = max(int(m.shape[-1]) for m in mels)
+    out = torch.zeros(len(mels), mels[0].shape[0], fmax, dtype=torch.float32)
+    for i, m in enumerate(mels):
+        out[i, :, : m.shape[-1]] = m
+    if cin_pad > 0:
+        out = torch.nn.functional.pad(out, (cin_pad, cin_pad), mode="replicate")
+    return out
+
+
+def broadcast_weights(model: torch.nn.Module, src: int = 0, group=None) -> None:
+    """One-time replication of the weights from ``src`` (one flat buffer, one collective: the whole egs/mol
+    model is 14.8 MB, far below anything worth bucketing)."""
+    import torch.distributed as dist
+    params = [p.data for p in model.parameters()]
+    flat = torch.cat([p.reshape(-1) for p in params])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.copy_(flat[off:off + n].view_as(p))
+        off += n
+
+
+def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torch.Tensor, List[int]], torch.Tensor],
+                       *, hop_size: int, cin_pad: int, group_size: int = 8, group=None,
+                       gather_to: Optional[int] = 0) -> Optional[List[torch.Tensor]]:
+    """Distribute ``mels`` (list of (cin, frames) tensors, identical on every rank) over the ranks.
+
+    ``synth_group(c, idx)`` receives the padded batch ``c`` (B, cin, frames + 2*cin_pad) and the global utterance
+    indices, and returns the waveforms (B, T) -- on the GPU box that is
+    ``model.incremental_forward(c=c.cuda(), T=frames*hop)[:, 0]``.  Returns the list of trimmed waveforms in the
+    original order on rank ``gather_to`` (on every rank if ``gather_to`` is None), None elsewhere."""
+    import torch.distributed as dist
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
+    lengths = [int(m.shape[-1]) * hop_size for m in mels]
+    mine = lpt_assign(lengths, world)[rank]
+    local = {}
+    for grp in pack_groups(mine, lengths, group_size):
+        c = pad_group([mels[i] for i in grp], cin_pad)
+        wav = synth_group(c, list(grp))
+        for row, i in enumerate(grp):
+            local[i] = wav[row, : lengths[i]].detach().to("cpu")
+    if not distributed:
+        return [local[i] for i in range(len(mels))]
+    if gather_to is None:
+        parts = [None] * world
+        dist.all_gather_object(parts, local, group=group)
+    else:
+        parts = [None] * world if rank == gather_to else None
+        dist.gather_object(local, parts, dst=gather_to, group=group)
+        if rank != gather_to:
+            return None
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    return [merged[i] for i in range(len(mels))]
