@@ -1,0 +1,34 @@
+"""Run the ring kernel once with WNV_RING_TRACE and print a per-stage timeline (debug aid)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/ring_trace.txt"
+os.makedirs(os.path.dirname(out), exist_ok=True)
+os.environ["WNV_RING_TRACE"] = out
+import torch
+from tests._configs import build, inputs
+B, T = int(os.environ.get("B", 8)), 4096
+m = build("cfg2_mol").to("cuda")
+eng = m._get_engine()
+c, _ = inputs("cfg2_mol", B, T)
+c_up = eng.upsample(c.cuda(), T_expected=T)
+eng.generate(B=B, T=T, c_up=c_up, seed=1, kernel=2)
+torch.cuda.synchronize()
+rows = [l.split() for l in open(out) if not l.startswith("#")]
+S = max(int(r[1]) for r in rows)
+steps = sorted({int(r[0]) for r in rows})
+print("step-to-step period (head send -> next head send), ns:")
+hs = {int(r[0]): int(r[2]) for r in rows if int(r[1]) == S}
+print([hs[b] - hs[a] for a, b in zip(steps, steps[1:])])
+t = steps[2]
+print(f"timeline of step {t} (ns, relative to the head's send of this step):")
+base = hs[t]
+prev_send = base
+for pos in list(range(S)) + [S]:
+    r = [x for x in rows if int(x[0]) == t and int(x[1]) == pos][0]
+    v = [int(x) - base if int(x) >= 0 else None for x in r[2:]]
+    if pos < S:
+        print(f" stage {pos:2d}: recv {v[0]:6d} (hop {v[0]-prev_send:5d})  layer0 +{v[1]-v[0]:5d}  layer1/send +{v[2]-v[1]:5d}  skip-sent +{v[3]-v[2]:5d}  deferred-done +{v[4]-v[3]:5d}")
+        prev_send = v[2]
+    else:
+        # head stamps of step t: [0] send (this step), [1] skip received, [2] sample done
+        print(f" head    : skip recv {v[1]:6d} (after last stage send {v[1]-prev_send:5d})  sample done +{v[2]-v[1]:5d}")

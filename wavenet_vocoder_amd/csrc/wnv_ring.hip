@@ -32,6 +32,7 @@
 #endif
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cmath>
 #include <cstring>
@@ -66,6 +67,8 @@ struct RingParams {
     unsigned long long seed;
     float *out, *params_out;
     unsigned int* status;
+    unsigned long long* trace;         // optional [T_trace][S+1][8] wall-clock stamps of utterance 0 (debug)
+    int trace_t0, trace_n;
 };
 
 using u64 = unsigned long long;
@@ -99,6 +102,12 @@ __device__ __forceinline__ bool wave_recv(const u64* g, bool active, unsigned ta
         }
         __builtin_amdgcn_s_sleep(1);
     }
+}
+
+// debug timeline: stamp slot k of (step t, position pos) with the device-wide 100 MHz wall clock
+__device__ __forceinline__ void stamp(const RingParams& p, int b, int t, int pos, int k) {
+    if (p.trace && b == 0 && threadIdx.x == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
+        p.trace[((size_t)(t - p.trace_t0) * (p.S + 1) + pos) * 8 + k] = wall_clock64();
 }
 
 // sum over the four lanes l, l^16, l^32, l^48 (the four K-quarters of one output channel)
@@ -233,6 +242,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             }
             __syncthreads();
             if (s.flags[0]) return;
+            stamp(p, b, t, sidx, 0);
             // ---- the chain: two gated layers ---------------------------------------------------------------
 #pragma unroll
             for (int J = 0; J < 2; ++J) {
@@ -265,6 +275,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                     }
                 }
                 __syncthreads();
+                stamp(p, b, t, sidx, 1 + J);
             }
             // ---- deferred 1: skip 1x1 of both layers, accumulated in the reference's layer order --------------
             float acc = 0.f;
@@ -285,11 +296,13 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 __syncthreads();
             }
             if (tid < p.K) st_granule(p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + tid, tag, acc);
+            stamp(p, b, t, sidx, 3);
             // ---- deferred 2: history push + next step's pre-activations ----------------------------------------
             if (t + 1 < p.T) {
 #pragma unroll
                 for (int J = 0; J < 2; ++J) deferred_pre(p, s, b, j, J, l0 + J, t, t + 1, tid, wave, lane);
             }
+            stamp(p, b, t, sidx, 4);
         }
     }
 }
@@ -339,6 +352,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             else if (t == 0) xs = p.initial ? p.initial[b] : 0.f;
             else xs = s.prevx[j];
             if (tid < RC) st_granule(p.hmail + ((size_t)b * S1) * RC + tid, tag, fmaf(wf, xs, bf));
+            stamp(p, b, t, p.S, 0);
             // noise of this step (independent of the network)
             if (tid < p.nz) {
                 int kind = 0;
@@ -354,6 +368,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             }
             __syncthreads();
             if (s.flags[0]) return;
+            stamp(p, b, t, p.S, 1);
             float x[32];
             lds_read32(s.vs + QS * q, x);
             const float h1 = fmaxf(quad_allreduce(dot32(wh1, x)) + bh1, 0.f);   // wavenet.py:317-318
@@ -371,6 +386,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
                 if (lane == 0) { p.out[(size_t)b * p.T + t] = xo; s.prevx[j] = xo; }
             }
             __syncthreads();
+            stamp(p, b, t, p.S, 2);
         }
     }
 }
@@ -576,12 +592,42 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     int ncu = 0;
     RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, st->device));
     if (grid > ncu) { err = "ring kernel needs one CU per workgroup"; return WNV_ERR_UNSUPPORTED; }
+    // optional timeline (WNV_RING_TRACE=<file>): wall-clock stamps of utterance 0 for 8 steps in mid-run
+    const char* trace_path = getenv("WNV_RING_TRACE");
+    unsigned long long* d_trace = nullptr;
+    const int trace_n = 8;
+    size_t trace_words = 0;
+    if (trace_path && *trace_path && p.T > 64) {
+        trace_words = (size_t)trace_n * (st->S + 1) * 8;
+        RING_HIP(hipMalloc((void**)&d_trace, trace_words * sizeof(unsigned long long)));
+        RING_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
+        p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
+    }
     hipLaunchKernelGGL(wnv_ring_kernel, dim3(grid), dim3(RT), lds, stream, p);
     RING_HIP(hipGetLastError());
     // the ring path is synchronous: a bounded spin that gave up must be reported to the caller
     unsigned int status = 0;
     RING_HIP(hipMemcpyAsync(&status, p.status, sizeof status, hipMemcpyDeviceToHost, stream));
     RING_HIP(hipStreamSynchronize(stream));
+    if (d_trace) {
+        std::vector<unsigned long long> tr(trace_words);
+        RING_HIP(hipMemcpy(tr.data(), d_trace, trace_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(d_trace);
+        if (FILE* f = fopen(trace_path, "w")) {
+            fprintf(f, "# step pos(S=head) stamps[0..4] in ns relative to the head's send of the first traced step (100 MHz wall clock)\n");
+            const unsigned long long t00 = tr[((size_t)0 * (st->S + 1) + st->S) * 8 + 0];
+            for (int tt = 0; tt < trace_n; ++tt)
+                for (int pos = 0; pos <= st->S; ++pos) {
+                    fprintf(f, "%d %d", p.trace_t0 + tt, pos);
+                    for (int k = 0; k < 5; ++k) {
+                        const unsigned long long v = tr[((size_t)tt * (st->S + 1) + pos) * 8 + k];
+                        fprintf(f, " %lld", v ? (long long)(v - t00) * 10 : -1LL);
+                    }
+                    fprintf(f, "\n");
+                }
+            fclose(f);
+        }
+    }
     if (status != 0) {
         char buf[128];
         snprintf(buf, sizeof buf, "ring kernel gave up waiting (code 0x%x: 0x1ss = activation into stage ss, 0x2ss = skip into stage ss, 0x300 = head)", status);
