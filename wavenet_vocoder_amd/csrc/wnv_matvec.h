@@ -68,3 +68,46 @@ __device__ __forceinline__ float reduce_part(const float* part, int pstride, int
     return v;
 }
 
+
+// Register-frugal, always-inlined variant for kernels that keep most of the register file pinned (ring kernel):
+// at most four 16-B loads in flight per lane.
+template <int NW>
+__device__ __forceinline__ void matvec_partial_small(const float* __restrict__ Wt, int K, int Np,
+                                                     const float* __restrict__ x, float* __restrict__ part,
+                                                     int pstride, int wave, int lane) {
+    const int kper = (K + NW - 1) / NW;
+    const int k0 = wave * kper;
+    int k1 = k0 + kper;
+    if (k1 > K) k1 = K;
+    for (int n0 = lane * 4; n0 < Np; n0 += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k0 < K) {
+            const float* wp = Wt + (size_t)k0 * Np + n0;
+            int k = k0;
+            for (; k + 4 <= k1; k += 4) {
+                float4 w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const float4*>(wp + (size_t)j * Np);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xv = x[k + j];
+                    acc.x = fmaf(w[j].x, xv, acc.x);
+                    acc.y = fmaf(w[j].y, xv, acc.y);
+                    acc.z = fmaf(w[j].z, xv, acc.z);
+                    acc.w = fmaf(w[j].w, xv, acc.w);
+                }
+                wp += (size_t)4 * Np;
+            }
+            for (; k < k1; ++k) {
+                const float4 w = *reinterpret_cast<const float4*>(wp);
+                const float xv = x[k];
+                acc.x = fmaf(w.x, xv, acc.x);
+                acc.y = fmaf(w.y, xv, acc.y);
+                acc.z = fmaf(w.z, xv, acc.z);
+                acc.w = fmaf(w.w, xv, acc.w);
+                wp += Np;
+            }
+        }
+        *reinterpret_cast<float4*>(part + (size_t)wave * pstride + n0) = acc;
+    }
+}

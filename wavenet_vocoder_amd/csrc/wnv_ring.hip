@@ -8,7 +8,9 @@
 //
 //     head -> stage 0 (layers 0,1) -> stage 1 (layers 2,3) -> ... -> stage S-1 -> head -> ...
 //
-//   * W_cur of both layers lives in VGPRs (64 floats per thread per layer), conv1x1_out in LDS (128 KiB);
+//   * W_cur and conv1x1_out of both layers live in VGPRs (96 floats per thread per layer), conv1x1_skip in LDS
+//     (128 KiB); the four K-quarters of an output channel sit in ADJACENT lanes, so every reduction is two DPP
+//     quad-permute adds (no LDS shuffles) and the gate uses the hardware exp/rcp;
 //   * the activation vector (128 floats) hops CU -> CU through L2 as 128 data-tagged 8-byte granules
 //     {tag = t+1, value}: ONE write-through (sc1) store per value, the consumer re-reads until every tag
 //     matches -- no flags, no fences, placement-independent (MI355X_MICROARCH.md "handoff-1to1", ~1 us);
@@ -56,7 +58,7 @@ struct RingParams {
     int pstride;                       // LDS partial stride (floats) = max(256, Kp)
     int hist_floats;
     float skip_scale;
-    const float *w2img, *woimg, *bo, *wpre, *wskip, *bskip;
+    const float *w2img, *woimg, *wsimg, *bo, *wpre, *bskip;
     const float *wh1img, *bh1, *wh2img, *bh2, *wfirst, *bfirst;
     const float* zbias;
     long long zbias_bstride;
@@ -110,11 +112,21 @@ __device__ __forceinline__ void stamp(const RingParams& p, int b, int t, int pos
         p.trace[((size_t)(t - p.trace_t0) * (p.S + 1) + pos) * 8 + k] = wall_clock64();
 }
 
-// sum over the four lanes l, l^16, l^32, l^48 (the four K-quarters of one output channel)
+// sum over the four adjacent lanes of a quad (the four K-quarters of one output channel): two DPP quad_perm adds
 __device__ __forceinline__ float quad_allreduce(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    const int a = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
+    v += __int_as_float(a);
+    const int b = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
+    return v + __int_as_float(b);
+}
+
+// tanh(a) * sigmoid(g) with the hardware exp2 / rcp (absolute error ~1e-7; the generic kernel keeps libm's
+// tanhf/expf and is the cross-check):  tanh(a) = sign(a) (1 - e)/(1 + e), e = exp(-2|a|);  sigmoid(g) = 1/(1 + exp(-g))
+__device__ __forceinline__ float fast_gate(float a, float g) {
+    const float e = __expf(-2.0f * fabsf(a));
+    const float f = __expf(-g);
+    const float r = __frcp_rn((1.0f + e) * (1.0f + f));
+    return copysignf((1.0f - e) * r, a);
 }
 
 __device__ __forceinline__ void lds_read32(const float* p, float (&x)[32]) {
@@ -138,11 +150,9 @@ __device__ __forceinline__ float dot32(const float (&w)[32], const float (&x)[32
 __device__ __forceinline__ int qidx(int i) { return QS * (i >> 5) + (i & 31); }   // channel -> strided LDS slot
 
 struct StageLds {
-    float4* wo;      // [2][8][512] conv1x1_out images
+    float4* ws;      // [2][8][512] conv1x1_skip images (K == 128)
     float* hs[3];    // strided activations: input of layer 0, of layer 1, output
-    float* us;       // strided gate output of the layer in flight
-    float* hcont;    // [2][128] layer inputs, contiguous (history / deferred work)
-    float* ucont;    // [2][128] gate outputs, contiguous (skip 1x1)
+    float* us[2];    // strided gate outputs of the two layers
     float* xin;      // [512] deferred mat-vec input
     float* part;     // [8][pstride]
     float* pre;      // [upr][2][256] next step's tap/conditioning pre-activations
@@ -151,13 +161,11 @@ struct StageLds {
 
 __device__ __forceinline__ StageLds carve_stage(float* smem, const RingParams& p) {
     StageLds s;
-    s.wo = reinterpret_cast<float4*>(smem);
+    s.ws = reinterpret_cast<float4*>(smem);
     float* f = smem + 2 * 8 * RT * 4;
     s.hs[0] = f; s.hs[1] = f + 4 * QS; s.hs[2] = f + 8 * QS;
-    s.us = f + 12 * QS;
-    s.hcont = f + 16 * QS;              // 576
-    s.ucont = s.hcont + 2 * RC;
-    s.xin = s.ucont + 2 * RC;
+    s.us[0] = f + 12 * QS; s.us[1] = f + 16 * QS;
+    s.xin = f + 20 * QS;                // 720
     s.part = s.xin + 512;
     s.pre = s.part + (size_t)RW * p.pstride;
     s.flags = reinterpret_cast<int*>(s.pre + (size_t)p.upr * 2 * GC);
@@ -174,7 +182,7 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
     float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
     const int hoff = (p.kw - 1) * RC;
     if (rows > 0) {
-        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hcont[J * RC + tid];
+        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hs[J][qidx(tid)];
         __syncthreads();
         for (int idx = tid; idx < hoff; idx += RT) {
             const int k = idx / RC, r = idx - k * RC;
@@ -185,7 +193,7 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
     float zb = 0.f;
     if (tid < GC) zb = p.zbias[(size_t)b * p.zbias_bstride + (size_t)l * GC + tid];
     __syncthreads();
-    matvec_partial<RW>(p.wpre + (size_t)l * p.kpre * GC, p.kpre, GC, s.xin, s.part, p.pstride, wave, lane);
+    matvec_partial_small<RW>(p.wpre + (size_t)l * p.kpre * GC, p.kpre, GC, s.xin, s.part, p.pstride, wave, lane);
     __syncthreads();
     if (tid < GC) s.pre[((size_t)j * 2 + J) * GC + tid] = reduce_part<RW>(s.part, p.pstride, tid, zb);
     __syncthreads();
@@ -194,26 +202,29 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
 __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
     const StageLds s = carve_stage(smem, p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int il = lane & 15, q = lane >> 4, i = wave * 16 + il;
+    const int q = lane & 3, i = wave * 16 + (lane >> 2);        // K-quarter, output channel
     const int l0 = 2 * sidx;
     const bool last_stage = sidx == p.S - 1;
     const int S1 = p.S + 1;
 
-    // ---- resident weights: newest conv tap in registers, conv1x1_out in LDS ------------------------------
-    float w2a[2][32], w2b[2][32], bo_r[2];
+    // ---- resident weights: newest conv tap + conv1x1_out in registers, conv1x1_skip in LDS ------------------
+    float w2a[2][32], w2b[2][32], wo[2][32], bo_r[2], bs_r[2];
 #pragma unroll
     for (int J = 0; J < 2; ++J) {
         const float4* src = reinterpret_cast<const float4*>(p.w2img) + (size_t)(l0 + J) * 16 * RT;
+        const float4* osrc = reinterpret_cast<const float4*>(p.woimg) + (size_t)(l0 + J) * 8 * RT;
+        const float4* ssrc = reinterpret_cast<const float4*>(p.wsimg) + (size_t)(l0 + J) * 8 * RT;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float4 va = src[(size_t)c * RT + tid], vb = src[(size_t)(8 + c) * RT + tid];
+            const float4 vo = osrc[(size_t)c * RT + tid];
             w2a[J][4 * c] = va.x; w2a[J][4 * c + 1] = va.y; w2a[J][4 * c + 2] = va.z; w2a[J][4 * c + 3] = va.w;
             w2b[J][4 * c] = vb.x; w2b[J][4 * c + 1] = vb.y; w2b[J][4 * c + 2] = vb.z; w2b[J][4 * c + 3] = vb.w;
+            wo[J][4 * c] = vo.x; wo[J][4 * c + 1] = vo.y; wo[J][4 * c + 2] = vo.z; wo[J][4 * c + 3] = vo.w;
+            s.ws[(size_t)(J * 8 + c) * RT + tid] = ssrc[(size_t)c * RT + tid];
         }
-        const float4* wsrc = reinterpret_cast<const float4*>(p.woimg) + (size_t)(l0 + J) * 8 * RT;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) s.wo[(size_t)(J * 8 + c) * RT + tid] = wsrc[(size_t)c * RT + tid];
         bo_r[J] = p.bo[(size_t)(l0 + J) * RC + i];
+        bs_r[J] = p.bskip[(size_t)(l0 + J) * p.Kp + i];
     }
     if (tid == 0) s.flags[0] = 0;
     __syncthreads();
@@ -238,7 +249,6 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                                           0x100u + (unsigned)sidx, lane);
                 if (!ok) s.flags[0] = 1;
                 s.hs[0][qidx(tid)] = v;
-                s.hcont[tid] = v;
             }
             __syncthreads();
             if (s.flags[0]) return;
@@ -255,53 +265,58 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 }
                 a = quad_allreduce(a);
                 g = quad_allreduce(g);
-                const float u = tanhf(a) * wnv_sigmoid(g);                      // modules.py:154
-                if (q == 0) { s.us[qidx(i)] = u; s.ucont[J * RC + i] = u; }
+                const float u = fast_gate(a, g);                                // modules.py:154
+                if (q == 0) s.us[J][qidx(i)] = u;
                 __syncthreads();
                 if (!(last_stage && J == 1)) {      // the last layer's residual output is never used (wavenet.py:310-313)
-                    float xu[32], wo[32];
-                    lds_read32(s.us + QS * q, xu);
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) {
-                        const float4 v = s.wo[(size_t)(J * 8 + c) * RT + tid];
-                        wo[4 * c] = v.x; wo[4 * c + 1] = v.y; wo[4 * c + 2] = v.z; wo[4 * c + 3] = v.w;
-                    }
-                    float o = quad_allreduce(dot32(wo, xu));
+                    float xu[32];
+                    lds_read32(s.us[J] + QS * q, xu);
+                    const float o = quad_allreduce(dot32(wo[J], xu));
                     const float hn = (o + bo_r[J] + s.hs[J][qidx(i)]) * 0.70710678118654752440f;   // modules.py:162
                     if (q == 0) {
                         if (J == 1) st_granule(p.hmail + ((size_t)b * S1 + sidx + 1) * RC + i, tag, hn);   // send on
                         s.hs[J + 1][qidx(i)] = hn;
-                        if (J == 0) s.hcont[RC + i] = hn;
                     }
                 }
-                __syncthreads();
+                if (J == 0) __syncthreads();
                 stamp(p, b, t, sidx, 1 + J);
             }
-            // ---- deferred 1: skip 1x1 of both layers, accumulated in the reference's layer order --------------
-            float acc = 0.f;
-            if (sidx > 0 && wave * 64 < p.K) {
-                const bool ok = wave_recv(p.smail + ((size_t)b * S1 + sidx) * p.Kp + tid, tid < p.K, tag, acc, p.status,
-                                          0x200u + (unsigned)sidx, lane);
+            // ---- deferred 1: skip 1x1 of both layers from LDS, accumulated in the reference's layer order -----
+            // (per wave, no barrier: the wave owns 16 skip channels; us[0] / us[1] are complete since the barriers above)
+            {
+                float acc = 0.f;
+                bool ok = true;
+                if (sidx > 0)
+                    ok = wave_recv(p.smail + ((size_t)b * S1 + sidx) * p.Kp + i, q == 0, tag, acc, p.status,
+                                   0x200u + (unsigned)sidx, lane);
+#pragma unroll 1
+                for (int J = 0; J < 2; ++J) {
+                    // rolled on purpose: off the chain, and it must not compete with the pinned weights for registers
+                    const float4* up = reinterpret_cast<const float4*>(s.us[J] + QS * q);
+                    const float4* wp = s.ws + (size_t)J * 8 * RT + tid;
+                    float d0 = 0.f, d1 = 0.f;
+#pragma unroll 1
+                    for (int c = 0; c < 8; c += 2) {
+                        const float4 u0 = up[c], u1 = up[c + 1];
+                        const float4 w0 = wp[(size_t)c * RT], w1 = wp[(size_t)(c + 1) * RT];
+                        d0 = fmaf(w0.x, u0.x, d0); d0 = fmaf(w0.y, u0.y, d0); d0 = fmaf(w0.z, u0.z, d0); d0 = fmaf(w0.w, u0.w, d0);
+                        d1 = fmaf(w1.x, u1.x, d1); d1 = fmaf(w1.y, u1.y, d1); d1 = fmaf(w1.z, u1.z, d1); d1 = fmaf(w1.w, u1.w, d1);
+                    }
+                    acc += quad_allreduce(d0 + d1) + (J == 0 ? bs_r[0] : bs_r[1]);      // wavenet.py:312
+                }
+                if (q == 0 && ok) st_granule(p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + i, tag, acc);
                 if (!ok) s.flags[0] = 1;
             }
-#pragma unroll
-            for (int J = 0; J < 2; ++J) {
-                const int l = l0 + J;
-                float bs = 0.f;
-                if (tid < p.K) bs = p.bskip[(size_t)l * p.Kp + tid];
-                matvec_partial<RW>(p.wskip + (size_t)l * RC * p.Kp, RC, p.Kp, s.ucont + J * RC, s.part, p.pstride, wave, lane);
-                __syncthreads();
-                if (s.flags[0]) return;
-                if (tid < p.K) acc += reduce_part<RW>(s.part, p.pstride, tid, bs);               // wavenet.py:312
-                __syncthreads();
-            }
-            if (tid < p.K) st_granule(p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + tid, tag, acc);
             stamp(p, b, t, sidx, 3);
             // ---- deferred 2: history push + next step's pre-activations ----------------------------------------
+            // (the barriers inside also fence us[]/hs[] against the next receive)
             if (t + 1 < p.T) {
 #pragma unroll
                 for (int J = 0; J < 2; ++J) deferred_pre(p, s, b, j, J, l0 + J, t, t + 1, tid, wave, lane);
+            } else {
+                __syncthreads();
             }
+            if (s.flags[0]) return;
             stamp(p, b, t, sidx, 4);
         }
     }
@@ -321,7 +336,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
     s.vs = smem; s.hid = smem + 4 * QS; s.obuf = smem + 8 * QS; s.nz = s.obuf + 128; s.prevx = s.nz + 64;
     s.flags = reinterpret_cast<int*>(s.prevx + 64);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int il = lane & 15, q = lane >> 4, i = wave * 16 + il;
+    const int q = lane & 3, i = wave * 16 + (lane >> 2);
     const int S1 = p.S + 1;
     float wh1[32], wh2[32];
     {
@@ -409,7 +424,7 @@ struct WnvRingState {
     int device = 0;
     int L = 0, S = 0, K = 0, Kp = 0, O = 0, cin = 0, kw = 0, kpre = 0;
     float* d_w = nullptr;          // one blob, offsets below (floats)
-    size_t o_w2 = 0, o_wo = 0, o_bo = 0, o_wpre = 0, o_wskip = 0, o_bskip = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0,
+    size_t o_w2 = 0, o_wo = 0, o_bo = 0, o_wpre = 0, o_ws = 0, o_bskip = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0,
            o_bh2 = 0, o_wf = 0, o_bf = 0;
     int* d_dil = nullptr;
     int* d_histoff = nullptr;
@@ -452,8 +467,8 @@ void wnv_ring_destroy(WnvRingState* st) {
         if (e__ != hipSuccess) { err = std::string(#expr) + " failed: " + hipGetErrorString(e__); return WNV_ERR_HIP; } \
     } while (0)
 
-// thread tid of a 512-thread workgroup owns channel i = 16*(tid>>6) + (tid&15) and K-quarter q = (tid&63)>>4
-static inline void tid_map(int tid, int& i, int& q) { i = 16 * (tid >> 6) + (tid & 15); q = (tid & 63) >> 4; }
+// thread tid of a 512-thread workgroup owns channel i = 16*(tid>>6) + ((tid&63)>>2) and K-quarter q = tid&3
+static inline void tid_map(int tid, int& i, int& q) { i = 16 * (tid >> 6) + ((tid & 63) >> 2); q = tid & 3; }
 
 // image of a (rows x 128) matrix M (row-major, M[o][k]) for the (o, q) register mapping:
 // chunk c (0..7) of thread tid = M[row_of(tid)][32q + 4c .. +4]
@@ -483,7 +498,7 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     st->o_wo = alloc((size_t)L * 8 * RT * 4);
     st->o_bo = alloc((size_t)L * RC);
     st->o_wpre = alloc((size_t)L * st->kpre * GC);
-    st->o_wskip = alloc((size_t)L * RC * Kp);
+    st->o_ws = alloc((size_t)L * 8 * RT * 4);
     st->o_bskip = alloc((size_t)L * Kp);
     std::vector<int> dil(L), hoff(L);
     int hist = 0;
@@ -511,10 +526,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
             for (int jx = 0; jx < cin; ++jx)
                 for (int o = 0; o < GC; ++o) wp[(size_t)((kw - 1) * RC + jx) * GC + o] = wcc.data[(size_t)o * cin + jx];
         }
-        const HostTensor& ws = T(pfx + "conv1x1_skip.weight");         // (K, G/2, 1)
-        float* wsk = blob.data() + st->o_wskip + (size_t)l * RC * Kp;
-        for (int ii = 0; ii < RC; ++ii)
-            for (int m = 0; m < K; ++m) wsk[(size_t)ii * Kp + m] = ws.data[(size_t)m * RC + ii];
+        const HostTensor& ws = T(pfx + "conv1x1_skip.weight");         // (K = 128, G/2, 1)
+        put_image(blob, st->o_ws + (size_t)l * 8 * RT * 4, ws.data.data(), 0, K);
         const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
         std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bskip + (size_t)l * Kp);
         dil[l] = 1 << (l % per);
@@ -564,7 +577,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.skip_scale = (float)std::sqrt(1.0 / st->L);
     const float* w = st->d_w;
     p.w2img = w + st->o_w2; p.woimg = w + st->o_wo; p.bo = w + st->o_bo; p.wpre = w + st->o_wpre;
-    p.wskip = w + st->o_wskip; p.bskip = w + st->o_bskip; p.wh1img = w + st->o_wh1; p.bh1 = w + st->o_bh1;
+    p.wsimg = w + st->o_ws; p.bskip = w + st->o_bskip; p.wh1img = w + st->o_wh1; p.bh1 = w + st->o_bh1;
     p.wh2img = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf;
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
@@ -585,7 +598,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.out = ga.out; p.params_out = ga.params_out;
     // LDS: the stage carve is the larger one
-    const size_t lds = ((size_t)2 * 8 * RT * 4 + 16 * QS + 4 * RC + 512 + (size_t)RW * p.pstride + (size_t)upr * 2 * GC + 16) * sizeof(float);
+    const size_t lds = ((size_t)2 * 8 * RT * 4 + 20 * QS + 512 + (size_t)RW * p.pstride + (size_t)upr * 2 * GC + 16) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS for this many utterances per ring"; return WNV_ERR_UNSUPPORTED; }
     RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = n_rings * (st->S + 1);
