@@ -4,13 +4,16 @@
 // of that chain, not bandwidth or FLOPs.  A single CU cannot hold the 4.6 MB of weights
 // on the chain (W_cur = the newest conv tap, 128->256, and conv1x1_out, 128->128, per layer), and streaming them
 // every step costs more than the chain itself.  So every utterance (or small group) gets a RING of persistent
-// workgroups, one per CU, each owning two consecutive layers with the chain weights resident on chip:
+// workgroups, one per CU, each owning ONE layer with all of its chain weights resident in registers:
 //
-//     head -> stage 0 (layers 0,1) -> stage 1 (layers 2,3) -> ... -> stage S-1 -> head -> ...
+//     head -> stage 0 (layer 0) -> stage 1 (layer 1) -> ... -> stage L-1 -> head -> ...
 //
-//   * W_cur and conv1x1_out of both layers live in VGPRs (96 floats per thread per layer), conv1x1_skip in LDS
-//     (128 KiB); the four K-quarters of an output channel sit in ADJACENT lanes, so every reduction is two DPP
-//     quad-permute adds (no LDS shuffles) and the gate uses the hardware exp/rcp;
+// (Measured on MI355X: a CU->CU hop through L2 costs ~0.6 us and a layer ~0.7 us; two layers per stage would
+// halve the hops but needs 192 pinned VGPRs + transients, which hipcc spills -- the reloads cost more than the hop.)
+//
+//   * W_cur, conv1x1_out and conv1x1_skip of the layer live in VGPRs (128 floats per thread); the four K-quarters
+//     of an output channel sit in ADJACENT lanes, so every reduction is two DPP quad-permute adds (no LDS
+//     shuffles) and the gate uses the hardware exp/rcp;
 //   * the activation vector (128 floats) hops CU -> CU through L2 as 128 data-tagged 8-byte granules
 //     {tag = t+1, value}: ONE write-through (sc1) store per value, the consumer re-reads until every tag
 //     matches -- no flags, no fences, placement-independent (MI355X_MICROARCH.md "handoff-1to1", ~1 us);
@@ -150,39 +153,36 @@ __device__ __forceinline__ float dot32(const float (&w)[32], const float (&x)[32
 __device__ __forceinline__ int qidx(int i) { return QS * (i >> 5) + (i & 31); }   // channel -> strided LDS slot
 
 struct StageLds {
-    float4* ws;      // [2][8][512] conv1x1_skip images (K == 128)
-    float* hs[3];    // strided activations: input of layer 0, of layer 1, output
-    float* us[2];    // strided gate outputs of the two layers
+    float* hs;       // strided layer input h_l[t]
+    float* us;       // strided gate output
     float* xin;      // [512] deferred mat-vec input
     float* part;     // [8][pstride]
-    float* pre;      // [upr][2][256] next step's tap/conditioning pre-activations
+    float* pre;      // [upr][256] next step's tap/conditioning pre-activations
     int* flags;
 };
 
 __device__ __forceinline__ StageLds carve_stage(float* smem, const RingParams& p) {
     StageLds s;
-    s.ws = reinterpret_cast<float4*>(smem);
-    float* f = smem + 2 * 8 * RT * 4;
-    s.hs[0] = f; s.hs[1] = f + 4 * QS; s.hs[2] = f + 8 * QS;
-    s.us[0] = f + 12 * QS; s.us[1] = f + 16 * QS;
-    s.xin = f + 20 * QS;                // 720
+    s.hs = smem;
+    s.us = smem + 4 * QS;
+    s.xin = smem + 8 * QS;              // 288
     s.part = s.xin + 512;
     s.pre = s.part + (size_t)RW * p.pstride;
-    s.flags = reinterpret_cast<int*>(s.pre + (size_t)p.upr * 2 * GC);
+    s.flags = reinterpret_cast<int*>(s.pre + (size_t)p.upr * GC);
     return s;
 }
 
 // Deferred: pre-activation of layer l for step tp (>= 0) of utterance b, from the history ring and c[tp]:
 //   pre[n] = b_in[n] (+ Wg.g) + sum_{k<kw-1} W[:, :, k] . h_l[tp - (kw-1-k)*d] + W_c . c[tp]       (conv.py:33-45)
 // When t_prev >= 0 the layer input of step t_prev (= tp - 1) is first pushed into the ring.
-__device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds& s, int b, int j, int J, int l,
+__device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds& s, int b, int j, int l,
                                              int t_prev, int tp, int tid, int wave, int lane) {
     const int d = p.lay_dil[l];
     const int rows = (p.kw - 1) * d;
     float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
     const int hoff = (p.kw - 1) * RC;
     if (rows > 0) {
-        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hs[J][qidx(tid)];
+        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hs[qidx(tid)];
         __syncthreads();
         for (int idx = tid; idx < hoff; idx += RT) {
             const int k = idx / RC, r = idx - k * RC;
@@ -195,7 +195,7 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
     __syncthreads();
     matvec_partial_small<RW>(p.wpre + (size_t)l * p.kpre * GC, p.kpre, GC, s.xin, s.part, p.pstride, wave, lane);
     __syncthreads();
-    if (tid < GC) s.pre[((size_t)j * 2 + J) * GC + tid] = reduce_part<RW>(s.part, p.pstride, tid, zb);
+    if (tid < GC) s.pre[(size_t)j * GC + tid] = reduce_part<RW>(s.part, p.pstride, tid, zb);
     __syncthreads();
 }
 
@@ -203,38 +203,35 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     const StageLds s = carve_stage(smem, p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, i = wave * 16 + (lane >> 2);        // K-quarter, output channel
-    const int l0 = 2 * sidx;
+    const int l = sidx;
     const bool last_stage = sidx == p.S - 1;
     const int S1 = p.S + 1;
 
-    // ---- resident weights: newest conv tap + conv1x1_out in registers, conv1x1_skip in LDS ------------------
-    float w2a[2][32], w2b[2][32], wo[2][32], bo_r[2], bs_r[2];
-#pragma unroll
-    for (int J = 0; J < 2; ++J) {
-        const float4* src = reinterpret_cast<const float4*>(p.w2img) + (size_t)(l0 + J) * 16 * RT;
-        const float4* osrc = reinterpret_cast<const float4*>(p.woimg) + (size_t)(l0 + J) * 8 * RT;
-        const float4* ssrc = reinterpret_cast<const float4*>(p.wsimg) + (size_t)(l0 + J) * 8 * RT;
+    // ---- resident weights (registers): newest conv tap (tanh / sigmoid halves), conv1x1_out, conv1x1_skip ----
+    float w2a[32], w2b[32], wo[32], ws[32];
+    {
+        const float4* src = reinterpret_cast<const float4*>(p.w2img) + (size_t)l * 16 * RT;
+        const float4* osrc = reinterpret_cast<const float4*>(p.woimg) + (size_t)l * 8 * RT;
+        const float4* ssrc = reinterpret_cast<const float4*>(p.wsimg) + (size_t)l * 8 * RT;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float4 va = src[(size_t)c * RT + tid], vb = src[(size_t)(8 + c) * RT + tid];
-            const float4 vo = osrc[(size_t)c * RT + tid];
-            w2a[J][4 * c] = va.x; w2a[J][4 * c + 1] = va.y; w2a[J][4 * c + 2] = va.z; w2a[J][4 * c + 3] = va.w;
-            w2b[J][4 * c] = vb.x; w2b[J][4 * c + 1] = vb.y; w2b[J][4 * c + 2] = vb.z; w2b[J][4 * c + 3] = vb.w;
-            wo[J][4 * c] = vo.x; wo[J][4 * c + 1] = vo.y; wo[J][4 * c + 2] = vo.z; wo[J][4 * c + 3] = vo.w;
-            s.ws[(size_t)(J * 8 + c) * RT + tid] = ssrc[(size_t)c * RT + tid];
+            const float4 vo = osrc[(size_t)c * RT + tid], vs = ssrc[(size_t)c * RT + tid];
+            w2a[4 * c] = va.x; w2a[4 * c + 1] = va.y; w2a[4 * c + 2] = va.z; w2a[4 * c + 3] = va.w;
+            w2b[4 * c] = vb.x; w2b[4 * c + 1] = vb.y; w2b[4 * c + 2] = vb.z; w2b[4 * c + 3] = vb.w;
+            wo[4 * c] = vo.x; wo[4 * c + 1] = vo.y; wo[4 * c + 2] = vo.z; wo[4 * c + 3] = vo.w;
+            ws[4 * c] = vs.x; ws[4 * c + 1] = vs.y; ws[4 * c + 2] = vs.z; ws[4 * c + 3] = vs.w;
         }
-        bo_r[J] = p.bo[(size_t)(l0 + J) * RC + i];
-        bs_r[J] = p.bskip[(size_t)(l0 + J) * p.Kp + i];
     }
+    const float bo_r = p.bo[(size_t)l * RC + i];
+    const float bs_r = p.bskip[(size_t)l * p.Kp + i];
     if (tid == 0) s.flags[0] = 0;
     __syncthreads();
 
     // ---- prologue: pre-activations of step 0 (all taps are zero history) ------------------------------------
     for (int j = 0; j < p.upr; ++j) {
         const int b = ring + j * p.n_rings;
-        if (b >= p.B) continue;
-#pragma unroll
-        for (int J = 0; J < 2; ++J) deferred_pre(p, s, b, j, J, l0 + J, -1, 0, tid, wave, lane);
+        if (b < p.B) deferred_pre(p, s, b, j, l, -1, 0, tid, wave, lane);
     }
 
     for (int t = 0; t < p.T; ++t) {
@@ -248,74 +245,50 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 const bool ok = wave_recv(p.hmail + ((size_t)b * S1 + sidx) * RC + tid, true, tag, v, p.status,
                                           0x100u + (unsigned)sidx, lane);
                 if (!ok) s.flags[0] = 1;
-                s.hs[0][qidx(tid)] = v;
+                s.hs[qidx(tid)] = v;
             }
             __syncthreads();
             if (s.flags[0]) return;
             stamp(p, b, t, sidx, 0);
-            // ---- the chain: two gated layers ---------------------------------------------------------------
-#pragma unroll
-            for (int J = 0; J < 2; ++J) {
+            // ---- the chain: newest tap + pre -> gate -> conv1x1_out -> residual -> send -------------------------
+            float xu[32];
+            {
                 float x[32];
-                lds_read32(s.hs[J] + QS * q, x);
-                float a = dot32(w2a[J], x), g = dot32(w2b[J], x);
+                lds_read32(s.hs + QS * q, x);
+                float a = dot32(w2a, x), g = dot32(w2b, x);
                 if (q == 0) {
-                    a += s.pre[((size_t)j * 2 + J) * GC + i];
-                    g += s.pre[((size_t)j * 2 + J) * GC + RC + i];
+                    a += s.pre[(size_t)j * GC + i];
+                    g += s.pre[(size_t)j * GC + RC + i];
                 }
                 a = quad_allreduce(a);
                 g = quad_allreduce(g);
                 const float u = fast_gate(a, g);                                // modules.py:154
-                if (q == 0) s.us[J][qidx(i)] = u;
-                __syncthreads();
-                if (!(last_stage && J == 1)) {      // the last layer's residual output is never used (wavenet.py:310-313)
-                    float xu[32];
-                    lds_read32(s.us[J] + QS * q, xu);
-                    const float o = quad_allreduce(dot32(wo[J], xu));
-                    const float hn = (o + bo_r[J] + s.hs[J][qidx(i)]) * 0.70710678118654752440f;   // modules.py:162
-                    if (q == 0) {
-                        if (J == 1) st_granule(p.hmail + ((size_t)b * S1 + sidx + 1) * RC + i, tag, hn);   // send on
-                        s.hs[J + 1][qidx(i)] = hn;
-                    }
-                }
-                if (J == 0) __syncthreads();
-                stamp(p, b, t, sidx, 1 + J);
+                if (q == 0) s.us[qidx(i)] = u;
             }
-            // ---- deferred 1: skip 1x1 of both layers from LDS, accumulated in the reference's layer order -----
-            // (per wave, no barrier: the wave owns 16 skip channels; us[0] / us[1] are complete since the barriers above)
+            __syncthreads();
+            stamp(p, b, t, sidx, 1);
+            lds_read32(s.us + QS * q, xu);
+            if (!last_stage) {                      // the last layer's residual output is never used (wavenet.py:310-313)
+                const float o = quad_allreduce(dot32(wo, xu));
+                const float hn = (o + bo_r + s.hs[qidx(i)]) * 0.70710678118654752440f;   // modules.py:162
+                if (q == 0) st_granule(p.hmail + ((size_t)b * S1 + sidx + 1) * RC + i, tag, hn);    // send on
+            }
+            stamp(p, b, t, sidx, 2);
+            // ---- deferred 1: skip 1x1 from the same registers, accumulated in the reference's layer order -----------
             {
                 float acc = 0.f;
                 bool ok = true;
                 if (sidx > 0)
                     ok = wave_recv(p.smail + ((size_t)b * S1 + sidx) * p.Kp + i, q == 0, tag, acc, p.status,
                                    0x200u + (unsigned)sidx, lane);
-#pragma unroll 1
-                for (int J = 0; J < 2; ++J) {
-                    // rolled on purpose: off the chain, and it must not compete with the pinned weights for registers
-                    const float4* up = reinterpret_cast<const float4*>(s.us[J] + QS * q);
-                    const float4* wp = s.ws + (size_t)J * 8 * RT + tid;
-                    float d0 = 0.f, d1 = 0.f;
-#pragma unroll 1
-                    for (int c = 0; c < 8; c += 2) {
-                        const float4 u0 = up[c], u1 = up[c + 1];
-                        const float4 w0 = wp[(size_t)c * RT], w1 = wp[(size_t)(c + 1) * RT];
-                        d0 = fmaf(w0.x, u0.x, d0); d0 = fmaf(w0.y, u0.y, d0); d0 = fmaf(w0.z, u0.z, d0); d0 = fmaf(w0.w, u0.w, d0);
-                        d1 = fmaf(w1.x, u1.x, d1); d1 = fmaf(w1.y, u1.y, d1); d1 = fmaf(w1.z, u1.z, d1); d1 = fmaf(w1.w, u1.w, d1);
-                    }
-                    acc += quad_allreduce(d0 + d1) + (J == 0 ? bs_r[0] : bs_r[1]);      // wavenet.py:312
-                }
+                acc += quad_allreduce(dot32(ws, xu)) + bs_r;                     // wavenet.py:312
                 if (q == 0 && ok) st_granule(p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + i, tag, acc);
                 if (!ok) s.flags[0] = 1;
             }
             stamp(p, b, t, sidx, 3);
-            // ---- deferred 2: history push + next step's pre-activations ----------------------------------------
-            // (the barriers inside also fence us[]/hs[] against the next receive)
-            if (t + 1 < p.T) {
-#pragma unroll
-                for (int J = 0; J < 2; ++J) deferred_pre(p, s, b, j, J, l0 + J, t, t + 1, tid, wave, lane);
-            } else {
-                __syncthreads();
-            }
+            // ---- deferred 2: history push + next step's pre-activations (its barriers fence hs/us for the next receive)
+            if (t + 1 < p.T) deferred_pre(p, s, b, j, l, t, t + 1, tid, wave, lane);
+            else __syncthreads();
             if (s.flags[0]) return;
             stamp(p, b, t, sidx, 4);
         }
@@ -438,9 +411,9 @@ static const char* why_not(const wnv_config& c, int B) {
     if (c.residual_channels != RC || c.gate_channels != GC) return "needs residual_channels == 128 and gate_channels == 256";
     if (c.skip_out_channels != 128) return "needs skip_out_channels == 128 (head kept in registers)";
     if (c.out_channels > 128) return "needs out_channels <= 128";
-    if (c.layers % 2 || c.layers < 2) return "needs an even number of layers";
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 512 - (c.kernel_size - 1) * RC) return "too many local-conditioning channels";
+    if (c.layers + 1 > 240) return "too many layers for one ring";
     if (B > 32) return "more than 32 utterances per call";
     return nullptr;
 }
@@ -489,7 +462,7 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     st->device = device;
     const int L = c.layers, kw = c.kernel_size, cin = c.cin_channels > 0 ? c.cin_channels : 0;
     const int K = c.skip_out_channels, Kp = (K + 3) & ~3, O = c.out_channels;
-    st->L = L; st->S = L / 2; st->K = K; st->Kp = Kp; st->O = O; st->cin = cin; st->kw = kw;
+    st->L = L; st->S = L; st->K = K; st->Kp = Kp; st->O = O; st->cin = cin; st->kw = kw;
     st->kpre = (kw - 1) * RC + cin;
     std::vector<float> blob;
     auto alloc = [&](size_t n) { size_t o = (blob.size() + 3) & ~(size_t)3; blob.resize(o + n, 0.f); return o; };
@@ -566,7 +539,10 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     }
     WnvRingState* st = *pst;
     const int B = ga.B;
-    const int n_rings = std::min(B, 8);
+    int ncu = 0;
+    RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, st->device));
+    // one workgroup per CU, one ring per utterance slot; at most 8 rings (one per XCD) and never more than fit
+    const int n_rings = std::max(1, std::min(std::min(B, 8), ncu / (st->S + 1)));
     const int upr = (B + n_rings - 1) / n_rings;
     RingParams p{};
     p.n_rings = n_rings; p.S = st->S; p.L = st->L; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.upr = upr;
@@ -598,12 +574,10 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.out = ga.out; p.params_out = ga.params_out;
     // LDS: the stage carve is the larger one
-    const size_t lds = ((size_t)2 * 8 * RT * 4 + 20 * QS + 512 + (size_t)RW * p.pstride + (size_t)upr * 2 * GC + 16) * sizeof(float);
+    const size_t lds = ((size_t)8 * QS + 512 + (size_t)RW * p.pstride + (size_t)upr * GC + 16) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS for this many utterances per ring"; return WNV_ERR_UNSUPPORTED; }
     RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = n_rings * (st->S + 1);
-    int ncu = 0;
-    RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, st->device));
     if (grid > ncu) { err = "ring kernel needs one CU per workgroup"; return WNV_ERR_UNSUPPORTED; }
     // optional timeline (WNV_RING_TRACE=<file>): wall-clock stamps of utterance 0 for 8 steps in mid-run
     const char* trace_path = getenv("WNV_RING_TRACE");
