@@ -33,7 +33,7 @@
 #include "wnv_ring.h"
 
 #ifndef WNV_RING_IS_DEFAULT
-#define WNV_RING_IS_DEFAULT 0   // flipped to 1 once the GPU parity suite of the ring kernel is green
+#define WNV_RING_IS_DEFAULT 1   // the GPU parity suite of the ring kernel is green (tests/test_gpu_ring.py)
 #endif
 
 #include <algorithm>
@@ -53,13 +53,17 @@ constexpr int RW = 8;              // waves per workgroup
 constexpr int RC = 128;            // residual channels this kernel is specialised for
 constexpr int GC = 256;            // gate channels
 constexpr int QS = 36;             // LDS stride of one 32-float quarter (+4 pad: the 4 quarters hit disjoint banks)
-constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 struct RingParams {
-    int n_rings, S, L, B, T, Tt, upr;
+    int n_rings, rstride, S, L, B, T, Tt, upr;
     int K, Kp, O, cin, kw, kpre, nz, dist;
     int pstride;                       // LDS partial stride (floats) = max(256, Kp)
     int hist_floats;
+    int allow_fast;                    // same-XCD hand-off through the XCD's L2 (plain stores) when placement allows
+    unsigned tag_base;                 // tags of this launch are tag_base + t + 1: unique across launches, no re-zeroing
     float skip_scale;
     const float *w2img, *woimg, *wsimg, *bo, *wpre, *bskip;
     const float *wh1img, *bh1, *wh2img, *bh2, *wfirst, *bfirst;
@@ -67,6 +71,7 @@ struct RingParams {
     long long zbias_bstride;
     const int *lay_dil, *lay_histoff;
     unsigned long long *hmail, *smail;
+    unsigned int* xcc;                 // [grid] XCC id + 1 of every workgroup (placement handshake)
     float* hist;
     const float *c_up, *initial, *teacher, *noise;
     unsigned long long seed;
@@ -79,13 +84,19 @@ struct RingParams {
 using u64 = unsigned long long;
 
 __device__ __forceinline__ u64 ld_granule(const u64* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_load_dwordx2 ... sc1 (L1 bypass)
 }
-__device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v) {
-    __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// One 8-byte {tag, value} granule.  slow: write-through (sc1) store, visible to every XCD.  fast: plain store that
+// stays in THIS XCD's L2 -- legal only when the consumer workgroup was verified to sit on the same XCD (its sc1
+// loads are served by that L2); ~0.2 us less per hop (scripts/ubench_hop.hip).
+__device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v, bool fast) {
+    const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
+    if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(x) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
 }
 
 // One wave waits until the granule of every ACTIVE lane carries `tag`; returns false on abort/timeout.
+template <bool SLEEP>
 __device__ __forceinline__ bool wave_recv(const u64* g, bool active, unsigned tag, float& v, unsigned int* status,
                                           unsigned code, int lane) {
     unsigned spins = 0;
@@ -98,15 +109,33 @@ __device__ __forceinline__ bool wave_recv(const u64* g, bool active, unsigned ta
         }
         if (__all(ok)) return true;
         ++spins;
-        if ((spins & 127u) == 0u) {
+        if ((spins & 255u) == 0u) {
             if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             if (spins > SPIN_LIMIT) {
                 if (lane == 0) atomicCAS(status, 0u, code);
                 return false;
             }
         }
-        __builtin_amdgcn_s_sleep(1);
+        if (SLEEP) __builtin_amdgcn_s_sleep(1);
     }
+}
+
+// Placement handshake: publish this workgroup's XCC id, read the successor's; true when both share an XCD (and L2).
+__device__ __forceinline__ bool same_xcd_as(const RingParams& p, int succ_block, int* flag) {
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x = (x & 0xfu) + 1u;
+        __hip_atomic_store(p.xcc + blockIdx.x, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned y = 0, spins = 0;
+        while ((y = __hip_atomic_load(p.xcc + succ_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+            if (++spins > SPIN_LIMIT) break;                       // unknown placement: take the placement-independent path
+            __builtin_amdgcn_s_sleep(2);
+        }
+        *flag = (p.allow_fast && y == x) ? 1 : 0;
+    }
+    __syncthreads();
+    return *flag != 0;
 }
 
 // debug timeline: stamp slot k of (step t, position pos) with the device-wide 100 MHz wall clock
@@ -116,19 +145,17 @@ __device__ __forceinline__ void stamp(const RingParams& p, int b, int t, int pos
 }
 
 // sum over the four adjacent lanes of a quad (the four K-quarters of one output channel): two DPP quad_perm adds
-__device__ __forceinline__ float quad_allreduce(float v) {
-    const int a = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true);   // quad_perm:[1,0,3,2]
-    v += __int_as_float(a);
-    const int b = __builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true);   // quad_perm:[2,3,0,1]
-    return v + __int_as_float(b);
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+__device__ __forceinline__ float quad_allreduce(float v) { return dpp_add<0x4E>(dpp_add<0xB1>(v)); }   // [1,0,3,2] then [2,3,0,1]
 
 // tanh(a) * sigmoid(g) with the hardware exp2 / rcp (absolute error ~1e-7; the generic kernel keeps libm's
 // tanhf/expf and is the cross-check):  tanh(a) = sign(a) (1 - e)/(1 + e), e = exp(-2|a|);  sigmoid(g) = 1/(1 + exp(-g))
 __device__ __forceinline__ float fast_gate(float a, float g) {
-    const float e = __expf(-2.0f * fabsf(a));
-    const float f = __expf(-g);
-    const float r = __frcp_rn((1.0f + e) * (1.0f + f));
+    const float e = __builtin_amdgcn_exp2f(fabsf(a) * -2.8853900817779268f);
+    const float f = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
+    const float r = __builtin_amdgcn_rcpf((1.0f + e) * (1.0f + f));
     return copysignf((1.0f - e) * r, a);
 }
 
@@ -139,16 +166,24 @@ __device__ __forceinline__ void lds_read32(const float* p, float (&x)[32]) {
         x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
     }
 }
-__device__ __forceinline__ float dot32(const float (&w)[32], const float (&x)[32]) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+// 32-long dot product with the weights packed in pairs along K (v_pk_fma_f32, two accumulators)
+__device__ __forceinline__ float dot32p(const f2 (&w)[16], const float (&x)[32]) {
+    f2 a0 = f2{0.f, 0.f}, a1 = f2{0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 32; k += 4) {
-        a0 = fmaf(w[k], x[k], a0);
-        a1 = fmaf(w[k + 1], x[k + 1], a1);
-        a2 = fmaf(w[k + 2], x[k + 2], a2);
-        a3 = fmaf(w[k + 3], x[k + 3], a3);
+    for (int k = 0; k < 16; k += 2) {
+        a0 = __builtin_elementwise_fma(w[k], f2{x[2 * k], x[2 * k + 1]}, a0);
+        a1 = __builtin_elementwise_fma(w[k + 1], f2{x[2 * k + 2], x[2 * k + 3]}, a1);
     }
-    return (a0 + a1) + (a2 + a3);
+    a0 += a1;
+    return a0.x + a0.y;
+}
+__device__ __forceinline__ void load_image16(const float* img, int tid, f2 (&w)[16]) {
+    const float4* src = reinterpret_cast<const float4*>(img);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const float4 v = src[(size_t)c * RT + tid];
+        w[2 * c] = f2{v.x, v.y}; w[2 * c + 1] = f2{v.z, v.w};
+    }
 }
 __device__ __forceinline__ int qidx(int i) { return QS * (i >> 5) + (i & 31); }   // channel -> strided LDS slot
 
@@ -207,26 +242,24 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     const bool last_stage = sidx == p.S - 1;
     const int S1 = p.S + 1;
 
-    // ---- resident weights (registers): newest conv tap (tanh / sigmoid halves), conv1x1_out, conv1x1_skip ----
-    float w2a[32], w2b[32], wo[32], ws[32];
+    // ---- resident weights (registers): newest conv tap as (tanh row, sigmoid row) pairs, conv1x1_out and
+    //      conv1x1_skip as K pairs -- every chain FMA is a v_pk_fma_f32 ------------------------------------------
+    f2 wz[32], wo[16], ws[16];
     {
         const float4* src = reinterpret_cast<const float4*>(p.w2img) + (size_t)l * 16 * RT;
-        const float4* osrc = reinterpret_cast<const float4*>(p.woimg) + (size_t)l * 8 * RT;
-        const float4* ssrc = reinterpret_cast<const float4*>(p.wsimg) + (size_t)l * 8 * RT;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float4 va = src[(size_t)c * RT + tid], vb = src[(size_t)(8 + c) * RT + tid];
-            const float4 vo = osrc[(size_t)c * RT + tid], vs = ssrc[(size_t)c * RT + tid];
-            w2a[4 * c] = va.x; w2a[4 * c + 1] = va.y; w2a[4 * c + 2] = va.z; w2a[4 * c + 3] = va.w;
-            w2b[4 * c] = vb.x; w2b[4 * c + 1] = vb.y; w2b[4 * c + 2] = vb.z; w2b[4 * c + 3] = vb.w;
-            wo[4 * c] = vo.x; wo[4 * c + 1] = vo.y; wo[4 * c + 2] = vo.z; wo[4 * c + 3] = vo.w;
-            ws[4 * c] = vs.x; ws[4 * c + 1] = vs.y; ws[4 * c + 2] = vs.z; ws[4 * c + 3] = vs.w;
+        for (int c = 0; c < 16; ++c) {
+            const float4 v = src[(size_t)c * RT + tid];
+            wz[2 * c] = f2{v.x, v.y}; wz[2 * c + 1] = f2{v.z, v.w};
         }
+        load_image16(p.woimg + (size_t)l * 8 * RT * 4, tid, wo);
+        load_image16(p.wsimg + (size_t)l * 8 * RT * 4, tid, ws);
     }
     const float bo_r = p.bo[(size_t)l * RC + i];
     const float bs_r = p.bskip[(size_t)l * p.Kp + i];
     if (tid == 0) s.flags[0] = 0;
-    __syncthreads();
+    // successor: next stage, or the head behind the last stage (block = ring + pos * rstride)
+    const bool fast = same_xcd_as(p, ring + (sidx + 1) * p.rstride, s.flags + 1);
 
     // ---- prologue: pre-activations of step 0 (all taps are zero history) ------------------------------------
     for (int j = 0; j < p.upr; ++j) {
@@ -235,33 +268,32 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     }
 
     for (int t = 0; t < p.T; ++t) {
-        const unsigned tag = (unsigned)t + 1u;
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
         for (int j = 0; j < p.upr; ++j) {
             const int b = ring + j * p.n_rings;
             if (b >= p.B) continue;
+            // accumulator init = next-step pre-activation (registers, loaded before the wait)
+            f2 z = f2{0.f, 0.f};
+            if (q == 0) z = f2{s.pre[(size_t)j * GC + i], s.pre[(size_t)j * GC + RC + i]};
             // ---- receive the activation vector of (b, t) ------------------------------------------------
             if (wave < 2) {
                 float v = 0.f;
-                const bool ok = wave_recv(p.hmail + ((size_t)b * S1 + sidx) * RC + tid, true, tag, v, p.status,
-                                          0x100u + (unsigned)sidx, lane);
-                if (!ok) s.flags[0] = 1;
+                if (!wave_recv<false>(p.hmail + ((size_t)b * S1 + sidx) * RC + tid, true, tag, v, p.status,
+                                      0x100u + (unsigned)sidx, lane)) s.flags[0] = 1;
                 s.hs[qidx(tid)] = v;
             }
             __syncthreads();
-            if (s.flags[0]) return;
             stamp(p, b, t, sidx, 0);
             // ---- the chain: newest tap + pre -> gate -> conv1x1_out -> residual -> send -------------------------
             float xu[32];
+            float hres;
             {
                 float x[32];
                 lds_read32(s.hs + QS * q, x);
-                float a = dot32(w2a, x), g = dot32(w2b, x);
-                if (q == 0) {
-                    a += s.pre[(size_t)j * GC + i];
-                    g += s.pre[(size_t)j * GC + RC + i];
-                }
-                a = quad_allreduce(a);
-                g = quad_allreduce(g);
+                hres = s.hs[qidx(i)];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) z = __builtin_elementwise_fma(wz[k], f2{x[k], x[k]}, z);
+                const float a = quad_allreduce(z.x), g = quad_allreduce(z.y);
                 const float u = fast_gate(a, g);                                // modules.py:154
                 if (q == 0) s.us[qidx(i)] = u;
             }
@@ -269,27 +301,27 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             stamp(p, b, t, sidx, 1);
             lds_read32(s.us + QS * q, xu);
             if (!last_stage) {                      // the last layer's residual output is never used (wavenet.py:310-313)
-                const float o = quad_allreduce(dot32(wo, xu));
-                const float hn = (o + bo_r + s.hs[qidx(i)]) * 0.70710678118654752440f;   // modules.py:162
-                if (q == 0) st_granule(p.hmail + ((size_t)b * S1 + sidx + 1) * RC + i, tag, hn);    // send on
+                const float o = quad_allreduce(dot32p(wo, xu));
+                const float hn = (o + bo_r + hres) * 0.70710678118654752440f;   // modules.py:162
+                if (q == 0) st_granule(p.hmail + ((size_t)b * S1 + sidx + 1) * RC + i, tag, hn, fast);    // send on
             }
             stamp(p, b, t, sidx, 2);
             // ---- deferred 1: skip 1x1 from the same registers, accumulated in the reference's layer order -----------
             {
+                const float mine = quad_allreduce(dot32p(ws, xu)) + bs_r;       // wavenet.py:312
                 float acc = 0.f;
                 bool ok = true;
                 if (sidx > 0)
-                    ok = wave_recv(p.smail + ((size_t)b * S1 + sidx) * p.Kp + i, q == 0, tag, acc, p.status,
-                                   0x200u + (unsigned)sidx, lane);
-                acc += quad_allreduce(dot32(ws, xu)) + bs_r;                     // wavenet.py:312
-                if (q == 0 && ok) st_granule(p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + i, tag, acc);
+                    ok = wave_recv<false>(p.smail + ((size_t)b * S1 + sidx) * p.Kp + i, q == 0, tag, acc, p.status,
+                                          0x200u + (unsigned)sidx, lane);
+                if (q == 0 && ok) st_granule(p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + i, tag, acc + mine, fast);
                 if (!ok) s.flags[0] = 1;
             }
             stamp(p, b, t, sidx, 3);
             // ---- deferred 2: history push + next step's pre-activations (its barriers fence hs/us for the next receive)
             if (t + 1 < p.T) deferred_pre(p, s, b, j, l, t, t + 1, tid, wave, lane);
             else __syncthreads();
-            if (s.flags[0]) return;
+            if (s.flags[0]) return;                 // a bounded wait gave up somewhere: drain (status holds the code)
             stamp(p, b, t, sidx, 4);
         }
     }
@@ -299,91 +331,116 @@ struct HeadLds {
     float* vs;     // strided relu(skip * scale)
     float* hid;    // strided hidden
     float* obuf;   // [128] head output
-    float* nz;     // [64] noise of this step
-    float* prevx;  // [upr]
+    float* vbuf;   // [48]  mixture logit + Gumbel noise, padded with -inf
     int* flags;
 };
 
+// noise value `idx` of (t, b): from the tape (rng = "replay") or the in-kernel Philox stream
+__device__ __forceinline__ float head_noise(const RingParams& p, int t, int b, int idx, int kind) {
+    return p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + idx] : wnv_noise_gen(p.seed, t, b, idx, kind);
+}
+
 __device__ void run_head(const RingParams& p, int ring, float* smem) {
     HeadLds s;
-    s.vs = smem; s.hid = smem + 4 * QS; s.obuf = smem + 8 * QS; s.nz = s.obuf + 128; s.prevx = s.nz + 64;
-    s.flags = reinterpret_cast<int*>(s.prevx + 64);
+    s.vs = smem; s.hid = smem + 4 * QS; s.obuf = smem + 8 * QS; s.vbuf = s.obuf + 128;
+    s.flags = reinterpret_cast<int*>(s.vbuf + 48);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, i = wave * 16 + (lane >> 2);
     const int S1 = p.S + 1;
-    float wh1[32], wh2[32];
-    {
-        const float4* a = reinterpret_cast<const float4*>(p.wh1img);
-        const float4* c2 = reinterpret_cast<const float4*>(p.wh2img);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const float4 va = a[(size_t)c * RT + tid], vb = c2[(size_t)c * RT + tid];
-            wh1[4 * c] = va.x; wh1[4 * c + 1] = va.y; wh1[4 * c + 2] = va.z; wh1[4 * c + 3] = va.w;
-            wh2[4 * c] = vb.x; wh2[4 * c + 1] = vb.y; wh2[4 * c + 2] = vb.z; wh2[4 * c + 3] = vb.w;
-        }
-    }
+    f2 wh1[16], wh2[16];
+    load_image16(p.wh1img, tid, wh1);
+    load_image16(p.wh2img, tid, wh2);
     const float bh1 = p.bh1[i], bh2 = p.bh2[i];
     float wf = 0.f, bf = 0.f;
     if (tid < RC) { wf = p.wfirst[tid]; bf = p.bfirst[tid]; }
+    // output distribution (mixture.py:118-156 / :221-270): which head outputs are mean / log-scale
+    const bool single = p.dist == 2 && p.O <= 3;
+    const int nmix = single ? 0 : p.O / 3;
+    const int o_mean = single ? (p.O == 2 ? 0 : 1) : nmix, o_ls = single ? (p.O == 2 ? 1 : 2) : 2 * nmix;
+    const int nchunk = (nmix + 3) >> 2;
+    if (tid < 48) s.vbuf[tid] = -INFINITY;
     if (tid == 0) s.flags[0] = 0;
-    if (tid < 64) s.prevx[tid] = 0.f;
-    __syncthreads();
+    const bool fast = same_xcd_as(p, ring, s.flags + 1);          // successor of the head = stage 0
+
+    // ---- prologue: the input of step 0 (wavenet.py:283-289, :297-308) ----------------------------------------
+    for (int j = 0; j < p.upr; ++j) {
+        const int b = ring + j * p.n_rings;
+        if (b >= p.B || tid >= RC) continue;
+        const float xs = p.Tt > 0 ? p.teacher[(size_t)b * p.Tt] : (p.initial ? p.initial[b] : 0.f);
+        st_granule(p.hmail + ((size_t)b * S1) * RC + tid, p.tag_base + 1u, fmaf(wf, xs, bf), fast);
+        stamp(p, b, 0, p.S, 0);
+    }
 
     for (int t = 0; t < p.T; ++t) {
-        const unsigned tag = (unsigned)t + 1u;
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
         for (int j = 0; j < p.upr; ++j) {
             const int b = ring + j * p.n_rings;
             if (b >= p.B) continue;
-            // ---- first_conv on this step's input (wavenet.py:297-308) ----------------------------------------
-            float xs;
-            if (t < p.Tt) xs = p.teacher[(size_t)b * p.Tt + t];
-            else if (t == 0) xs = p.initial ? p.initial[b] : 0.f;
-            else xs = s.prevx[j];
-            if (tid < RC) st_granule(p.hmail + ((size_t)b * S1) * RC + tid, tag, fmaf(wf, xs, bf));
-            stamp(p, b, t, p.S, 0);
-            // noise of this step (independent of the network)
-            if (tid < p.nz) {
-                int kind = 0;
-                if (p.dist == 2 && tid == p.nz - 1) kind = 1;
-                s.nz[tid] = p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, b, tid, kind);
+            // ---- everything that does not depend on the network, while the ring works ---------------------------
+            float gum = 0.f, lr = 0.f, forced = 0.f;
+            if (i < nmix) gum = -logf(-logf(head_noise(p, t, b, i, 0)));          // Gumbel noise (mixture.py:138-140)
+            if (wave < 2) {
+                const float r = head_noise(p, t, b, nmix, p.dist == 2 ? 1 : 0);
+                lr = p.dist == 1 ? logf(r) - logf(1.0f - r) : r;                     // mixture.py:151-152 / :265-267
+                if (t + 1 < p.Tt) forced = p.teacher[(size_t)b * p.Tt + t + 1];
             }
             // ---- wait for the accumulated skip vector of (b, t) -----------------------------------------------
             if (wave < 2) {
                 float v = 0.f;
-                const bool ok = wave_recv(p.smail + ((size_t)b * S1 + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane);
-                if (!ok) s.flags[0] = 1;
+                if (!wave_recv<false>(p.smail + ((size_t)b * S1 + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane))
+                    s.flags[0] = 1;
                 s.vs[qidx(tid)] = fmaxf(v * p.skip_scale, 0.f);                  // wavenet.py:313-316
             }
             __syncthreads();
-            if (s.flags[0]) return;
             stamp(p, b, t, p.S, 1);
             float x[32];
             lds_read32(s.vs + QS * q, x);
-            const float h1 = fmaxf(quad_allreduce(dot32(wh1, x)) + bh1, 0.f);   // wavenet.py:317-318
+            const float h1 = fmaxf(quad_allreduce(dot32p(wh1, x)) + bh1, 0.f);  // wavenet.py:317-318
             if (q == 0) s.hid[qidx(i)] = h1;
             __syncthreads();
             lds_read32(s.hid + QS * q, x);
-            const float o = quad_allreduce(dot32(wh2, x)) + bh2;                  // wavenet.py:319
+            const float o = quad_allreduce(dot32p(wh2, x)) + bh2;                 // wavenet.py:319
             if (q == 0 && i < p.O) {
                 s.obuf[i] = o;
+                if (i < nmix) s.vbuf[i] = o + gum;
                 if (p.params_out) p.params_out[((size_t)b * p.O + i) * p.T + t] = o;
             }
             __syncthreads();
-            if (wave == 0) {
-                const float xo = sample_scalar(p.dist, p.O, s.obuf, s.nz, lane);   // wavenet.py:322-330
-                if (lane == 0) { p.out[(size_t)b * p.T + t] = xo; s.prevx[j] = xo; }
+            // ---- sample, redundantly in every lane of waves 0-1 (no cross-lane traffic), then first_conv of step t+1 ----
+            if (wave < 2) {
+                int bi = 0;
+                if (nmix > 0) {                                                     // Gumbel-max, first index wins ties
+                    float best = -INFINITY;
+                    for (int c = 0; c < nchunk; ++c) {
+                        const float4 v = reinterpret_cast<const float4*>(s.vbuf)[c];
+                        if (v.x > best) { best = v.x; bi = 4 * c; }
+                        if (v.y > best) { best = v.y; bi = 4 * c + 1; }
+                        if (v.z > best) { best = v.z; bi = 4 * c + 2; }
+                        if (v.w > best) { best = v.w; bi = 4 * c + 3; }
+                    }
+                }
+                const float mean = s.obuf[o_mean + bi], ls = s.obuf[o_ls + bi];   // mixture.py:143-146 / :258-261
+                float xo = p.dist == 1 ? mean + expf(ls) * lr : lr * expf(ls) + mean;
+                xo = fminf(fmaxf(xo, -1.0f), 1.0f);                               // mixture.py:154 / :269
+                if (t + 1 < p.T) {
+                    const float xs = t + 1 < p.Tt ? forced : xo;                   // wavenet.py:297-305
+                    st_granule(p.hmail + ((size_t)b * S1) * RC + tid, tag + 1u, fmaf(wf, xs, bf), fast);
+                    stamp(p, b, t + 1, p.S, 0);
+                }
+                if (tid == 0) p.out[(size_t)b * p.T + t] = xo;
             }
-            __syncthreads();
             stamp(p, b, t, p.S, 2);
+            if (s.flags[0]) return;                 // uniform: written before the barriers above
         }
     }
 }
 
 __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    // block i -> XCD i % 8 (observed, speed only): ring r lives on one XCD when n_rings == 8
-    const int ring = blockIdx.x % p.n_rings;
-    const int pos = blockIdx.x / p.n_rings;
+    // block i -> XCD i % 8 (observed, speed only): with rstride == 8 every workgroup of ring r sits on XCD r
+    const int ring = blockIdx.x % p.rstride;
+    const int pos = blockIdx.x / p.rstride;
+    if (ring >= p.n_rings) return;
     if (pos < p.S) run_stage(p, ring, pos, smem);
     else run_head(p, ring, smem);
 }
@@ -402,8 +459,10 @@ struct WnvRingState {
     int* d_dil = nullptr;
     int* d_histoff = nullptr;
     int hist_floats = 0;
-    void* d_state = nullptr;       // mailboxes + history + status
+    void* d_state = nullptr;       // status + placement table + mailboxes + history
     size_t state_cap = 0;
+    unsigned tag_next = 0;         // tags handed out so far (mailboxes are only re-zeroed when this would wrap)
+    size_t mail_bytes = 0;         // size of the mailbox region the tags in flight refer to
 };
 
 static const char* why_not(const wnv_config& c, int B) {
@@ -456,6 +515,21 @@ static void put_image(std::vector<float>& blob, size_t off, const float* M, int 
     }
 }
 
+// image of the newest-tap matrix (256 x 128) as (tanh row i, sigmoid row 128 + i) pairs:
+// chunk c (0..15) of thread tid = { M[i][32q + 2c], M[128 + i][32q + 2c], M[i][32q + 2c + 1], M[128 + i][32q + 2c + 1] }
+static void put_image_z(std::vector<float>& blob, size_t off, const float* M) {
+    for (int tid = 0; tid < RT; ++tid) {
+        int i, q;
+        tid_map(tid, i, q);
+        for (int c = 0; c < 16; ++c)
+            for (int e = 0; e < 2; ++e) {
+                const int k = 32 * q + 2 * c + e;
+                blob[off + ((size_t)c * RT + tid) * 4 + 2 * e] = M[(size_t)i * RC + k];
+                blob[off + ((size_t)c * RT + tid) * 4 + 2 * e + 1] = M[(size_t)(RC + i) * RC + k];
+            }
+    }
+}
+
 static wnv_status build_state(WnvRingState** out, int device, const wnv_config& c, const TensorStore& store,
                               std::string& err) {
     WnvRingState* st = new WnvRingState();
@@ -483,8 +557,7 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
         // newest tap (k = kw-1) as a (256 x 128) matrix
         for (int o = 0; o < GC; ++o)
             for (int ii = 0; ii < RC; ++ii) cur[(size_t)o * RC + ii] = wc.data[((size_t)o * RC + ii) * kw + (kw - 1)];
-        put_image(blob, st->o_w2 + (size_t)l * 16 * RT * 4, cur.data(), 0, GC);                       // tanh half
-        put_image(blob, st->o_w2 + (size_t)l * 16 * RT * 4 + (size_t)8 * RT * 4, cur.data(), RC, GC); // sigmoid half
+        put_image_z(blob, st->o_w2 + (size_t)l * 16 * RT * 4, cur.data());
         const HostTensor& wo = T(pfx + "conv1x1_out.weight");          // (R, G/2, 1)
         put_image(blob, st->o_wo + (size_t)l * 8 * RT * 4, wo.data.data(), 0, RC);
         const HostTensor& bo = T(pfx + "conv1x1_out.bias");
@@ -544,31 +617,53 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     // one workgroup per CU, one ring per utterance slot; at most 8 rings (one per XCD) and never more than fit
     const int n_rings = std::max(1, std::min(std::min(B, 8), ncu / (st->S + 1)));
     const int upr = (B + n_rings - 1) / n_rings;
+    // block b lands on XCD b % 8 (observed): a ring stride of 8 keeps every workgroup of a ring on one XCD, which the
+    // kernel verifies at run time before it uses the same-XCD hand-off; surplus workgroups exit at once
+    const int rstride = 8 * (st->S + 1) <= ncu ? 8 : n_rings;
     RingParams p{};
-    p.n_rings = n_rings; p.S = st->S; p.L = st->L; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.upr = upr;
+    p.n_rings = n_rings; p.rstride = rstride; p.S = st->S; p.L = st->L; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.upr = upr;
     p.K = st->K; p.Kp = st->Kp; p.O = st->O; p.cin = st->cin; p.kw = st->kw; p.kpre = st->kpre; p.nz = ga.nz;
     p.dist = c.output_distribution;
     p.pstride = std::max(GC, st->Kp);
     p.hist_floats = st->hist_floats;
     p.skip_scale = (float)std::sqrt(1.0 / st->L);
+    { const char* e = getenv("WNV_RING_FAST"); p.allow_fast = !(e && e[0] == '0'); }
     const float* w = st->d_w;
     p.w2img = w + st->o_w2; p.woimg = w + st->o_wo; p.bo = w + st->o_bo; p.wpre = w + st->o_wpre;
     p.wsimg = w + st->o_ws; p.bskip = w + st->o_bskip; p.wh1img = w + st->o_wh1; p.bh1 = w + st->o_bh1;
     p.wh2img = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf;
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
-    // state: [status 64 B][hmail B*(S+1)*128 u64][smail B*(S+1)*Kp u64][hist B*hist_floats f32]
+    // state: [status 64 B][placement table 4 KiB][hmail B*(S+1)*128 u64][smail B*(S+1)*Kp u64][hist B*hist_floats f32]
+    const size_t head_bytes = 64 + 4096;
     const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
-    const size_t bytes = 64 + (n_h + n_s) * sizeof(u64) + (size_t)B * st->hist_floats * sizeof(float);
+    const size_t mail_bytes = (n_h + n_s) * sizeof(u64);
+    const size_t hist_bytes = (size_t)B * st->hist_floats * sizeof(float);
+    const size_t bytes = head_bytes + mail_bytes + hist_bytes;
+    bool fresh = false;
     if (bytes > st->state_cap) {
         if (st->d_state) { RING_HIP(hipFree(st->d_state)); st->d_state = nullptr; st->state_cap = 0; }
         RING_HIP(hipMalloc(&st->d_state, bytes));
         st->state_cap = bytes;
+        fresh = true;
     }
-    RING_HIP(hipMemsetAsync(st->d_state, 0, bytes, stream));     // tags 0 = "nothing sent", history = zeros
     char* base = (char*)st->d_state;
+    // Mailbox tags are unique across launches (tag_base + t + 1), so the mailboxes are zeroed only when the buffer is
+    // new, when its layout changes, or before the 32-bit tag would wrap; the history rings are zeroed every call
+    // (= clear_buffer, wavenet.py:241) together with the status word and the placement table.
+    if (fresh || mail_bytes != st->mail_bytes || (unsigned long long)st->tag_next + (unsigned long long)ga.T + 2ull > 0xFFFFFFF0ull) {
+        RING_HIP(hipMemsetAsync(base, 0, head_bytes + mail_bytes, stream));
+        st->tag_next = 0;
+        st->mail_bytes = mail_bytes;
+    } else {
+        RING_HIP(hipMemsetAsync(base, 0, head_bytes, stream));
+    }
+    RING_HIP(hipMemsetAsync(base + head_bytes + mail_bytes, 0, hist_bytes, stream));
+    p.tag_base = st->tag_next;
+    st->tag_next += (unsigned)ga.T + 1u;
     p.status = (unsigned int*)base;
-    p.hmail = (u64*)(base + 64);
+    p.xcc = (unsigned int*)(base + 64);
+    p.hmail = (u64*)(base + head_bytes);
     p.smail = p.hmail + n_h;
     p.hist = (float*)(p.smail + n_s);
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
@@ -577,8 +672,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t lds = ((size_t)8 * QS + 512 + (size_t)RW * p.pstride + (size_t)upr * GC + 16) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS for this many utterances per ring"; return WNV_ERR_UNSUPPORTED; }
     RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = n_rings * (st->S + 1);
-    if (grid > ncu) { err = "ring kernel needs one CU per workgroup"; return WNV_ERR_UNSUPPORTED; }
+    const int grid = rstride * (st->S + 1);
+    if (grid > ncu || grid > 1024) { err = "ring kernel needs one CU per workgroup"; return WNV_ERR_UNSUPPORTED; }
     // optional timeline (WNV_RING_TRACE=<file>): wall-clock stamps of utterance 0 for 8 steps in mid-run
     const char* trace_path = getenv("WNV_RING_TRACE");
     unsigned long long* d_trace = nullptr;
