@@ -242,19 +242,13 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     const bool last_stage = sidx == p.S - 1;
     const int S1 = p.S + 1;
 
-    // ---- resident weights (registers): newest conv tap as (tanh row, sigmoid row) pairs, conv1x1_out and
-    //      conv1x1_skip as K pairs -- every chain FMA is a v_pk_fma_f32 ------------------------------------------
-    f2 wz[32], wo[16], ws[16];
-    {
-        const float4* src = reinterpret_cast<const float4*>(p.w2img) + (size_t)l * 16 * RT;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const float4 v = src[(size_t)c * RT + tid];
-            wz[2 * c] = f2{v.x, v.y}; wz[2 * c + 1] = f2{v.z, v.w};
-        }
-        load_image16(p.woimg + (size_t)l * 8 * RT * 4, tid, wo);
-        load_image16(p.wsimg + (size_t)l * 8 * RT * 4, tid, ws);
-    }
+    // ---- resident weights (registers): newest conv tap (tanh row, sigmoid row), conv1x1_out and conv1x1_skip, all
+    //      as pairs along K -- every chain FMA is a v_pk_fma_f32 ---------------------------------------------------
+    f2 wa[16], wg[16], wo[16], ws[16];
+    load_image16(p.w2img + (size_t)l * 16 * RT * 4, tid, wa);
+    load_image16(p.w2img + (size_t)l * 16 * RT * 4 + (size_t)8 * RT * 4, tid, wg);
+    load_image16(p.woimg + (size_t)l * 8 * RT * 4, tid, wo);
+    load_image16(p.wsimg + (size_t)l * 8 * RT * 4, tid, ws);
     const float bo_r = p.bo[(size_t)l * RC + i];
     const float bs_r = p.bskip[(size_t)l * p.Kp + i];
     if (tid == 0) s.flags[0] = 0;
@@ -272,14 +266,19 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
         for (int j = 0; j < p.upr; ++j) {
             const int b = ring + j * p.n_rings;
             if (b >= p.B) continue;
-            // accumulator init = next-step pre-activation (registers, loaded before the wait)
-            f2 z = f2{0.f, 0.f};
-            if (q == 0) z = f2{s.pre[(size_t)j * GC + i], s.pre[(size_t)j * GC + RC + i]};
+            // everything the chain needs that is known before the activation arrives: mailbox addresses and the
+            // accumulator init (= next-step pre-activation), pinned in registers ahead of the wait
+            const u64* hm_in = p.hmail + ((size_t)b * S1 + sidx) * RC + tid;
+            u64* hm_out = p.hmail + ((size_t)b * S1 + sidx + 1) * RC + i;
+            const u64* sm_in = p.smail + ((size_t)b * S1 + sidx) * p.Kp + i;
+            u64* sm_out = p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + i;
+            float za = 0.f, zg = 0.f;
+            if (q == 0) { za = s.pre[(size_t)j * GC + i]; zg = s.pre[(size_t)j * GC + RC + i]; }
+            asm volatile("" : "+v"(hm_in), "+v"(hm_out), "+v"(sm_in), "+v"(sm_out), "+v"(za), "+v"(zg));
             // ---- receive the activation vector of (b, t) ------------------------------------------------
             if (wave < 2) {
                 float v = 0.f;
-                if (!wave_recv<false>(p.hmail + ((size_t)b * S1 + sidx) * RC + tid, true, tag, v, p.status,
-                                      0x100u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                if (!wave_recv<false>(hm_in, true, tag, v, p.status, 0x100u + (unsigned)sidx, lane)) s.flags[0] = 1;
                 s.hs[qidx(tid)] = v;
             }
             __syncthreads();
@@ -291,9 +290,16 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 float x[32];
                 lds_read32(s.hs + QS * q, x);
                 hres = s.hs[qidx(i)];
+                f2 a0 = f2{za, 0.f}, a1 = f2{0.f, 0.f}, g0 = f2{zg, 0.f}, g1 = f2{0.f, 0.f};
 #pragma unroll
-                for (int k = 0; k < 32; ++k) z = __builtin_elementwise_fma(wz[k], f2{x[k], x[k]}, z);
-                const float a = quad_allreduce(z.x), g = quad_allreduce(z.y);
+                for (int k = 0; k < 16; k += 2) {
+                    a0 = __builtin_elementwise_fma(wa[k], f2{x[2 * k], x[2 * k + 1]}, a0);
+                    g0 = __builtin_elementwise_fma(wg[k], f2{x[2 * k], x[2 * k + 1]}, g0);
+                    a1 = __builtin_elementwise_fma(wa[k + 1], f2{x[2 * k + 2], x[2 * k + 3]}, a1);
+                    g1 = __builtin_elementwise_fma(wg[k + 1], f2{x[2 * k + 2], x[2 * k + 3]}, g1);
+                }
+                a0 += a1; g0 += g1;
+                const float a = quad_allreduce(a0.x + a0.y), g = quad_allreduce(g0.x + g0.y);
                 const float u = fast_gate(a, g);                                // modules.py:154
                 if (q == 0) s.us[qidx(i)] = u;
             }
@@ -303,7 +309,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             if (!last_stage) {                      // the last layer's residual output is never used (wavenet.py:310-313)
                 const float o = quad_allreduce(dot32p(wo, xu));
                 const float hn = (o + bo_r + hres) * 0.70710678118654752440f;   // modules.py:162
-                if (q == 0) st_granule(p.hmail + ((size_t)b * S1 + sidx + 1) * RC + i, tag, hn, fast);    // send on
+                if (q == 0) st_granule(hm_out, tag, hn, fast);                  // send on
             }
             stamp(p, b, t, sidx, 2);
             // ---- deferred 1: skip 1x1 from the same registers, accumulated in the reference's layer order -----------
@@ -311,10 +317,8 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 const float mine = quad_allreduce(dot32p(ws, xu)) + bs_r;       // wavenet.py:312
                 float acc = 0.f;
                 bool ok = true;
-                if (sidx > 0)
-                    ok = wave_recv<false>(p.smail + ((size_t)b * S1 + sidx) * p.Kp + i, q == 0, tag, acc, p.status,
-                                          0x200u + (unsigned)sidx, lane);
-                if (q == 0 && ok) st_granule(p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + i, tag, acc + mine, fast);
+                if (sidx > 0) ok = wave_recv<false>(sm_in, q == 0, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
+                if (q == 0 && ok) st_granule(sm_out, tag, acc + mine, fast);
                 if (!ok) s.flags[0] = 1;
             }
             stamp(p, b, t, sidx, 3);
@@ -515,21 +519,6 @@ static void put_image(std::vector<float>& blob, size_t off, const float* M, int 
     }
 }
 
-// image of the newest-tap matrix (256 x 128) as (tanh row i, sigmoid row 128 + i) pairs:
-// chunk c (0..15) of thread tid = { M[i][32q + 2c], M[128 + i][32q + 2c], M[i][32q + 2c + 1], M[128 + i][32q + 2c + 1] }
-static void put_image_z(std::vector<float>& blob, size_t off, const float* M) {
-    for (int tid = 0; tid < RT; ++tid) {
-        int i, q;
-        tid_map(tid, i, q);
-        for (int c = 0; c < 16; ++c)
-            for (int e = 0; e < 2; ++e) {
-                const int k = 32 * q + 2 * c + e;
-                blob[off + ((size_t)c * RT + tid) * 4 + 2 * e] = M[(size_t)i * RC + k];
-                blob[off + ((size_t)c * RT + tid) * 4 + 2 * e + 1] = M[(size_t)(RC + i) * RC + k];
-            }
-    }
-}
-
 static wnv_status build_state(WnvRingState** out, int device, const wnv_config& c, const TensorStore& store,
                               std::string& err) {
     WnvRingState* st = new WnvRingState();
@@ -557,7 +546,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
         // newest tap (k = kw-1) as a (256 x 128) matrix
         for (int o = 0; o < GC; ++o)
             for (int ii = 0; ii < RC; ++ii) cur[(size_t)o * RC + ii] = wc.data[((size_t)o * RC + ii) * kw + (kw - 1)];
-        put_image_z(blob, st->o_w2 + (size_t)l * 16 * RT * 4, cur.data());
+        put_image(blob, st->o_w2 + (size_t)l * 16 * RT * 4, cur.data(), 0, GC);                       // tanh half
+        put_image(blob, st->o_w2 + (size_t)l * 16 * RT * 4 + (size_t)8 * RT * 4, cur.data(), RC, GC); // sigmoid half
         const HostTensor& wo = T(pfx + "conv1x1_out.weight");          // (R, G/2, 1)
         put_image(blob, st->o_wo + (size_t)l * 8 * RT * 4, wo.data.data(), 0, RC);
         const HostTensor& bo = T(pfx + "conv1x1_out.bias");
