@@ -139,8 +139,8 @@ __device__ __forceinline__ bool same_xcd_as(const RingParams& p, int succ_block,
 }
 
 // debug timeline: stamp slot k of (step t, position pos) with the device-wide 100 MHz wall clock
-__device__ __forceinline__ void stamp(const RingParams& p, int b, int t, int pos, int k) {
-    if (p.trace && b == 0 && threadIdx.x == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
+__device__ __forceinline__ void stamp(const RingParams& p, int b, int t, int pos, int k, int who = 0) {
+    if (p.trace && b == 0 && threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
         p.trace[((size_t)(t - p.trace_t0) * (p.S + 1) + pos) * 8 + k] = wall_clock64();
 }
 
@@ -177,6 +177,35 @@ __device__ __forceinline__ float dot32p(const f2 (&w)[16], const float (&x)[32])
     a0 += a1;
     return a0.x + a0.y;
 }
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ void lds_read16(const float* p, float (&x)[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 v = reinterpret_cast<const float4*>(p)[c];
+        x[4 * c] = v.x; x[4 * c + 1] = v.y; x[4 * c + 2] = v.z; x[4 * c + 3] = v.w;
+    }
+}
+__device__ __forceinline__ float dot16p(const f2 (&w)[8], const float (&x)[16]) {
+    f2 a0 = f2{0.f, 0.f}, a1 = f2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; k += 2) {
+        a0 = __builtin_elementwise_fma(w[k], f2{x[2 * k], x[2 * k + 1]}, a0);
+        a1 = __builtin_elementwise_fma(w[k + 1], f2{x[2 * k + 2], x[2 * k + 3]}, a1);
+    }
+    a0 += a1;
+    return a0.x + a0.y;
+}
+// one matrix row's 16-float K-slice: 4 chunks of 16 B, image layout [chunk][512 threads][4]
+__device__ __forceinline__ void load_image8(const float* img, int tid, f2 (&w)[8]) {
+    const float4* src = reinterpret_cast<const float4*>(img);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 v = src[(size_t)c * RT + tid];
+        w[2 * c] = f2{v.x, v.y}; w[2 * c + 1] = f2{v.z, v.w};
+    }
+}
 __device__ __forceinline__ void load_image16(const float* img, int tid, f2 (&w)[16]) {
     const float4* src = reinterpret_cast<const float4*>(img);
 #pragma unroll
@@ -185,7 +214,10 @@ __device__ __forceinline__ void load_image16(const float* img, int tid, f2 (&w)[
         w[2 * c] = f2{v.x, v.y}; w[2 * c + 1] = f2{v.z, v.w};
     }
 }
-__device__ __forceinline__ int qidx(int i) { return QS * (i >> 5) + (i & 31); }   // channel -> strided LDS slot
+__device__ __forceinline__ int qidx(int i) { return QS * (i >> 5) + (i & 31); }   // channel -> strided LDS slot (head: 4 K-quarters)
+// stage kernel: eight K-slices of 16 floats, stride 20 -- the eight slices of one ds_read_b128 hit disjoint banks
+constexpr int ES = 20;
+__device__ __forceinline__ int eidx(int i) { return ES * (i >> 4) + (i & 15); }
 
 struct StageLds {
     float* hs;       // strided layer input h_l[t]
@@ -199,8 +231,8 @@ struct StageLds {
 __device__ __forceinline__ StageLds carve_stage(float* smem, const RingParams& p) {
     StageLds s;
     s.hs = smem;
-    s.us = smem + 4 * QS;
-    s.xin = smem + 8 * QS;              // 288
+    s.us = smem + 8 * ES;
+    s.xin = smem + 16 * ES;             // 320
     s.part = s.xin + 512;
     s.pre = s.part + (size_t)RW * p.pstride;
     s.flags = reinterpret_cast<int*>(s.pre + (size_t)p.upr * GC);
@@ -217,7 +249,7 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
     float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
     const int hoff = (p.kw - 1) * RC;
     if (rows > 0) {
-        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hs[qidx(tid)];
+        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hs[eidx(tid)];
         __syncthreads();
         for (int idx = tid; idx < hoff; idx += RT) {
             const int k = idx / RC, r = idx - k * RC;
@@ -234,23 +266,35 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
     __syncthreads();
 }
 
+// One stage = one gated layer on one CU, weights resident in VGPRs.  Thread mapping: eight adjacent lanes split the
+// K = 128 contraction (16 floats each: four ds_read_b128 per broadcast vector instead of eight -- the broadcast reads
+// are what the chain waits for, 8 waves x 8 reads saturate the LDS for 256 cycles and skew the waves by as much),
+// a group of eight lanes owns channels 2og and 2og + 1.  The reductions are reduce-scatters: the first DPP step
+// (row_half_mirror, lane j <-> 7 - j) also hands lanes 0-3 the sums of channel 2og and lanes 4-7 those of 2og + 1,
+// the remaining two quad_perm steps run on one value per matrix row instead of two.
 __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
     const StageLds s = carve_stage(smem, p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q = lane & 3, i = wave * 16 + (lane >> 2);        // K-quarter, output channel
+    const int ks = tid & 7, og = tid >> 3;                      // K-slice; lane group = channels 2og, 2og + 1
+    const bool hi = ks >= 4;                                    // lanes 4-7 finish channel 2og + 1, lanes 0-3 channel 2og
+    const int ch = 2 * og + (hi ? 1 : 0);
+    const bool writer = (ks & 3) == 0;                          // lanes 0 and 4 of the group publish
     const int l = sidx;
     const bool last_stage = sidx == p.S - 1;
     const int S1 = p.S + 1;
 
-    // ---- resident weights (registers): newest conv tap (tanh row, sigmoid row), conv1x1_out and conv1x1_skip, all
-    //      as pairs along K -- every chain FMA is a v_pk_fma_f32 ---------------------------------------------------
-    f2 wa[16], wg[16], wo[16], ws[16];
-    load_image16(p.w2img + (size_t)l * 16 * RT * 4, tid, wa);
-    load_image16(p.w2img + (size_t)l * 16 * RT * 4 + (size_t)8 * RT * 4, tid, wg);
-    load_image16(p.woimg + (size_t)l * 8 * RT * 4, tid, wo);
-    load_image16(p.wsimg + (size_t)l * 8 * RT * 4, tid, ws);
-    const float bo_r = p.bo[(size_t)l * RC + i];
-    const float bs_r = p.bskip[(size_t)l * p.Kp + i];
+    // ---- resident weights (registers), all as pairs along K (every chain FMA is a v_pk_fma_f32):
+    //      wz rows = {tanh c0, sigmoid c0, tanh c1, sigmoid c1} of the newest conv tap, wo / ws rows = {c0, c1} ----
+    f2 wz[4][8], wo[2][8], ws[2][8];
+#pragma unroll
+    for (int row = 0; row < 4; ++row) load_image8(p.w2img + ((size_t)l * 4 + row) * 4 * RT * 4, tid, wz[row]);
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        load_image8(p.woimg + ((size_t)l * 2 + row) * 4 * RT * 4, tid, wo[row]);
+        load_image8(p.wsimg + ((size_t)l * 2 + row) * 4 * RT * 4, tid, ws[row]);
+    }
+    const float bo_r = p.bo[(size_t)l * RC + ch];
+    const float bs_r = p.bskip[(size_t)l * p.Kp + ch];
     if (tid == 0) s.flags[0] = 0;
     // successor: next stage, or the head behind the last stage (block = ring + pos * rstride)
     const bool fast = same_xcd_as(p, ring + (sidx + 1) * p.rstride, s.flags + 1);
@@ -269,56 +313,73 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             // everything the chain needs that is known before the activation arrives: mailbox addresses and the
             // accumulator init (= next-step pre-activation), pinned in registers ahead of the wait
             const u64* hm_in = p.hmail + ((size_t)b * S1 + sidx) * RC + tid;
-            u64* hm_out = p.hmail + ((size_t)b * S1 + sidx + 1) * RC + i;
-            const u64* sm_in = p.smail + ((size_t)b * S1 + sidx) * p.Kp + i;
-            u64* sm_out = p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + i;
-            float za = 0.f, zg = 0.f;
-            if (q == 0) { za = s.pre[(size_t)j * GC + i]; zg = s.pre[(size_t)j * GC + RC + i]; }
-            asm volatile("" : "+v"(hm_in), "+v"(hm_out), "+v"(sm_in), "+v"(sm_out), "+v"(za), "+v"(zg));
+            u64* hm_out = p.hmail + ((size_t)b * S1 + sidx + 1) * RC + ch;
+            const u64* sm_in = p.smail + ((size_t)b * S1 + sidx) * p.Kp + ch;
+            u64* sm_out = p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + ch;
+            float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
+            if (ks == 0) {
+                const float* pre = s.pre + (size_t)j * GC;
+                z0 = pre[2 * og]; z1 = pre[RC + 2 * og]; z2 = pre[2 * og + 1]; z3 = pre[RC + 2 * og + 1];
+            }
+            asm volatile("" : "+v"(hm_in), "+v"(hm_out), "+v"(sm_in), "+v"(sm_out), "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
             // ---- receive the activation vector of (b, t) ------------------------------------------------
             if (wave < 2) {
                 float v = 0.f;
                 if (!wave_recv<false>(hm_in, true, tag, v, p.status, 0x100u + (unsigned)sidx, lane)) s.flags[0] = 1;
-                s.hs[qidx(tid)] = v;
+                s.hs[eidx(tid)] = v;
             }
             __syncthreads();
             stamp(p, b, t, sidx, 0);
             // ---- the chain: newest tap + pre -> gate -> conv1x1_out -> residual -> send -------------------------
-            float xu[32];
+            float xu[16];
             float hres;
             {
-                float x[32];
-                lds_read32(s.hs + QS * q, x);
-                hres = s.hs[qidx(i)];
-                f2 a0 = f2{za, 0.f}, a1 = f2{0.f, 0.f}, g0 = f2{zg, 0.f}, g1 = f2{0.f, 0.f};
+                float x[16];
+                lds_read16(s.hs + ES * ks, x);
+                hres = s.hs[eidx(ch)];
+                f2 acc[4] = {f2{z0, 0.f}, f2{z1, 0.f}, f2{z2, 0.f}, f2{z3, 0.f}};
 #pragma unroll
-                for (int k = 0; k < 16; k += 2) {
-                    a0 = __builtin_elementwise_fma(wa[k], f2{x[2 * k], x[2 * k + 1]}, a0);
-                    g0 = __builtin_elementwise_fma(wg[k], f2{x[2 * k], x[2 * k + 1]}, g0);
-                    a1 = __builtin_elementwise_fma(wa[k + 1], f2{x[2 * k + 2], x[2 * k + 3]}, a1);
-                    g1 = __builtin_elementwise_fma(wg[k + 1], f2{x[2 * k + 2], x[2 * k + 3]}, g1);
-                }
-                a0 += a1; g0 += g1;
-                const float a = quad_allreduce(a0.x + a0.y), g = quad_allreduce(g0.x + g0.y);
-                const float u = fast_gate(a, g);                                // modules.py:154
-                if (q == 0) s.us[qidx(i)] = u;
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int row = 0; row < 4; ++row)
+                        acc[row] = __builtin_elementwise_fma(wz[row][k], f2{x[2 * k], x[2 * k + 1]}, acc[row]);
+                float a0 = acc[0].x + acc[0].y, g0 = acc[1].x + acc[1].y, a1 = acc[2].x + acc[2].y, g1 = acc[3].x + acc[3].y;
+#ifdef WNV_FINE_TRACE
+                asm volatile("" : "+v"(a0), "+v"(g0), "+v"(a1), "+v"(g1));
+                stamp(p, b, t, sidx, 5);
+#endif
+                // reduce-scatter: lanes 0-3 collect channel c0, lanes 4-7 channel c1 (the partner is lane 7 - j)
+                float a = (hi ? a1 : a0) + dpp_mov<0x141>(hi ? a0 : a1);
+                float g = (hi ? g1 : g0) + dpp_mov<0x141>(hi ? g0 : g1);
+                a = quad_allreduce(a); g = quad_allreduce(g);
+                float u = fast_gate(a, g);                                      // modules.py:154
+#ifdef WNV_FINE_TRACE
+                asm volatile("" : "+v"(u));
+                stamp(p, b, t, sidx, 6);
+#endif
+                if (writer) s.us[eidx(ch)] = u;
+#ifdef WNV_FINE_TRACE
+                stamp(p, b, t, sidx, 7, 448);
+#endif
             }
             __syncthreads();
             stamp(p, b, t, sidx, 1);
-            lds_read32(s.us + QS * q, xu);
+            lds_read16(s.us + ES * ks, xu);
             if (!last_stage) {                      // the last layer's residual output is never used (wavenet.py:310-313)
-                const float o = quad_allreduce(dot32p(wo, xu));
+                const float o0 = dot16p(wo[0], xu), o1 = dot16p(wo[1], xu);
+                const float o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1));
                 const float hn = (o + bo_r + hres) * 0.70710678118654752440f;   // modules.py:162
-                if (q == 0) st_granule(hm_out, tag, hn, fast);                  // send on
+                if (writer) st_granule(hm_out, tag, hn, fast);                  // send on
             }
             stamp(p, b, t, sidx, 2);
             // ---- deferred 1: skip 1x1 from the same registers, accumulated in the reference's layer order -----------
             {
-                const float mine = quad_allreduce(dot32p(ws, xu)) + bs_r;       // wavenet.py:312
+                const float m0 = dot16p(ws[0], xu), m1 = dot16p(ws[1], xu);
+                const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + bs_r;   // wavenet.py:312
                 float acc = 0.f;
                 bool ok = true;
-                if (sidx > 0) ok = wave_recv<false>(sm_in, q == 0, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
-                if (q == 0 && ok) st_granule(sm_out, tag, acc + mine, fast);
+                if (sidx > 0) ok = wave_recv<false>(sm_in, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
+                if (writer && ok) st_granule(sm_out, tag, acc + mine, fast);
                 if (!ok) s.flags[0] = 1;
             }
             stamp(p, b, t, sidx, 3);
@@ -519,6 +580,17 @@ static void put_image(std::vector<float>& blob, size_t off, const float* M, int 
     }
 }
 
+// stage-kernel row image: thread tid (K-slice ks = tid & 7, lane group og = tid >> 3) holds
+// M[row_offset + 2og + odd][16ks .. 16ks + 16) as 4 chunks of 4 floats, laid out [chunk][512 threads][4]
+static void put_row8(std::vector<float>& blob, size_t off, const float* M, int row_offset, int odd) {
+    for (int tid = 0; tid < RT; ++tid) {
+        const int ks = tid & 7, og = tid >> 3;
+        const float* src = M + (size_t)(row_offset + 2 * og + odd) * RC + 16 * ks;
+        for (int c = 0; c < 4; ++c)
+            for (int e = 0; e < 4; ++e) blob[off + ((size_t)c * RT + tid) * 4 + e] = src[4 * c + e];
+    }
+}
+
 static wnv_status build_state(WnvRingState** out, int device, const wnv_config& c, const TensorStore& store,
                               std::string& err) {
     WnvRingState* st = new WnvRingState();
@@ -546,10 +618,14 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
         // newest tap (k = kw-1) as a (256 x 128) matrix
         for (int o = 0; o < GC; ++o)
             for (int ii = 0; ii < RC; ++ii) cur[(size_t)o * RC + ii] = wc.data[((size_t)o * RC + ii) * kw + (kw - 1)];
-        put_image(blob, st->o_w2 + (size_t)l * 16 * RT * 4, cur.data(), 0, GC);                       // tanh half
-        put_image(blob, st->o_w2 + (size_t)l * 16 * RT * 4 + (size_t)8 * RT * 4, cur.data(), RC, GC); // sigmoid half
+        const size_t rowsz = (size_t)4 * RT * 4;                   // one row image: 4 chunks x 512 threads x 4 floats
+        put_row8(blob, st->o_w2 + ((size_t)l * 4 + 0) * rowsz, cur.data(), 0, 0);      // tanh row of channel 2og
+        put_row8(blob, st->o_w2 + ((size_t)l * 4 + 1) * rowsz, cur.data(), RC, 0);     // sigmoid row of channel 2og
+        put_row8(blob, st->o_w2 + ((size_t)l * 4 + 2) * rowsz, cur.data(), 0, 1);      // tanh row of channel 2og + 1
+        put_row8(blob, st->o_w2 + ((size_t)l * 4 + 3) * rowsz, cur.data(), RC, 1);     // sigmoid row of channel 2og + 1
         const HostTensor& wo = T(pfx + "conv1x1_out.weight");          // (R, G/2, 1)
-        put_image(blob, st->o_wo + (size_t)l * 8 * RT * 4, wo.data.data(), 0, RC);
+        put_row8(blob, st->o_wo + ((size_t)l * 2 + 0) * rowsz, wo.data.data(), 0, 0);
+        put_row8(blob, st->o_wo + ((size_t)l * 2 + 1) * rowsz, wo.data.data(), 0, 1);
         const HostTensor& bo = T(pfx + "conv1x1_out.bias");
         std::copy(bo.data.begin(), bo.data.end(), blob.begin() + st->o_bo + (size_t)l * RC);
         // deferred: older taps (oldest first) then local conditioning, K-major [kpre][256]
@@ -563,7 +639,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
                 for (int o = 0; o < GC; ++o) wp[(size_t)((kw - 1) * RC + jx) * GC + o] = wcc.data[(size_t)o * cin + jx];
         }
         const HostTensor& ws = T(pfx + "conv1x1_skip.weight");         // (K = 128, G/2, 1)
-        put_image(blob, st->o_ws + (size_t)l * 8 * RT * 4, ws.data.data(), 0, K);
+        put_row8(blob, st->o_ws + ((size_t)l * 2 + 0) * rowsz, ws.data.data(), 0, 0);
+        put_row8(blob, st->o_ws + ((size_t)l * 2 + 1) * rowsz, ws.data.data(), 0, 1);
         const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
         std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bskip + (size_t)l * Kp);
         dil[l] = 1 << (l % per);
@@ -659,7 +736,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.out = ga.out; p.params_out = ga.params_out;
     // LDS: the stage carve is the larger one
-    const size_t lds = ((size_t)8 * QS + 512 + (size_t)RW * p.pstride + (size_t)upr * GC + 16) * sizeof(float);
+    const size_t lds = ((size_t)16 * ES + 512 + (size_t)RW * p.pstride + (size_t)upr * GC + 16) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS for this many utterances per ring"; return WNV_ERR_UNSUPPORTED; }
     RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = rstride * (st->S + 1);
@@ -691,7 +768,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
             for (int tt = 0; tt < trace_n; ++tt)
                 for (int pos = 0; pos <= st->S; ++pos) {
                     fprintf(f, "%d %d", p.trace_t0 + tt, pos);
-                    for (int k = 0; k < 5; ++k) {
+                    for (int k = 0; k < 8; ++k) {
                         const unsigned long long v = tr[((size_t)tt * (st->S + 1) + pos) * 8 + k];
                         fprintf(f, " %lld", v ? (long long)(v - t00) * 10 : -1LL);
                     }
