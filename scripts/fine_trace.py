@@ -1,10 +1,11 @@
-"""Fine-grained timeline of one ring stage (debug build with -DWNV_FINE_TRACE): slots 5-7."""
+"""Fine-grained timeline of ring stages (debug build with -DWNV_FINE_TRACE): slots 5-7."""
 import sys
 rows = [l.split() for l in open(sys.argv[1]) if not l.startswith("#")]
 steps = sorted({int(r[0]) for r in rows})
 t = steps[2]
-for pos in (3, 4, 10):
+S = max(int(r[1]) for r in rows)
+base = [int(x) for x in [r for r in rows if int(r[0]) == t and int(r[1]) == S][0][2:]][0]
+for pos in range(2, 12):
     r = [x for x in rows if int(x[0]) == t and int(x[1]) == pos][0]
-    v = [int(x) for x in r[2:]]
-    b = v[0]
-    print(f"stage {pos}: recv 0 | z FMAs done (wave0) +{v[5]-b} | gate computed (wave0) +{v[6]-b} | wave7 at barrier +{v[7]-b} | barrier passed (wave0) +{v[1]-b} | out/send +{v[2]-b} | skip sent +{v[3]-b}")
+    v = [int(x) - base for x in r[2:]]
+    print(f"stage {pos:2d}: step start {v[5]:6d} | zin ready {v[6]:6d} | X received {v[0]:6d} | u sent {v[1]:6d} | barrier {v[7]:6d} | H sent {v[2]:6d} | skip sent {v[3]:6d} | deferred done {v[4]:6d}")

@@ -27,8 +27,9 @@ for pos in list(range(S)) + [S]:
     r = [x for x in rows if int(x[0]) == t and int(x[1]) == pos][0]
     v = [int(x) - base if int(x) >= 0 else None for x in r[2:]]
     if pos < S:
-        print(f" stage {pos:2d}: recv {v[0]:6d} (hop {v[0]-prev_send:5d})  gate +{v[1]-v[0]:5d}  out/send +{v[2]-v[1]:5d}  skip-sent +{v[3]-v[2]:5d}  deferred-done +{v[4]-v[3]:5d}")
-        prev_send = v[2]
+        print(f" stage {pos:2d}: recv {v[0]:6d} (hop {v[0]-prev_send:5d})  gate/send-u +{v[1]-v[0]:5d}  h-sent +{v[2]-v[1]:5d}  skip-sent +{v[3]-v[2]:5d}  deferred-done +{v[4]-v[3]:5d}")
+        prev_send = v[1]
+        last_skip = v[3]
     else:
         # head stamps of step t: [0] send (this step), [1] skip received, [2] sample done
-        print(f" head    : skip recv {v[1]:6d} (after last stage send {v[1]-prev_send:5d})  sample done +{v[2]-v[1]:5d}")
+        print(f" head    : skip recv {v[1]:6d} (after last stage's skip send {v[1]-last_skip:5d})  sample done +{v[2]-v[1]:5d}")

@@ -65,12 +65,12 @@ struct RingParams {
     int allow_fast;                    // same-XCD hand-off through the XCD's L2 (plain stores) when placement allows
     unsigned tag_base;                 // tags of this launch are tag_base + t + 1: unique across launches, no re-zeroing
     float skip_scale;
-    const float *w2img, *woimg, *wsimg, *bo, *wpre, *bskip;
+    const float *w2img, *wnimg, *woimg, *wsimg, *bo, *wpre, *bskip, *cvec;
     const float *wh1img, *bh1, *wh2img, *bh2, *wfirst, *bfirst;
     const float* zbias;
     long long zbias_bstride;
     const int *lay_dil, *lay_histoff;
-    unsigned long long *hmail, *smail;
+    unsigned long long *xmail, *hmail, *smail;   // chain inputs X[b][S+1][128]; layer inputs H[b][2 (t parity)][S+1][128]; skip sums
     unsigned int* xcc;                 // [grid] XCC id + 1 of every workgroup (placement handshake)
     float* hist;
     const float *c_up, *initial, *teacher, *noise;
@@ -79,6 +79,7 @@ struct RingParams {
     unsigned int* status;
     unsigned long long* trace;         // optional [T_trace][S+1][8] wall-clock stamps of utterance 0 (debug)
     int trace_t0, trace_n;
+    const RingParams* self;            // device-memory copy of this block (see reread())
 };
 
 using u64 = unsigned long long;
@@ -95,15 +96,25 @@ __device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v, bool f
     else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
 }
 
+// A poll whose first load is issued early (inline asm: the compiler neither moves it nor waits for it) so that its L2
+// round trip (~0.25 us even when the granule is already there) overlaps the work in between; redeem() waits for it.
+__device__ __forceinline__ u64 ld_issue(const u64* p) {
+    u64 v;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ld_redeem(u64& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+
 // One wave waits until the granule of every ACTIVE lane carries `tag`; returns false on abort/timeout.
 template <bool SLEEP>
 __device__ __forceinline__ bool wave_recv(const u64* g, bool active, unsigned tag, float& v, unsigned int* status,
-                                          unsigned code, int lane) {
+                                          unsigned code, int lane, bool have_first = false, u64 first = 0) {
     unsigned spins = 0;
     for (;;) {
         bool ok = true;
         if (active) {
-            const u64 x = ld_granule(g);
+            const u64 x = have_first ? first : ld_granule(g);
+            have_first = false;
             v = __uint_as_float((unsigned)x);
             ok = (unsigned)(x >> 32) == tag;
         }
@@ -120,22 +131,38 @@ __device__ __forceinline__ bool wave_recv(const u64* g, bool active, unsigned ta
     }
 }
 
-// Placement handshake: publish this workgroup's XCC id, read the successor's; true when both share an XCD (and L2).
-__device__ __forceinline__ bool same_xcd_as(const RingParams& p, int succ_block, int* flag) {
+// Placement handshake: publish this workgroup's XCC id, read those of the (up to two) workgroups that read what this one
+// sends; true when all share an XCD (and its L2).
+__device__ __forceinline__ bool same_xcd_as(const RingParams& p, int reader_a, int reader_b, int* flag) {
     if (threadIdx.x == 0) {
         unsigned x;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
         x = (x & 0xfu) + 1u;
         __hip_atomic_store(p.xcc + blockIdx.x, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned y = 0, spins = 0;
-        while ((y = __hip_atomic_load(p.xcc + succ_block, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
-            if (++spins > SPIN_LIMIT) break;                       // unknown placement: take the placement-independent path
-            __builtin_amdgcn_s_sleep(2);
+        bool same = true;
+        const int rd[2] = {reader_a, reader_b};
+        for (int k = 0; k < 2; ++k) {
+            unsigned y = 0, spins = 0;
+            while ((y = __hip_atomic_load(p.xcc + rd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                if (++spins > SPIN_LIMIT) break;                   // unknown placement: take the placement-independent path
+                __builtin_amdgcn_s_sleep(2);
+            }
+            same = same && y == x;
         }
-        *flag = (p.allow_fast && y == x) ? 1 : 0;
+        *flag = (p.allow_fast && same) ? 1 : 0;
     }
     __syncthreads();
     return *flag != 0;
+}
+
+// The parameter block is passed twice: by value (kernel-argument segment) for the chain, and as a copy in device memory
+// (p.self) for the deferred work, which reads its fields through a pointer made opaque once per step -- re-read with
+// scalar loads off the chain instead of being hoisted out of the time loop into ~40 long-lived SGPRs that would spill
+// into VGPR lanes (and come back through v_readlane on the chain).
+__device__ __forceinline__ const RingParams& reread(const RingParams& p) {
+    const RingParams* q = p.self;
+    asm volatile("" : "+s"(q));
+    return *q;
 }
 
 // debug timeline: stamp slot k of (step t, position pos) with the device-wide 100 MHz wall clock
@@ -197,6 +224,18 @@ __device__ __forceinline__ float dot16p(const f2 (&w)[8], const float (&x)[16]) 
     a0 += a1;
     return a0.x + a0.y;
 }
+// the same with the weight row read from an LDS image ([chunk][512 threads] float4, conflict-free 16 B per lane)
+__device__ __forceinline__ float dot16l(const float4* w, const float (&x)[16]) {
+    f2 a0 = f2{0.f, 0.f}, a1 = f2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 v = w[(size_t)c * RT];
+        a0 = __builtin_elementwise_fma(f2{v.x, v.y}, f2{x[4 * c], x[4 * c + 1]}, a0);
+        a1 = __builtin_elementwise_fma(f2{v.z, v.w}, f2{x[4 * c + 2], x[4 * c + 3]}, a1);
+    }
+    a0 += a1;
+    return a0.x + a0.y;
+}
 // one matrix row's 16-float K-slice: 4 chunks of 16 B, image layout [chunk][512 threads][4]
 __device__ __forceinline__ void load_image8(const float* img, int tid, f2 (&w)[8]) {
     const float4* src = reinterpret_cast<const float4*>(img);
@@ -220,23 +259,32 @@ constexpr int ES = 20;
 __device__ __forceinline__ int eidx(int i) { return ES * (i >> 4) + (i & 15); }
 
 struct StageLds {
-    float* hs;       // strided layer input h_l[t]
-    float* us;       // strided gate output
+    float* hx;       // chain input X[l][t]  (u of the layer before, or h_0 at stage 0), eight padded K-slices
+    float* hb;       // h_{l-1}[t]: input of the off-chain mat-vec N_l . h_{l-1}
+    float* hh;       // h_l[t]: residual input of conv1x1_out and the row pushed into the history ring
+    float* us;       // gate output u_l[t]
     float* xin;      // [512] deferred mat-vec input
     float* part;     // [8][pstride]
     float* pre;      // [upr][256] next step's tap/conditioning pre-activations
     int* flags;
+    float4* wsk;     // [2 rows][4 chunks][512 threads] image of conv1x1_skip (64 KiB; off the chain)
 };
 
 __device__ __forceinline__ StageLds carve_stage(float* smem, const RingParams& p) {
     StageLds s;
-    s.hs = smem;
-    s.us = smem + 8 * ES;
-    s.xin = smem + 16 * ES;             // 320
+    s.hx = smem;
+    s.hb = smem + 8 * ES;
+    s.hh = smem + 16 * ES;
+    s.us = smem + 24 * ES;
+    s.xin = smem + 32 * ES;             // 640
     s.part = s.xin + 512;
     s.pre = s.part + (size_t)RW * p.pstride;
     s.flags = reinterpret_cast<int*>(s.pre + (size_t)p.upr * GC);
+    s.wsk = reinterpret_cast<float4*>(s.flags + 16);
     return s;
+}
+__host__ __device__ constexpr size_t stage_lds_floats(int pstride, int upr) {
+    return (size_t)32 * ES + 512 + (size_t)RW * pstride + (size_t)upr * GC + 16 + (size_t)8 * RT * 4;
 }
 
 // Deferred: pre-activation of layer l for step tp (>= 0) of utterance b, from the history ring and c[tp]:
@@ -249,7 +297,7 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
     float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
     const int hoff = (p.kw - 1) * RC;
     if (rows > 0) {
-        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hs[eidx(tid)];
+        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hh[eidx(tid)];
         __syncthreads();
         for (int idx = tid; idx < hoff; idx += RT) {
             const int k = idx / RC, r = idx - k * RC;
@@ -258,7 +306,7 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
     }
     for (int c = tid; c < p.cin; c += RT) s.xin[hoff + c] = p.c_up[((size_t)b * p.T + tp) * p.cin + c];
     float zb = 0.f;
-    if (tid < GC) zb = p.zbias[(size_t)b * p.zbias_bstride + (size_t)l * GC + tid];
+    if (tid < GC) zb = p.zbias[(size_t)b * p.zbias_bstride + (size_t)l * GC + tid] + p.cvec[(size_t)l * GC + tid];
     __syncthreads();
     matvec_partial_small<RW>(p.wpre + (size_t)l * p.kpre * GC, p.kpre, GC, s.xin, s.part, p.pstride, wave, lane);
     __syncthreads();
@@ -266,12 +314,22 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
     __syncthreads();
 }
 
-// One stage = one gated layer on one CU, weights resident in VGPRs.  Thread mapping: eight adjacent lanes split the
-// K = 128 contraction (16 floats each: four ds_read_b128 per broadcast vector instead of eight -- the broadcast reads
-// are what the chain waits for, 8 waves x 8 reads saturate the LDS for 256 cycles and skew the waves by as much),
-// a group of eight lanes owns channels 2og and 2og + 1.  The reductions are reduce-scatters: the first DPP step
-// (row_half_mirror, lane j <-> 7 - j) also hands lanes 0-3 the sums of channel 2og and lanes 4-7 those of 2og + 1,
-// the remaining two quad_perm steps run on one value per matrix row instead of two.
+// One stage = one gated layer on one CU, weights resident in VGPRs.
+//
+// GATE-TO-GATE CHAIN.  The reference's layer is  z_l = W_cur,l h_l + pre_l ;  u_l = tanh . sigmoid (z_l) ;
+// h_{l+1} = sqrt(.5) (W_o,l u_l + b_o,l + h_l)   (modules.py:127-163).  Substituting h_l into z_l,
+//     z_l = M_l u_{l-1} + N_l h_{l-1} + c_l + pre_l ,   M_l = sqrt(.5) W_cur,l W_o,l-1 ,  N_l = sqrt(.5) W_cur,l ,  c_l = N_l b_o,l-1
+// (M, N, c folded once on the host, in double).  h_{l-1} is known a whole layer earlier than u_{l-1}, so only
+// M_l u_{l-1} -> gate -> send u_l  is on the chain; conv1x1_out (the h recurrence itself, bit for bit the reference's),
+// the N_l mat-vec (weights in LDS), the skip 1x1, the history push and the older taps all happen behind the send.
+// The values exchanged:  X[l] = u_{l-1} (X[0] = h_0 from the head) over the chain mailbox;  H[l] = h_l, written by
+// stage l-1 into a mailbox with one slot per step parity and read by stage l (residual, history) and stage l+1 (N);
+// two slots because those reads are off the chain: a slot is rewritten two steps later, which the data flow itself
+// orders behind every reader (the writer's gate of step t+2 needs the sample of step t+1, hence every stage's step t+1).
+//
+// Thread mapping: eight adjacent lanes split the K = 128 contraction (16 floats each), a group of eight lanes owns
+// channels 2og and 2og + 1; reductions are reduce-scatters (first DPP step row_half_mirror, lane j <-> 7 - j, hands
+// lanes 0-3 the sums of channel 2og and lanes 4-7 those of 2og + 1; two quad_perm steps finish).
 __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
     const StageLds s = carve_stage(smem, p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -280,24 +338,30 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     const int ch = 2 * og + (hi ? 1 : 0);
     const bool writer = (ks & 3) == 0;                          // lanes 0 and 4 of the group publish
     const int l = sidx;
-    const bool last_stage = sidx == p.S - 1;
+    const bool first_stage = sidx == 0, last_stage = sidx == p.S - 1;
     const int S1 = p.S + 1;
 
-    // ---- resident weights (registers), all as pairs along K (every chain FMA is a v_pk_fma_f32):
-    //      wz rows = {tanh c0, sigmoid c0, tanh c1, sigmoid c1} of the newest conv tap, wo / ws rows = {c0, c1} ----
-    f2 wz[4][8], wo[2][8], ws[2][8];
+    // ---- resident weights (registers), pairs along K (every FMA on or near the chain is a v_pk_fma_f32):
+    //      wm / wn rows = {tanh c0, sigmoid c0, tanh c1, sigmoid c1} of M_l and N_l, wo rows = {c0, c1} of conv1x1_out;
+    //      conv1x1_skip (nobody waits for it) is read from an LDS image ----------------------------------------------
+    f2 wm[4][8], wn[4][8], wo[2][8];
 #pragma unroll
-    for (int row = 0; row < 4; ++row) load_image8(p.w2img + ((size_t)l * 4 + row) * 4 * RT * 4, tid, wz[row]);
+    for (int row = 0; row < 4; ++row) {
+        load_image8(p.w2img + ((size_t)l * 4 + row) * 4 * RT * 4, tid, wm[row]);
+        load_image8(p.wnimg + ((size_t)l * 4 + row) * 4 * RT * 4, tid, wn[row]);      // zeros at stage 0
+    }
 #pragma unroll
-    for (int row = 0; row < 2; ++row) {
-        load_image8(p.woimg + ((size_t)l * 2 + row) * 4 * RT * 4, tid, wo[row]);
-        load_image8(p.wsimg + ((size_t)l * 2 + row) * 4 * RT * 4, tid, ws[row]);
+    for (int row = 0; row < 2; ++row) load_image8(p.woimg + ((size_t)l * 2 + row) * 4 * RT * 4, tid, wo[row]);
+    {
+        const float4* ssrc = reinterpret_cast<const float4*>(p.wsimg) + (size_t)l * 8 * RT;
+        for (int c = 0; c < 8; ++c) s.wsk[(size_t)c * RT + tid] = ssrc[(size_t)c * RT + tid];
     }
     const float bo_r = p.bo[(size_t)l * RC + ch];
     const float bs_r = p.bskip[(size_t)l * p.Kp + ch];
     if (tid == 0) s.flags[0] = 0;
-    // successor: next stage, or the head behind the last stage (block = ring + pos * rstride)
-    const bool fast = same_xcd_as(p, ring + (sidx + 1) * p.rstride, s.flags + 1);
+    // readers of what this stage sends: the next stage (X, H) and the one behind it (H); the head behind the last stage
+    const int rd1 = ring + (sidx + 1) * p.rstride, rd2 = ring + (sidx + 2 <= p.S ? sidx + 2 : sidx + 1) * p.rstride;
+    const bool fast = same_xcd_as(p, rd1, rd2, s.flags + 1);
 
     // ---- prologue: pre-activations of step 0 (all taps are zero history) ------------------------------------
     for (int j = 0; j < p.upr; ++j) {
@@ -307,85 +371,135 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
 
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        const int par = t & 1;
         for (int j = 0; j < p.upr; ++j) {
             const int b = ring + j * p.n_rings;
             if (b >= p.B) continue;
-            // everything the chain needs that is known before the activation arrives: mailbox addresses and the
-            // accumulator init (= next-step pre-activation), pinned in registers ahead of the wait
-            const u64* hm_in = p.hmail + ((size_t)b * S1 + sidx) * RC + tid;
-            u64* hm_out = p.hmail + ((size_t)b * S1 + sidx + 1) * RC + ch;
+            // every mailbox address of this step, pinned in registers before the first wait
+            const u64* x_in = p.xmail + ((size_t)b * S1 + sidx) * RC + tid;
+            u64 x_first = 0;
+            u64* x_out = p.xmail + ((size_t)b * S1 + sidx + 1) * RC + ch;
+            const u64* h_in = p.hmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + ch;
+            u64* h_out = p.hmail + (((size_t)b * 2 + par) * S1 + sidx + 1) * RC + ch;
             const u64* sm_in = p.smail + ((size_t)b * S1 + sidx) * p.Kp + ch;
             u64* sm_out = p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + ch;
-            float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
-            if (ks == 0) {
-                const float* pre = s.pre + (size_t)j * GC;
-                z0 = pre[2 * og]; z1 = pre[RC + 2 * og]; z2 = pre[2 * og + 1]; z3 = pre[RC + 2 * og + 1];
-            }
-            asm volatile("" : "+v"(hm_in), "+v"(hm_out), "+v"(sm_in), "+v"(sm_out), "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));
-            // ---- receive the activation vector of (b, t) ------------------------------------------------
-            if (wave < 2) {
-                float v = 0.f;
-                if (!wave_recv<false>(hm_in, true, tag, v, p.status, 0x100u + (unsigned)sidx, lane)) s.flags[0] = 1;
-                s.hs[eidx(tid)] = v;
-            }
-            __syncthreads();
-            stamp(p, b, t, sidx, 0);
-            // ---- the chain: newest tap + pre -> gate -> conv1x1_out -> residual -> send -------------------------
-            float xu[16];
-            float hres;
+            asm volatile("" : "+v"(x_in), "+v"(h_in), "+v"(h_out), "+v"(sm_in), "+v"(sm_out));
+            // ---- ahead of the chain: zin = N_l h_{l-1}[t] + pre_l[t]  (h_{l-1} arrives a layer time before u_{l-1}) ------
+            float zin_a, zin_g;
             {
+                const float* pre = s.pre + (size_t)j * GC;
+                zin_a = pre[ch]; zin_g = pre[RC + ch];
+            }
+#ifdef WNV_FINE_TRACE
+            stamp(p, b, t, sidx, 5);
+#endif
+            if (!first_stage) {
+                if (wave < 2) {
+                    // h_0 is the chain input of stage 0; h_{l-1} for l >= 2 comes from stage l-2's conv1x1_out
+                    const u64* hb_in = sidx == 1 ? p.xmail + ((size_t)b * S1) * RC + tid
+                                                 : p.hmail + (((size_t)b * 2 + par) * S1 + sidx - 1) * RC + tid;
+                    float v = 0.f;
+                    if (!wave_recv<false>(hb_in, true, tag, v, p.status, 0x400u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                    s.hb[eidx(tid)] = v;
+                    x_first = ld_issue(x_in);       // the chain input is usually there already: fetch it under the N mat-vec
+                }
+                __syncthreads();
                 float x[16];
-                lds_read16(s.hs + ES * ks, x);
-                hres = s.hs[eidx(ch)];
-                f2 acc[4] = {f2{z0, 0.f}, f2{z1, 0.f}, f2{z2, 0.f}, f2{z3, 0.f}};
+                lds_read16(s.hb + ES * ks, x);
+                f2 acc[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
 #pragma unroll
                 for (int k = 0; k < 8; ++k)
 #pragma unroll
                     for (int row = 0; row < 4; ++row)
-                        acc[row] = __builtin_elementwise_fma(wz[row][k], f2{x[2 * k], x[2 * k + 1]}, acc[row]);
-                float a0 = acc[0].x + acc[0].y, g0 = acc[1].x + acc[1].y, a1 = acc[2].x + acc[2].y, g1 = acc[3].x + acc[3].y;
+                        acc[row] = __builtin_elementwise_fma(wn[row][k], f2{x[2 * k], x[2 * k + 1]}, acc[row]);
+                const float a0 = acc[0].x + acc[0].y, g0 = acc[1].x + acc[1].y, a1 = acc[2].x + acc[2].y, g1 = acc[3].x + acc[3].y;
+                zin_a += quad_allreduce((hi ? a1 : a0) + dpp_mov<0x141>(hi ? a0 : a1));
+                zin_g += quad_allreduce((hi ? g1 : g0) + dpp_mov<0x141>(hi ? g0 : g1));
+            }
+            asm volatile("" : "+v"(x_out), "+v"(zin_a), "+v"(zin_g));
 #ifdef WNV_FINE_TRACE
-                asm volatile("" : "+v"(a0), "+v"(g0), "+v"(a1), "+v"(g1));
-                stamp(p, b, t, sidx, 5);
+            stamp(p, b, t, sidx, 6);
 #endif
-                // reduce-scatter: lanes 0-3 collect channel c0, lanes 4-7 channel c1 (the partner is lane 7 - j)
-                float a = (hi ? a1 : a0) + dpp_mov<0x141>(hi ? a0 : a1);
-                float g = (hi ? g1 : g0) + dpp_mov<0x141>(hi ? g0 : g1);
-                a = quad_allreduce(a); g = quad_allreduce(g);
-                float u = fast_gate(a, g);                                      // modules.py:154
-#ifdef WNV_FINE_TRACE
-                asm volatile("" : "+v"(u));
-                stamp(p, b, t, sidx, 6);
-#endif
-                if (writer) s.us[eidx(ch)] = u;
-#ifdef WNV_FINE_TRACE
-                stamp(p, b, t, sidx, 7, 448);
-#endif
+            // ---- the chain: receive X[l][t]  ->  M_l X + zin  ->  gate  ->  send u_l --------------------------------
+            if (wave < 2) {
+                float v = 0.f;
+                if (!first_stage) ld_redeem(x_first);
+                if (!wave_recv<false>(x_in, true, tag, v, p.status, 0x100u + (unsigned)sidx, lane, !first_stage, x_first))
+                    s.flags[0] = 1;
+                s.hx[eidx(tid)] = v;
             }
             __syncthreads();
+            stamp(p, b, t, sidx, 0);
+            {
+                float x[16];
+                lds_read16(s.hx + ES * ks, x);
+                f2 acc[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+#pragma unroll
+                    for (int row = 0; row < 4; ++row)
+                        acc[row] = __builtin_elementwise_fma(wm[row][k], f2{x[2 * k], x[2 * k + 1]}, acc[row]);
+                const float a0 = acc[0].x + acc[0].y, g0 = acc[1].x + acc[1].y, a1 = acc[2].x + acc[2].y, g1 = acc[3].x + acc[3].y;
+                // reduce-scatter: lanes 0-3 collect channel c0, lanes 4-7 channel c1 (the partner is lane 7 - j)
+                const float a = quad_allreduce((hi ? a1 : a0) + dpp_mov<0x141>(hi ? a0 : a1)) + zin_a;
+                const float g = quad_allreduce((hi ? g1 : g0) + dpp_mov<0x141>(hi ? g0 : g1)) + zin_g;
+                const float u = fast_gate(a, g);                                // modules.py:154
+                if (writer) {
+                    if (!last_stage) st_granule(x_out, tag, u, fast);           // send on: nothing else is on the chain
+                    s.us[eidx(ch)] = u;
+                }
+            }
             stamp(p, b, t, sidx, 1);
+            // ---- behind the send -----------------------------------------------------------------------------------
+            // h_l[t] (from stage l-1, normally a hop behind its u) is awaited by the very lanes that own the channel and
+            // added in registers: the h recurrence costs one hop + one add per layer.  Its first poll is issued here, under
+            // the barrier and the conv1x1_out mat-vec.
+            u64 h_first = 0;
+            if (!first_stage && writer) h_first = ld_issue(h_in);
+            __syncthreads();                                                    // u_l complete in LDS
+#ifdef WNV_FINE_TRACE
+            stamp(p, b, t, sidx, 7);
+#endif
+            float xu[16];
             lds_read16(s.us + ES * ks, xu);
-            if (!last_stage) {                      // the last layer's residual output is never used (wavenet.py:310-313)
-                const float o0 = dot16p(wo[0], xu), o1 = dot16p(wo[1], xu);
-                const float o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1));
-                const float hn = (o + bo_r + hres) * 0.70710678118654752440f;   // modules.py:162
-                if (writer) st_granule(hm_out, tag, hn, fast);                  // send on
+            // conv1x1_out -> residual -> publish h_{l+1}[t]  (modules.py:157-162: the reference's own recurrence)
+            {
+                float o = 0.f;
+                if (!last_stage) {                  // the last layer's residual output is never used (wavenet.py:310-313)
+                    const float o0 = dot16p(wo[0], xu), o1 = dot16p(wo[1], xu);
+                    o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1)) + bo_r;
+                }
+                float h = 0.f;
+                bool ok = true;
+                if (first_stage) {
+                    h = s.hx[eidx(ch)];                                          // h_0 is the chain input itself
+                } else {
+                    if (writer) ld_redeem(h_first);
+                    ok = wave_recv<false>(h_in, writer, tag, h, p.status, 0x500u + (unsigned)sidx, lane, true, h_first);
+                }
+                if (writer) {
+                    if (!last_stage && ok)
+                        st_granule(h_out, tag, (o + h) * 0.70710678118654752440f, fast);
+                    s.hh[eidx(ch)] = h;                                          // the row the history ring gets
+                }
+                if (!ok) s.flags[0] = 1;
             }
             stamp(p, b, t, sidx, 2);
-            // ---- deferred 1: skip 1x1 from the same registers, accumulated in the reference's layer order -----------
+            // ---- skip 1x1, accumulated stage to stage in the reference's layer order (wavenet.py:312) --------------------
             {
-                const float m0 = dot16p(ws[0], xu), m1 = dot16p(ws[1], xu);
-                const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + bs_r;   // wavenet.py:312
+                const float m0 = dot16l(s.wsk + (size_t)0 * RT + tid, xu), m1 = dot16l(s.wsk + (size_t)4 * RT + tid, xu);
+                const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + bs_r;
                 float acc = 0.f;
                 bool ok = true;
-                if (sidx > 0) ok = wave_recv<false>(sm_in, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
+                if (sidx > 0)
+                    ok = wave_recv<false>(sm_in, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
                 if (writer && ok) st_granule(sm_out, tag, acc + mine, fast);
                 if (!ok) s.flags[0] = 1;
             }
             stamp(p, b, t, sidx, 3);
-            // ---- deferred 2: history push + next step's pre-activations (its barriers fence hs/us for the next receive)
-            if (t + 1 < p.T) deferred_pre(p, s, b, j, l, t, t + 1, tid, wave, lane);
-            else __syncthreads();
+            // ---- history push + next step's pre-activations (its barriers fence the LDS vectors for the next step) -------
+            __syncthreads();                        // h_l[t] complete in LDS (written by the lanes that received it)
+            if (t + 1 < p.T) deferred_pre(reread(p), s, b, j, l, t, t + 1, tid, wave, lane);
             if (s.flags[0]) return;                 // a bounded wait gave up somewhere: drain (status holds the code)
             stamp(p, b, t, sidx, 4);
         }
@@ -425,14 +539,14 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
     const int nchunk = (nmix + 3) >> 2;
     if (tid < 48) s.vbuf[tid] = -INFINITY;
     if (tid == 0) s.flags[0] = 0;
-    const bool fast = same_xcd_as(p, ring, s.flags + 1);          // successor of the head = stage 0
+    const bool fast = same_xcd_as(p, ring, ring + (p.S > 1 ? p.rstride : 0), s.flags + 1);   // h_0 is read by stages 0 and 1
 
     // ---- prologue: the input of step 0 (wavenet.py:283-289, :297-308) ----------------------------------------
     for (int j = 0; j < p.upr; ++j) {
         const int b = ring + j * p.n_rings;
         if (b >= p.B || tid >= RC) continue;
         const float xs = p.Tt > 0 ? p.teacher[(size_t)b * p.Tt] : (p.initial ? p.initial[b] : 0.f);
-        st_granule(p.hmail + ((size_t)b * S1) * RC + tid, p.tag_base + 1u, fmaf(wf, xs, bf), fast);
+        st_granule(p.xmail + ((size_t)b * S1) * RC + tid, p.tag_base + 1u, fmaf(wf, xs, bf), fast);
         stamp(p, b, 0, p.S, 0);
     }
 
@@ -489,7 +603,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
                 xo = fminf(fmaxf(xo, -1.0f), 1.0f);                               // mixture.py:154 / :269
                 if (t + 1 < p.T) {
                     const float xs = t + 1 < p.Tt ? forced : xo;                   // wavenet.py:297-305
-                    st_granule(p.hmail + ((size_t)b * S1) * RC + tid, tag + 1u, fmaf(wf, xs, bf), fast);
+                    st_granule(p.xmail + ((size_t)b * S1) * RC + tid, tag + 1u, fmaf(wf, xs, bf), fast);
                     stamp(p, b, t + 1, p.S, 0);
                 }
                 if (tid == 0) p.out[(size_t)b * p.T + t] = xo;
@@ -519,7 +633,7 @@ struct WnvRingState {
     int device = 0;
     int L = 0, S = 0, K = 0, Kp = 0, O = 0, cin = 0, kw = 0, kpre = 0;
     float* d_w = nullptr;          // one blob, offsets below (floats)
-    size_t o_w2 = 0, o_wo = 0, o_bo = 0, o_wpre = 0, o_ws = 0, o_bskip = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0,
+    size_t o_wn = 0, o_cvec = 0, o_w2 = 0, o_wo = 0, o_bo = 0, o_wpre = 0, o_ws = 0, o_bskip = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0,
            o_bh2 = 0, o_wf = 0, o_bf = 0;
     int* d_dil = nullptr;
     int* d_histoff = nullptr;
@@ -603,6 +717,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     auto alloc = [&](size_t n) { size_t o = (blob.size() + 3) & ~(size_t)3; blob.resize(o + n, 0.f); return o; };
     auto T = [&](const std::string& n) -> const HostTensor& { return *store.get(n); };
     st->o_w2 = alloc((size_t)L * 16 * RT * 4);
+    st->o_wn = alloc((size_t)L * 16 * RT * 4);
+    st->o_cvec = alloc((size_t)L * GC);
     st->o_wo = alloc((size_t)L * 8 * RT * 4);
     st->o_bo = alloc((size_t)L * RC);
     st->o_wpre = alloc((size_t)L * st->kpre * GC);
@@ -611,18 +727,38 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     std::vector<int> dil(L), hoff(L);
     int hist = 0;
     const int per = L / c.stacks;
-    std::vector<float> cur((size_t)GC * RC);
+    std::vector<float> cur((size_t)GC * RC), mmat((size_t)GC * RC), nmat((size_t)GC * RC);
+    const double rs = std::sqrt(0.5);
     for (int l = 0; l < L; ++l) {
         const std::string pfx = "conv_layers." + std::to_string(l) + ".";
         const HostTensor& wc = T(pfx + "conv.weight");                 // (G, R, kw)
         // newest tap (k = kw-1) as a (256 x 128) matrix
         for (int o = 0; o < GC; ++o)
             for (int ii = 0; ii < RC; ++ii) cur[(size_t)o * RC + ii] = wc.data[((size_t)o * RC + ii) * kw + (kw - 1)];
+        // gate-to-gate chain (see run_stage): M_l = sqrt(.5) W_cur,l W_o,l-1, N_l = sqrt(.5) W_cur,l, c_l = N_l b_o,l-1, folded in
+        // double and rounded once; layer 0 reads h_0 itself: M_0 = W_cur,0, no N term
+        if (l == 0) {
+            mmat = cur;
+        } else {
+            const HostTensor& wop = T("conv_layers." + std::to_string(l - 1) + ".conv1x1_out.weight");   // (R, G/2, 1)
+            const HostTensor& bop = T("conv_layers." + std::to_string(l - 1) + ".conv1x1_out.bias");
+            for (int o = 0; o < GC; ++o) {
+                for (int kk = 0; kk < RC; ++kk) {
+                    double acc = 0.0;
+                    for (int m = 0; m < RC; ++m) acc += (double)cur[(size_t)o * RC + m] * (double)wop.data[(size_t)m * RC + kk];
+                    mmat[(size_t)o * RC + kk] = (float)(rs * acc);
+                    nmat[(size_t)o * RC + kk] = (float)(rs * (double)cur[(size_t)o * RC + kk]);
+                }
+                double cb = 0.0;
+                for (int m = 0; m < RC; ++m) cb += (double)cur[(size_t)o * RC + m] * (double)bop.data[m];
+                blob[st->o_cvec + (size_t)l * GC + o] = (float)(rs * cb);
+            }
+        }
         const size_t rowsz = (size_t)4 * RT * 4;                   // one row image: 4 chunks x 512 threads x 4 floats
-        put_row8(blob, st->o_w2 + ((size_t)l * 4 + 0) * rowsz, cur.data(), 0, 0);      // tanh row of channel 2og
-        put_row8(blob, st->o_w2 + ((size_t)l * 4 + 1) * rowsz, cur.data(), RC, 0);     // sigmoid row of channel 2og
-        put_row8(blob, st->o_w2 + ((size_t)l * 4 + 2) * rowsz, cur.data(), 0, 1);      // tanh row of channel 2og + 1
-        put_row8(blob, st->o_w2 + ((size_t)l * 4 + 3) * rowsz, cur.data(), RC, 1);     // sigmoid row of channel 2og + 1
+        for (int row = 0; row < 4; ++row) {                        // rows: tanh c0, sigmoid c0, tanh c1, sigmoid c1  (c0 = 2og, c1 = 2og + 1)
+            put_row8(blob, st->o_w2 + ((size_t)l * 4 + row) * rowsz, mmat.data(), (row & 1) ? RC : 0, row >> 1);
+            if (l > 0) put_row8(blob, st->o_wn + ((size_t)l * 4 + row) * rowsz, nmat.data(), (row & 1) ? RC : 0, row >> 1);
+        }
         const HostTensor& wo = T(pfx + "conv1x1_out.weight");          // (R, G/2, 1)
         put_row8(blob, st->o_wo + ((size_t)l * 2 + 0) * rowsz, wo.data.data(), 0, 0);
         put_row8(blob, st->o_wo + ((size_t)l * 2 + 1) * rowsz, wo.data.data(), 0, 1);
@@ -696,15 +832,16 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.skip_scale = (float)std::sqrt(1.0 / st->L);
     { const char* e = getenv("WNV_RING_FAST"); p.allow_fast = !(e && e[0] == '0'); }
     const float* w = st->d_w;
-    p.w2img = w + st->o_w2; p.woimg = w + st->o_wo; p.bo = w + st->o_bo; p.wpre = w + st->o_wpre;
+    p.w2img = w + st->o_w2; p.wnimg = w + st->o_wn; p.cvec = w + st->o_cvec; p.woimg = w + st->o_wo; p.bo = w + st->o_bo; p.wpre = w + st->o_wpre;
     p.wsimg = w + st->o_ws; p.bskip = w + st->o_bskip; p.wh1img = w + st->o_wh1; p.bh1 = w + st->o_bh1;
     p.wh2img = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf;
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
-    // state: [status 64 B][placement table 4 KiB][hmail B*(S+1)*128 u64][smail B*(S+1)*Kp u64][hist B*hist_floats f32]
-    const size_t head_bytes = 64 + 4096;
+    // state: [status 64 B][placement table 4 KiB][xmail B*(S+1)*128 u64][hmail B*2*(S+1)*128 u64][smail B*(S+1)*Kp u64]
+    //        [hist B*hist_floats f32]
+    const size_t head_bytes = 64 + 4096 + 1024;                    // status, placement table, parameter-block copy
     const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
-    const size_t mail_bytes = (n_h + n_s) * sizeof(u64);
+    const size_t mail_bytes = (3 * n_h + n_s) * sizeof(u64);
     const size_t hist_bytes = (size_t)B * st->hist_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -730,13 +867,14 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     st->tag_next += (unsigned)ga.T + 1u;
     p.status = (unsigned int*)base;
     p.xcc = (unsigned int*)(base + 64);
-    p.hmail = (u64*)(base + head_bytes);
-    p.smail = p.hmail + n_h;
+    p.xmail = (u64*)(base + head_bytes);
+    p.hmail = p.xmail + n_h;
+    p.smail = p.hmail + 2 * n_h;
     p.hist = (float*)(p.smail + n_s);
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.out = ga.out; p.params_out = ga.params_out;
     // LDS: the stage carve is the larger one
-    const size_t lds = ((size_t)16 * ES + 512 + (size_t)RW * p.pstride + (size_t)upr * GC + 16) * sizeof(float);
+    const size_t lds = stage_lds_floats(p.pstride, upr) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS for this many utterances per ring"; return WNV_ERR_UNSUPPORTED; }
     RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int grid = rstride * (st->S + 1);
@@ -752,6 +890,9 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         RING_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
     }
+    static_assert(sizeof(RingParams) <= 1024, "parameter-block copy area");
+    p.self = reinterpret_cast<const RingParams*>(base + 64 + 4096);
+    RING_HIP(hipMemcpyAsync(base + 64 + 4096, &p, sizeof p, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(wnv_ring_kernel, dim3(grid), dim3(RT), lds, stream, p);
     RING_HIP(hipGetLastError());
     // the ring path is synchronous: a bounded spin that gave up must be reported to the caller
