@@ -71,6 +71,9 @@ struct RingParams {
     long long zbias_bstride;
     const int *lay_dil, *lay_histoff;
     unsigned long long *xmail, *hmail, *smail;   // chain inputs X[b][S+1][128]; layer inputs H[b][2 (t parity)][S+1][128]; skip sums
+    float *fmail, *pmail;                        // bulk records: stage -> tap workgroup h_l[t]: F[b][L][4 + 128]; tap workgroup -> stage pre_l[t+1]: P[b][L][4 + 256]
+    int ring_blocks;                             // blocks [0, ring_blocks) = rings, [ring_blocks, ring_blocks + L) = tap workgroups
+    int kper, kreg_rows, klds_rows;              // tap workgroup: K rows per wave; of those resident in VGPRs / in LDS (the rest streams)
     unsigned int* xcc;                 // [grid] XCC id + 1 of every workgroup (placement handshake)
     float* hist;
     const float *c_up, *initial, *teacher, *noise;
@@ -104,6 +107,39 @@ __device__ __forceinline__ u64 ld_issue(const u64* p) {
     return v;
 }
 __device__ __forceinline__ void ld_redeem(u64& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+
+// BULK hand-off for the traffic nobody waits for (stage <-> tap workgroup, any XCD): raw floats in 16-B write-through
+// stores, the producer drains them (vmcnt(0)) and then publishes ONE tag granule; the consumer polls that granule from a
+// single lane at a relaxed cadence and reads the payload with L1-bypassing loads.  A quarter of the fabric writes of the
+// per-value granules and one polled word instead of hundreds (MI355X_MICROARCH.md: handoff-flag, "16-B sc1 stores and
+// sc1 loads").  Layout of one record: [flag granule, pad to 16 B][payload floats].
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void bulk_store16(float* dst, float4 v) {
+    const f4v x = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(x) : "memory");
+}
+__device__ __forceinline__ float4 bulk_load16(const float* src) {
+    f4v x;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(src) : "memory");
+    return make_float4(x.x, x.y, x.z, x.w);
+}
+__device__ __forceinline__ void bulk_publish(u64* flag, unsigned tag, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's payload stores have left the CU
+    if (lane == 0) st_granule(flag, tag, 0.f, false);
+}
+// one wave; returns false on abort / timeout
+__device__ __forceinline__ bool bulk_wait(const u64* flag, unsigned tag, unsigned int* status, unsigned code, int lane) {
+    unsigned spins = 0;
+    for (;;) {
+        const u64 x = ld_granule(flag);                            // every lane the same word: one request
+        if ((unsigned)(x >> 32) == tag) return true;
+        if ((++spins & 63u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > (SPIN_LIMIT >> 3)) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
 
 // One wave waits until the granule of every ACTIVE lane carries `tag`; returns false on abort/timeout.
 template <bool SLEEP>
@@ -261,57 +297,183 @@ __device__ __forceinline__ int eidx(int i) { return ES * (i >> 4) + (i & 15); }
 struct StageLds {
     float* hx;       // chain input X[l][t]  (u of the layer before, or h_0 at stage 0), eight padded K-slices
     float* hb;       // h_{l-1}[t]: input of the off-chain mat-vec N_l . h_{l-1}
-    float* hh;       // h_l[t]: residual input of conv1x1_out and the row pushed into the history ring
     float* us;       // gate output u_l[t]
-    float* xin;      // [512] deferred mat-vec input
-    float* part;     // [8][pstride]
-    float* pre;      // [upr][256] next step's tap/conditioning pre-activations
+    float* hh;       // h_l[t], collected for the tap workgroup
+    float* pre;      // [256] pre_l[t] from the layer's tap workgroup
     int* flags;
     float4* wsk;     // [2 rows][4 chunks][512 threads] image of conv1x1_skip (64 KiB; off the chain)
 };
 
-__device__ __forceinline__ StageLds carve_stage(float* smem, const RingParams& p) {
+__device__ __forceinline__ StageLds carve_stage(float* smem) {
     StageLds s;
     s.hx = smem;
     s.hb = smem + 8 * ES;
-    s.hh = smem + 16 * ES;
-    s.us = smem + 24 * ES;
-    s.xin = smem + 32 * ES;             // 640
-    s.part = s.xin + 512;
-    s.pre = s.part + (size_t)RW * p.pstride;
-    s.flags = reinterpret_cast<int*>(s.pre + (size_t)p.upr * GC);
+    s.us = smem + 16 * ES;
+    s.hh = smem + 24 * ES;
+    s.pre = smem + 32 * ES;
+    s.flags = reinterpret_cast<int*>(s.pre + GC);
     s.wsk = reinterpret_cast<float4*>(s.flags + 16);
     return s;
 }
-__host__ __device__ constexpr size_t stage_lds_floats(int pstride, int upr) {
-    return (size_t)32 * ES + 512 + (size_t)RW * pstride + (size_t)upr * GC + 16 + (size_t)8 * RT * 4;
+constexpr size_t STAGE_LDS_FLOATS = (size_t)32 * ES + GC + 16 + (size_t)8 * RT * 4;
+
+// ---- tap workgroup (one per layer, shared by all rings) -----------------------------------------------------------------
+// Everything of a layer that is known a step ahead -- the dilated conv's older taps and the local-conditioning 1x1,
+//   pre_l[t+1] = b_l (+ W_g g) + c_l + sum_{k<kw-1} W_l[:, :, k] h_l[t+1 - (kw-1-k) d] + W_c,l c[t+1]        (conv.py:33-45)
+// -- is computed here for EVERY utterance, with the [kw-1 taps + cin][256] matrix resident on this CU (VGPRs first, then
+// LDS; only what fits neither streams from L2).  The stages forward h_l[t] (one write-through granule per value) and get
+// pre_l[t+1] back the same way; both trips have a whole step of slack.  The workgroup also owns the history rings.
+constexpr int KR_MAX = 32;         // K rows per wave held in VGPRs (32 float4 = 128 registers)
+constexpr int KL_MAX = 16;         // further K rows per wave held in LDS
+constexpr int TB = 8;              // utterances per pass (one polling wave each; their latencies overlap)
+struct TapLds {
+    float* xin;      // [TB][8 * kper] mat-vec inputs: tap rows then conditioning row, zero padded
+    float* part;     // [4][8][256] per-wave partial sums of four utterances
+    int* flags;
+    float4* wl;      // [8 waves][klds_rows][64 lanes] LDS-resident rows
+};
+__device__ __forceinline__ TapLds carve_tap(float* smem, const RingParams& p) {
+    TapLds s;
+    s.xin = smem;
+    s.part = smem + (size_t)TB * RW * p.kper;
+    s.flags = reinterpret_cast<int*>(s.part + (size_t)4 * RW * GC);
+    s.wl = reinterpret_cast<float4*>(s.flags + 16);
+    return s;
+}
+__host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
+    return (size_t)TB * RW * kper + (size_t)4 * RW * GC + 16 + (size_t)RW * klds_rows * 64 * 4;
 }
 
-// Deferred: pre-activation of layer l for step tp (>= 0) of utterance b, from the history ring and c[tp]:
-//   pre[n] = b_in[n] (+ Wg.g) + sum_{k<kw-1} W[:, :, k] . h_l[tp - (kw-1-k)*d] + W_c . c[tp]       (conv.py:33-45)
-// When t_prev >= 0 the layer input of step t_prev (= tp - 1) is first pushed into the ring.
-__device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds& s, int b, int j, int l,
-                                             int t_prev, int tp, int tid, int wave, int lane) {
+__device__ void run_tap(const RingParams& p, int l, float* smem) {
+    const TapLds s = carve_tap(smem, p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = p.lay_dil[l];
     const int rows = (p.kw - 1) * d;
-    float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
     const int hoff = (p.kw - 1) * RC;
-    if (rows > 0) {
-        if (t_prev >= 0 && tid < RC) hist[(size_t)(t_prev % rows) * RC + tid] = s.hh[eidx(tid)];
-        __syncthreads();
-        for (int idx = tid; idx < hoff; idx += RT) {
-            const int k = idx / RC, r = idx - k * RC;
-            s.xin[idx] = hist[(size_t)((tp + k * d) % rows) * RC + r];
+    const int kx = RW * p.kper;                                    // padded K
+    const int k0 = wave * p.kper;                                  // this wave's K rows: [k0, k0 + kper) of the padded matrix
+    const float* Wt = p.wpre + (size_t)l * p.kpre * GC;           // K-major [kpre][256]
+    // resident rows: lane owns outputs 4 lane .. 4 lane + 3 of every row
+    float4 wreg[KR_MAX];
+#pragma unroll
+    for (int r = 0; r < KR_MAX; ++r) {
+        const int k = k0 + r;
+        wreg[r] = (r < p.kreg_rows && k < p.kpre) ? *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + lane * 4)
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int r = 0; r < p.klds_rows; ++r) {
+        const int k = k0 + p.kreg_rows + r;
+        s.wl[((size_t)wave * p.klds_rows + r) * 64 + lane] =
+            k < p.kpre ? *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int i = tid; i < TB * kx; i += RT) s.xin[i] = 0.f;
+    if (tid == 0) s.flags[0] = 0;
+    __syncthreads();
+    const int kres = p.kreg_rows + p.klds_rows;                    // rows of this wave that never touch memory again
+
+    for (int t = -1; t + 1 < p.T; ++t) {                           // consumes h_l[t] (t >= 0), produces pre_l[t + 1]
+        const int tp = t + 1;
+        for (int b0 = 0; b0 < p.B; b0 += TB) {
+            const int nb = min(TB, p.B - b0);
+            // ---- h_l[t] of utterances b0 .. b0+nb-1, forwarded by their stages: wave w takes utterance b0 + w, two granules
+            //      per lane (one 16-B load), and files the row in the history ring ------------------------------------------
+            if (t >= 0 && wave < nb) {
+                const int b = b0 + wave;
+                const float* rec = p.fmail + ((size_t)b * p.L + l) * (4 + RC);
+                if (!bulk_wait(reinterpret_cast<const u64*>(rec), p.tag_base + (unsigned)t + 1u, p.status, 0x600u + (unsigned)l, lane))
+                    s.flags[0] = 1;
+                if (lane < RC / 4 && rows > 0) {
+                    const float4 v = bulk_load16(rec + 4 + 4 * lane);
+                    float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
+                    *reinterpret_cast<float4*>(hist + (size_t)(t % rows) * RC + 4 * lane) = v;
+                }
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+            // ---- gather: the kw-1 older taps of step tp (zeros before t = 0: the rings start zeroed) and c[tp] ------------
+            for (int idx = tid; idx < nb * (hoff + p.cin); idx += RT) {
+                const int u = idx / (hoff + p.cin), e = idx - u * (hoff + p.cin);
+                const int b = b0 + u;
+                float v;
+                if (e < hoff) {
+                    const int k = e / RC, r = e - k * RC;
+                    v = p.hist[(size_t)b * p.hist_floats + p.lay_histoff[l] + (size_t)((tp + k * d) % rows) * RC + r];
+                } else {
+                    v = p.c_up[((size_t)b * p.T + tp) * p.cin + (e - hoff)];
+                }
+                s.xin[(size_t)u * kx + e] = v;
+            }
+            __syncthreads();
+            // ---- mat-vec for all utterances of the pass, four at a time (accumulators + weights must fit the register file):
+            //      VGPR rows, then LDS rows, then whatever streams -----------------------------------------------------------
+#pragma unroll 1
+            for (int u0 = 0; u0 < nb; u0 += 4) {
+                float4 acc[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float* xb = s.xin + (size_t)u0 * kx + k0;
+#pragma unroll
+                for (int r4 = 0; r4 < KR_MAX / 4; ++r4) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)u * kx + 4 * r4);
+                        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float4 w = wreg[4 * r4 + e];
+                            acc[u].x = fmaf(w.x, xs[e], acc[u].x); acc[u].y = fmaf(w.y, xs[e], acc[u].y);
+                            acc[u].z = fmaf(w.z, xs[e], acc[u].z); acc[u].w = fmaf(w.w, xs[e], acc[u].w);
+                        }
+                    }
+                }
+                for (int r = 0; r < p.klds_rows; ++r) {
+                    const float4 w = s.wl[((size_t)wave * p.klds_rows + r) * 64 + lane];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float xs = xb[(size_t)u * kx + p.kreg_rows + r];
+                        acc[u].x = fmaf(w.x, xs, acc[u].x); acc[u].y = fmaf(w.y, xs, acc[u].y);
+                        acc[u].z = fmaf(w.z, xs, acc[u].z); acc[u].w = fmaf(w.w, xs, acc[u].w);
+                    }
+                }
+                for (int k = k0 + kres; k < k0 + p.kper && k < p.kpre; ++k) {
+                    const float4 w = *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + lane * 4);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float xs = xb[(size_t)u * kx + k - k0];
+                        acc[u].x = fmaf(w.x, xs, acc[u].x); acc[u].y = fmaf(w.y, xs, acc[u].y);
+                        acc[u].z = fmaf(w.z, xs, acc[u].z); acc[u].w = fmaf(w.w, xs, acc[u].w);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    *reinterpret_cast<float4*>(s.part + ((size_t)u * RW + wave) * GC + lane * 4) = acc[u];
+                __syncthreads();
+                // reduce over the waves and hand pre_l[tp] to the stages: thread (u, n4) finishes four adjacent outputs of
+                // utterance u0 + u -- waves 0-1 serve u = 0, waves 2-3 u = 1, ... -- and the first wave of each pair publishes
+                {
+                    const int u = tid >> 6 >> 1, n4 = tid & 127;                // 128 threads x 4 outputs per utterance
+                    const bool live = u0 + u < nb && n4 < GC / 4;
+                    const int b = b0 + u0 + u;
+                    float* rec = p.pmail + ((size_t)b * p.L + l) * (4 + GC);
+                    if (live) {
+                        const float4 zb = *reinterpret_cast<const float4*>(p.zbias + (size_t)b * p.zbias_bstride + (size_t)l * GC + 4 * n4);
+                        const float4 cv = *reinterpret_cast<const float4*>(p.cvec + (size_t)l * GC + 4 * n4);
+                        float4 v = make_float4(zb.x + cv.x, zb.y + cv.y, zb.z + cv.z, zb.w + cv.w);
+#pragma unroll
+                        for (int w = 0; w < RW; ++w) {
+                            const float4 q = *reinterpret_cast<const float4*>(s.part + ((size_t)u * RW + w) * GC + 4 * n4);
+                            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                        }
+                        if (n4 < GC / 4) bulk_store16(rec + 4 + 4 * n4, v);
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __syncthreads();                                             // both waves of the pair have drained their stores
+                    if (live && (tid & 127) == 0) st_granule(reinterpret_cast<u64*>(rec), p.tag_base + (unsigned)tp + 1u, 0.f, false);
+                }
+                __syncthreads();
+            }
         }
     }
-    for (int c = tid; c < p.cin; c += RT) s.xin[hoff + c] = p.c_up[((size_t)b * p.T + tp) * p.cin + c];
-    float zb = 0.f;
-    if (tid < GC) zb = p.zbias[(size_t)b * p.zbias_bstride + (size_t)l * GC + tid] + p.cvec[(size_t)l * GC + tid];
-    __syncthreads();
-    matvec_partial_small<RW>(p.wpre + (size_t)l * p.kpre * GC, p.kpre, GC, s.xin, s.part, p.pstride, wave, lane);
-    __syncthreads();
-    if (tid < GC) s.pre[(size_t)j * GC + tid] = reduce_part<RW>(s.part, p.pstride, tid, zb);
-    __syncthreads();
 }
 
 // One stage = one gated layer on one CU, weights resident in VGPRs.
@@ -331,7 +493,7 @@ __device__ __forceinline__ void deferred_pre(const RingParams& p, const StageLds
 // channels 2og and 2og + 1; reductions are reduce-scatters (first DPP step row_half_mirror, lane j <-> 7 - j, hands
 // lanes 0-3 the sums of channel 2og and lanes 4-7 those of 2og + 1; two quad_perm steps finish).
 __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
-    const StageLds s = carve_stage(smem, p);
+    const StageLds s = carve_stage(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ks = tid & 7, og = tid >> 3;                      // K-slice; lane group = channels 2og, 2og + 1
     const bool hi = ks >= 4;                                    // lanes 4-7 finish channel 2og + 1, lanes 0-3 channel 2og
@@ -363,12 +525,6 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     const int rd1 = ring + (sidx + 1) * p.rstride, rd2 = ring + (sidx + 2 <= p.S ? sidx + 2 : sidx + 1) * p.rstride;
     const bool fast = same_xcd_as(p, rd1, rd2, s.flags + 1);
 
-    // ---- prologue: pre-activations of step 0 (all taps are zero history) ------------------------------------
-    for (int j = 0; j < p.upr; ++j) {
-        const int b = ring + j * p.n_rings;
-        if (b < p.B) deferred_pre(p, s, b, j, l, -1, 0, tid, wave, lane);
-    }
-
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
         const int par = t & 1;
@@ -384,15 +540,18 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             const u64* sm_in = p.smail + ((size_t)b * S1 + sidx) * p.Kp + ch;
             u64* sm_out = p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + ch;
             asm volatile("" : "+v"(x_in), "+v"(h_in), "+v"(h_out), "+v"(sm_in), "+v"(sm_out));
-            // ---- ahead of the chain: zin = N_l h_{l-1}[t] + pre_l[t]  (h_{l-1} arrives a layer time before u_{l-1}) ------
-            float zin_a, zin_g;
-            {
-                const float* pre = s.pre + (size_t)j * GC;
-                zin_a = pre[ch]; zin_g = pre[RC + ch];
+            // ---- ahead of the chain: zin = N_l h_{l-1}[t] + pre_l[t]  (h_{l-1} arrives a layer time before u_{l-1}; pre_l[t]
+            //      comes from the layer's tap workgroup and has been on its way since the previous step) ----------------
+            //      ONE wave waits for it, at a relaxed cadence: the stage is idle here for most of a step, and hundreds of
+            //      waves polling write-through lines would load the fabric that the chain's hops share.
+            float zin_a = 0.f, zin_g = 0.f;
+            if (wave == 0) {
+                const float* rec = p.pmail + ((size_t)b * p.L + l) * (4 + GC);
+                if (!bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                *reinterpret_cast<float4*>(s.pre + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
             }
-#ifdef WNV_FINE_TRACE
-            stamp(p, b, t, sidx, 5);
-#endif
+            __syncthreads();
+            zin_a = s.pre[ch]; zin_g = s.pre[RC + ch];
             if (!first_stage) {
                 if (wave < 2) {
                     // h_0 is the chain input of stage 0; h_{l-1} for l >= 2 comes from stage l-2's conv1x1_out
@@ -480,7 +639,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 if (writer) {
                     if (!last_stage && ok)
                         st_granule(h_out, tag, (o + h) * 0.70710678118654752440f, fast);
-                    s.hh[eidx(ch)] = h;                                          // the row the history ring gets
+                    s.hh[eidx(ch)] = h;                 // forwarded to the layer's tap workgroup at the end of the step
                 }
                 if (!ok) s.flags[0] = 1;
             }
@@ -498,9 +657,16 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             }
             stamp(p, b, t, sidx, 3);
             // ---- history push + next step's pre-activations (its barriers fence the LDS vectors for the next step) -------
-            __syncthreads();                        // h_l[t] complete in LDS (written by the lanes that received it)
-            if (t + 1 < p.T) deferred_pre(reread(p), s, b, j, l, t, t + 1, tid, wave, lane);
+            __syncthreads();                        // fences the LDS vectors against the next step; makes flags[0] uniform
             if (s.flags[0]) return;                 // a bounded wait gave up somewhere: drain (status holds the code)
+            if (wave == 0) {                        // h_l[t] to the layer's tap workgroup (history ring, older taps): bulk record
+                float* rec = p.fmail + ((size_t)b * p.L + l) * (4 + RC);
+                if (lane < RC / 4) {
+                    const float* src = s.hh + ES * (lane >> 2) + 4 * (lane & 3);     // channels 4 lane .. 4 lane + 3
+                    bulk_store16(rec + 4 + 4 * lane, *reinterpret_cast<const float4*>(src));
+                }
+                bulk_publish(reinterpret_cast<u64*>(rec), tag, lane);
+            }
             stamp(p, b, t, sidx, 4);
         }
     }
@@ -617,6 +783,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
 __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // block i -> XCD i % 8 (observed, speed only): with rstride == 8 every workgroup of ring r sits on XCD r
+    if ((int)blockIdx.x >= p.ring_blocks) { run_tap(p, (int)blockIdx.x - p.ring_blocks, smem); return; }
     const int ring = blockIdx.x % p.rstride;
     const int pos = blockIdx.x / p.rstride;
     if (ring >= p.n_rings) return;
@@ -818,11 +985,11 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     int ncu = 0;
     RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, st->device));
     // one workgroup per CU, one ring per utterance slot; at most 8 rings (one per XCD) and never more than fit
-    const int n_rings = std::max(1, std::min(std::min(B, 8), ncu / (st->S + 1)));
+    const int n_rings = std::max(1, std::min(std::min(B, 8), (ncu - st->L) / (st->S + 1)));
     const int upr = (B + n_rings - 1) / n_rings;
     // block b lands on XCD b % 8 (observed): a ring stride of 8 keeps every workgroup of a ring on one XCD, which the
     // kernel verifies at run time before it uses the same-XCD hand-off; surplus workgroups exit at once
-    const int rstride = 8 * (st->S + 1) <= ncu ? 8 : n_rings;
+    const int rstride = 8 * (st->S + 1) + st->L <= ncu ? 8 : n_rings;
     RingParams p{};
     p.n_rings = n_rings; p.rstride = rstride; p.S = st->S; p.L = st->L; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.upr = upr;
     p.K = st->K; p.Kp = st->Kp; p.O = st->O; p.cin = st->cin; p.kw = st->kw; p.kpre = st->kpre; p.nz = ga.nz;
@@ -841,7 +1008,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     //        [hist B*hist_floats f32]
     const size_t head_bytes = 64 + 4096 + 1024;                    // status, placement table, parameter-block copy
     const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
-    const size_t mail_bytes = (3 * n_h + n_s) * sizeof(u64);
+    const size_t n_f = (size_t)B * st->L * (4 + RC), n_p = (size_t)B * st->L * (4 + GC);   // stage <-> tap-workgroup bulk records (floats)
+    const size_t mail_bytes = (3 * n_h + n_s) * sizeof(u64) + (n_f + n_p) * sizeof(float);
     const size_t hist_bytes = (size_t)B * st->hist_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -870,15 +1038,23 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.xmail = (u64*)(base + head_bytes);
     p.hmail = p.xmail + n_h;
     p.smail = p.hmail + 2 * n_h;
-    p.hist = (float*)(p.smail + n_s);
+    p.fmail = (float*)(p.smail + n_s);
+    p.pmail = p.fmail + n_f;
+    p.hist = p.pmail + n_p;
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.out = ga.out; p.params_out = ga.params_out;
     // LDS: the stage carve is the larger one
-    const size_t lds = stage_lds_floats(p.pstride, upr) * sizeof(float);
-    if (lds > 160 * 1024) { err = "ring kernel needs too much LDS for this many utterances per ring"; return WNV_ERR_UNSUPPORTED; }
+    // tap workgroups: K rows per wave (a multiple of 4), first in VGPRs, then in LDS, the remainder streams from L2
+    p.kper = (((st->kpre + RW - 1) / RW) + 3) & ~3;
+    p.kreg_rows = std::min(p.kper, KR_MAX);
+    p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);
+    while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 150 * 1024) --p.klds_rows;
+    p.ring_blocks = rstride * (st->S + 1);
+    const size_t lds = std::max(STAGE_LDS_FLOATS, tap_lds_floats(p.kper, p.klds_rows)) * sizeof(float);
+    if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
     RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = rstride * (st->S + 1);
-    if (grid > ncu || grid > 1024) { err = "ring kernel needs one CU per workgroup"; return WNV_ERR_UNSUPPORTED; }
+    const int grid = p.ring_blocks + st->L;
+    if (grid > ncu || grid > 1024) { err = "ring kernel needs one CU per workgroup (rings + one tap workgroup per layer)"; return WNV_ERR_UNSUPPORTED; }
     // optional timeline (WNV_RING_TRACE=<file>): wall-clock stamps of utterance 0 for 8 steps in mid-run
     const char* trace_path = getenv("WNV_RING_TRACE");
     unsigned long long* d_trace = nullptr;
