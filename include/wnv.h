@@ -183,6 +183,26 @@ wnv_status wnv_glu_step(wnv_glu_handle g, const float* x, const float* c, const 
 wnv_status wnv_glu_reset(wnv_glu_handle g);              /* modules.py:165-169 clear_buffer */
 wnv_status wnv_glu_destroy(wnv_glu_handle g);
 
+/* ---- post-chain ------------------------------------------------------------
+ * Replaces the tail of synthesis.batch_wavegen (synthesis.py:66-84) and the clip / int16 conversion of
+ * evaluate.py:238, :43-48 on the device: argmax + inv_mulaw_quantize | inv_mulaw | raw, then the optional
+ * audio.inv_preemphasis (audio.py:57-58), / global_gain_scale, clip, int16.  inv_mulaw* / inv_preemphasis are
+ * nnmnkwii's published definitions (the reference's un-vendored dependency, setup.py:23). */
+typedef struct wnv_post_args {
+    int32_t B, C;              /* y is (B, C, T): C = 1 for scalar input types, quantize_channels for one-hot */
+    int64_t T;
+    const float* y;            /* device: wnv_generate's `out`                                            */
+    int32_t input_type;        /* 0 "raw", 1 "mulaw", 2 "mulaw-quantize"  (hparams.input_type)             */
+    int32_t mu;                /* hparams.quantize_channels - 1 (unused for "raw")                        */
+    float preemphasis;         /* > 0: postprocess = inv_preemphasis with this coefficient; 0: none       */
+    float gain_scale;          /* > 0: divide by hparams.global_gain_scale                                */
+    int32_t clip;              /* np.clip(gen, -1, 1)  (evaluate.py:238)                                  */
+    float* wav;                /* device (B, T) float32                                                   */
+    int16_t* pcm;              /* optional device (B, T): to_int16 (evaluate.py:43-48), needs clip        */
+    void* stream;
+} wnv_post_args;
+wnv_status wnv_postprocess(int32_t device, const wnv_post_args* args);
+
 /* ---- misc --------------------------------------------------------------------------------------- */
 const char* wnv_last_error(void);
 int32_t wnv_abi_version(void);

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-__all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "LIB_PATH",
+__all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "LIB_PATH",
            "WNV_ABI_VERSION", "DIST", "UPSAMPLE"]
 
 WNV_ABI_VERSION = 1
@@ -61,6 +61,14 @@ class GenerateArgs(C.Structure):
     ]
 
 
+class PostArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("C", C.c_int32), ("T", C.c_int64), ("y", C.c_void_p), ("input_type", C.c_int32),
+        ("mu", C.c_int32), ("preemphasis", C.c_float), ("gain_scale", C.c_float), ("clip", C.c_int32),
+        ("wav", C.c_void_p), ("pcm", C.c_void_p), ("stream", C.c_void_p),
+    ]
+
+
 class GluConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("residual_channels", "gate_channels", "kernel_size",
                                          "skip_out_channels", "cin_channels", "gin_channels", "dilation",
@@ -90,6 +98,7 @@ _PROTOS = {
     "wnv_glu_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "wnv_glu_reset": (C.c_int, [C.c_void_p]),
     "wnv_glu_destroy": (C.c_int, [C.c_void_p]),
+    "wnv_postprocess": (C.c_int, [C.c_int32, C.POINTER(PostArgs)]),
     "wnv_bytes_per_step": (C.c_int64, [C.c_void_p, C.c_int32]),
     "wnv_macs_per_sample": (C.c_int64, [C.c_void_p]),
 }
