@@ -141,3 +141,39 @@ def test_unsupported_configs_say_so():
     eng = m._get_engine()
     with pytest.raises(NotImplementedError, match="ring kernel"):
         eng.generate(B=1, T=16, kernel=2)
+
+
+def test_ring_slow_path_is_bit_identical(monkeypatch):
+    """WNV_RING_FAST=0 forces the placement-independent write-through hand-offs; same arithmetic, same bits."""
+    name = "cfg2_mol"
+    kw = CONFIGS[name]
+    B, T = 3, 384
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    c, _ = inputs(name, B, T)
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    tape = tape_for(kw, T, B, 5).cuda()
+    fast, pf, _ = run(eng, 2, B, T, c_up, None, tape)
+    monkeypatch.setenv("WNV_RING_FAST", "0")
+    slow, ps, _ = run(eng, 2, B, T, c_up, None, tape)
+    assert torch.equal(fast, slow) and torch.equal(pf, ps)
+
+
+def test_ring_back_to_back_launches_with_changing_shapes():
+    """Mailbox tags are unique across launches (no re-zeroing): alternate B and T and compare with fresh engines."""
+    name = "cfg2_mol"
+    kw = CONFIGS[name]
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    outs = []
+    for B, T in [(8, 300), (2, 700), (8, 300), (5, 129)]:
+        c, _ = inputs(name, B, T)
+        c_up = eng.upsample(c.cuda(), T_expected=T)
+        tape = tape_for(kw, T, B, 11).cuda()
+        outs.append(run(eng, 2, B, T, c_up, None, tape)[0])
+    assert torch.equal(outs[0], outs[2])
+    m2 = build(name).to("cuda")
+    eng2 = m2._get_engine()
+    c, _ = inputs(name, 5, 129)
+    ref = run(eng2, 2, 5, 129, eng2.upsample(c.cuda(), T_expected=129), None, tape_for(kw, 129, 5, 11).cuda())[0]
+    assert torch.equal(outs[3], ref)

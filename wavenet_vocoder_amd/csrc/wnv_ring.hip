@@ -622,7 +622,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             float xu[16];
             lds_read16(s.us + ES * ks, xu);
             // conv1x1_out -> residual -> publish h_{l+1}[t]  (modules.py:157-162: the reference's own recurrence)
-            {
+            auto h_phase = [&]() {
                 float o = 0.f;
                 if (!last_stage) {                  // the last layer's residual output is never used (wavenet.py:310-313)
                     const float o0 = dot16p(wo[0], xu), o1 = dot16p(wo[1], xu);
@@ -642,10 +642,9 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                     s.hh[eidx(ch)] = h;                 // forwarded to the layer's tap workgroup at the end of the step
                 }
                 if (!ok) s.flags[0] = 1;
-            }
-            stamp(p, b, t, sidx, 2);
-            // ---- skip 1x1, accumulated stage to stage in the reference's layer order (wavenet.py:312) --------------------
-            {
+            };
+            // skip 1x1, accumulated stage to stage in the reference's layer order (wavenet.py:312)
+            auto skip_phase = [&]() {
                 const float m0 = dot16l(s.wsk + (size_t)0 * RT + tid, xu), m1 = dot16l(s.wsk + (size_t)4 * RT + tid, xu);
                 const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + bs_r;
                 float acc = 0.f;
@@ -654,8 +653,11 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                     ok = wave_recv<false>(sm_in, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
                 if (writer && ok) st_granule(sm_out, tag, acc + mine, fast);
                 if (!ok) s.flags[0] = 1;
-            }
-            stamp(p, b, t, sidx, 3);
+            };
+            // the h recurrence is what the next-but-one stage waits for; only at the last stage the skip sum (the head's
+            // input) is the urgent one
+            if (last_stage) { skip_phase(); stamp(p, b, t, sidx, 3); h_phase(); stamp(p, b, t, sidx, 2); }
+            else { h_phase(); stamp(p, b, t, sidx, 2); skip_phase(); stamp(p, b, t, sidx, 3); }
             // ---- history push + next step's pre-activations (its barriers fence the LDS vectors for the next step) -------
             __syncthreads();                        // fences the LDS vectors against the next step; makes flags[0] uniform
             if (s.flags[0]) return;                 // a bounded wait gave up somewhere: drain (status holds the code)
