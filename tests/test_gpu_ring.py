@@ -147,7 +147,7 @@ def test_ring_slow_path_is_bit_identical(monkeypatch):
     """WNV_RING_FAST=0 forces the placement-independent write-through hand-offs; same arithmetic, same bits."""
     name = "cfg2_mol"
     kw = CONFIGS[name]
-    B, T = 3, 384
+    B, T = 3, 512
     m = build(name).to("cuda")
     eng = m._get_engine()
     c, _ = inputs(name, B, T)
@@ -166,14 +166,13 @@ def test_ring_back_to_back_launches_with_changing_shapes():
     m = build(name).to("cuda")
     eng = m._get_engine()
     outs = []
+
+    def cond(B, T):          # conditioning at sample rate, any T (the upsampler is not what is tested here)
+        return torch.randn(B, T, 80, generator=torch.Generator().manual_seed(100 * B + T)).cuda()
+
     for B, T in [(8, 300), (2, 700), (8, 300), (5, 129)]:
-        c, _ = inputs(name, B, T)
-        c_up = eng.upsample(c.cuda(), T_expected=T)
-        tape = tape_for(kw, T, B, 11).cuda()
-        outs.append(run(eng, 2, B, T, c_up, None, tape)[0])
+        outs.append(run(eng, 2, B, T, cond(B, T), None, tape_for(kw, T, B, 11).cuda())[0])
     assert torch.equal(outs[0], outs[2])
-    m2 = build(name).to("cuda")
-    eng2 = m2._get_engine()
-    c, _ = inputs(name, 5, 129)
-    ref = run(eng2, 2, 5, 129, eng2.upsample(c.cuda(), T_expected=129), None, tape_for(kw, 129, 5, 11).cuda())[0]
+    eng2 = build(name).to("cuda")._get_engine()
+    ref = run(eng2, 2, 5, 129, cond(5, 129), None, tape_for(kw, 129, 5, 11).cuda())[0]
     assert torch.equal(outs[3], ref)
