@@ -1,35 +1,35 @@
 // wnv_ring.hip -- the pipelined, weight-stationary sample-loop kernel for gfx950 ("ring" kernel).
 //
-// WHY.  One autoregressive step is a chain of L gated layers; for 8 utterances the per-step cost is the latency
-// of that chain, not bandwidth or FLOPs.  A single CU cannot hold the 4.6 MB of weights
-// on the chain (W_cur = the newest conv tap, 128->256, and conv1x1_out, 128->128, per layer), and streaming them
-// every step costs more than the chain itself.  So every utterance (or small group) gets a RING of persistent
-// workgroups, one per CU, each owning ONE layer with all of its chain weights resident in registers:
+// WHY.  One autoregressive step is a chain of L gated layers; for 8 utterances the per-step cost is the latency of
+// that chain, not bandwidth or FLOPs.  No CU can hold the model and streaming the weights every
+// step costs more than the chain itself, so the model is spread over the chip and stays there: every utterance slot
+// gets a RING of persistent workgroups, one per CU, each owning ONE layer,
 //
-//     head -> stage 0 (layer 0) -> stage 1 (layer 1) -> ... -> stage L-1 -> head -> ...
+//     head -> stage 0 (layer 0) -> stage 1 (layer 1) -> ... -> stage L-1 -> head -> ...      (8 rings, ring r on XCD r)
 //
-// (Measured on MI355X: a CU->CU hop through L2 costs ~0.6 us and a layer ~0.7 us; two layers per stage would
-// halve the hops but needs 192 pinned VGPRs + transients, which hipcc spills -- the reloads cost more than the hop.)
+// plus one TAP workgroup per layer that serves all rings.  One launch runs all T steps; the only synchronisation is the
+// data flow itself.
 //
-//   * W_cur, conv1x1_out and conv1x1_skip of the layer live in VGPRs (128 floats per thread); the four K-quarters
-//     of an output channel sit in ADJACENT lanes, so every reduction is two DPP quad-permute adds (no LDS
-//     shuffles) and the gate uses the hardware exp/rcp;
-//   * the activation vector (128 floats) hops CU -> CU through L2 as 128 data-tagged 8-byte granules
-//     {tag = t+1, value}: ONE write-through (sc1) store per value, the consumer re-reads until every tag
-//     matches -- no flags, no fences, placement-independent (MI355X_MICROARCH.md "handoff-1to1", ~1 us);
-//   * everything that does not sit on the chain is DEFERRED until after the activation has been sent on:
-//     the skip 1x1 (accumulated stage to stage in the reference's layer order through a second granule
-//     mailbox), the history-ring update, and next step's  W_old-taps . h[t+1-k*d] + W_c . c[t+1] + bias, whose
-//     inputs are all known one step early.  Deferred weights are streamed from L2 (K-major rows, 16 B/lane);
-//     a stage has a whole ring trip (~25 us) of slack to do it;
-//   * the head workgroup owns the output MLP (registers), the sampler and first_conv.
+//   * stage (run_stage): gate-to-gate chain -- with M_l = sqrt(.5) W_cur,l W_o,l-1 folded on the host, only
+//     M_l u_{l-1} -> tanh.sigmoid -> send u_l  is on the chain (weights in VGPRs, 8-lane K split, reduce-scatter over
+//     DPP, hardware exp/rcp); conv1x1_out (the h recurrence, evaluated exactly as the reference does), N_l h_{l-1},
+//     the skip 1x1 and the hand-over to the tap workgroup all run behind the send;
+//   * hand-off: the 128-float vector hops CU -> CU as data-tagged 8-byte granules {tag, value}: one store per value,
+//     the consumer re-reads until every tag matches -- no flag, no fence.  Between workgroups that verified at start-up
+//     (HW_REG_XCC_ID exchange) that they share an XCD the stores are plain and stay in that XCD's L2 (~0.45 us per hop
+//     incl. LDS write + barrier, scripts/ubench_hop.hip); otherwise write-through (sc1) stores, placement-independent
+//     (~0.65-0.8 us).  Tags are launch-unique, mailboxes are never re-zeroed;
+//   * tap workgroup (run_tap): the dilated conv's older taps + the local-conditioning 1x1 of its layer for EVERY
+//     utterance, matrix resident in VGPRs + LDS, history rings owned here; bulk records (16-B write-through payload,
+//     drained, one tag granule) carry h_l[t] in and pre_l[t+1] out with a whole step of slack;
+//   * head (run_head): skip sum -> output MLP (registers) -> sampler -> first_conv of the next step.
 //
-// One launch runs all T steps; the only global synchronisation is the data flow itself.  Every wait is bounded:
-// a spin that exceeds its budget writes a code to `status` and every workgroup drains out (WNV_ERR_TIMEOUT).
+// Every wait is bounded: a spin that exceeds its budget writes a code to `status` and every workgroup drains out
+// (WNV_ERR_TIMEOUT).
 //
 // Reference semantics: wavenet.py:296-336 (loop), modules.py:127-163 (layer), conv.py:33-45 (history taps),
-// mixture.py:118-156 / 221-270 (samplers).  Numerics: fp32 throughout; only the association order of the
-// dot products differs from ATen's (covered by the 1e-4 parity tolerance).
+// mixture.py:118-156 / 221-270 (samplers).  Numerics: fp32 throughout; the association order of the dot products and
+// the M/N folding differ from ATen's evaluation order (<= 5e-7 on the head outputs; parity tolerance 1e-4).
 #include "wnv_ring.h"
 
 #ifndef WNV_RING_IS_DEFAULT
