@@ -44,7 +44,7 @@ def test_ring_teacher_forced_vs_oracle(name):
     assert (d < TOL).float().mean().item() > 0.98
 
 
-@pytest.mark.parametrize("B", [1, 2, 5, 8, 11, 16])
+@pytest.mark.parametrize("B", [1, 2, 5, 8, 11, 16, 24, 37])
 def test_ring_equals_generic_kernel(B):
     name = "cfg2_mol"
     kw = CONFIGS[name]

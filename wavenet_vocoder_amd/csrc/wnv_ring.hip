@@ -72,7 +72,7 @@ struct RingParams {
     const int *lay_dil, *lay_histoff;
     unsigned long long *xmail, *hmail, *smail;   // chain inputs X[b][S+1][128]; layer inputs H[b][2 (t parity)][S+1][128]; skip sums
     float *fmail, *pmail;                        // bulk records: stage -> tap workgroup h_l[t]: F[b][L][4 + 128]; tap workgroup -> stage pre_l[t+1]: P[b][L][4 + 256]
-    int ring_blocks;                             // blocks [0, ring_blocks) = rings, [ring_blocks, ring_blocks + L) = tap workgroups
+    int ring_blocks, tap_parts;                  // blocks [0, ring_blocks) = rings, then tap_parts tap workgroups per layer (part q serves passes q, q + parts, ...)
     int kper, kreg_rows, klds_rows;              // tap workgroup: K rows per wave; of those resident in VGPRs / in LDS (the rest streams)
     unsigned int* xcc;                 // [grid] XCC id + 1 of every workgroup (placement handshake)
     float* hist;
@@ -344,7 +344,7 @@ __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
     return (size_t)TB * RW * kper + (size_t)4 * RW * GC + 16 + (size_t)RW * klds_rows * 64 * 4;
 }
 
-__device__ void run_tap(const RingParams& p, int l, float* smem) {
+__device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
     const TapLds s = carve_tap(smem, p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = p.lay_dil[l];
@@ -373,7 +373,7 @@ __device__ void run_tap(const RingParams& p, int l, float* smem) {
 
     for (int t = -1; t + 1 < p.T; ++t) {                           // consumes h_l[t] (t >= 0), produces pre_l[t + 1]
         const int tp = t + 1;
-        for (int b0 = 0; b0 < p.B; b0 += TB) {
+        for (int b0 = part * TB; b0 < p.B; b0 += p.tap_parts * TB) {
             const int nb = min(TB, p.B - b0);
             // ---- h_l[t] of utterances b0 .. b0+nb-1, forwarded by their stages: wave w takes utterance b0 + w, two granules
             //      per lane (one 16-B load), and files the row in the history ring ------------------------------------------
@@ -785,7 +785,11 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
 __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // block i -> XCD i % 8 (observed, speed only): with rstride == 8 every workgroup of ring r sits on XCD r
-    if ((int)blockIdx.x >= p.ring_blocks) { run_tap(p, (int)blockIdx.x - p.ring_blocks, smem); return; }
+    if ((int)blockIdx.x >= p.ring_blocks) {
+        const int k = (int)blockIdx.x - p.ring_blocks;
+        run_tap(p, k % p.L, k / p.L, smem);
+        return;
+    }
     const int ring = blockIdx.x % p.rstride;
     const int pos = blockIdx.x / p.rstride;
     if (ring >= p.n_rings) return;
@@ -821,7 +825,7 @@ static const char* why_not(const wnv_config& c, int B) {
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 512 - (c.kernel_size - 1) * RC) return "too many local-conditioning channels";
     if (c.layers + 1 > 240) return "too many layers for one ring";
-    if (B > 32) return "more than 32 utterances per call";
+    if (B > 64) return "more than 64 utterances per call";
     return nullptr;
 }
 bool wnv_ring_supported(const wnv_config& c, int B) { return why_not(c, B) == nullptr; }
@@ -1055,7 +1059,9 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t lds = std::max(STAGE_LDS_FLOATS, tap_lds_floats(p.kper, p.klds_rows)) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
     RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int grid = p.ring_blocks + st->L;
+    // a tap workgroup serves 8 utterances per pass (~4-5 us); a second one per layer when there are more and the CUs allow
+    p.tap_parts = (B > TB && p.ring_blocks + 2 * st->L <= ncu) ? 2 : 1;
+    const int grid = p.ring_blocks + p.tap_parts * st->L;
     if (grid > ncu || grid > 1024) { err = "ring kernel needs one CU per workgroup (rings + one tap workgroup per layer)"; return WNV_ERR_UNSUPPORTED; }
     // optional timeline (WNV_RING_TRACE=<file>): wall-clock stamps of utterance 0 for 8 steps in mid-run
     const char* trace_path = getenv("WNV_RING_TRACE");
