@@ -67,6 +67,27 @@ def test_ring_equals_generic_kernel(B):
     assert torch.equal(o2, o3)
 
 
+def test_ring_30_layers_seven_rings_vs_oracle():
+    """egs/gaussian as BASELINE.json words it (30 layers, 3 stacks: dilations up to 512): 8 x 31 ring workgroups + 30 tap
+    workgroups do not fit 256 CUs, so 7 rings carry the 8 utterances (one ring pipelines two)."""
+    kw = dict(out_channels=2, layers=30, stacks=3, residual_channels=128, gate_channels=256, skip_out_channels=128,
+              kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Normal", cin_channels=80)
+    torch.manual_seed(5)
+    m = tame_head_(wnv.WaveNet(**kw).eval())
+    o = Oracle(oracle_config(kw), m.state_dict())
+    B, T = 8, 160
+    g = torch.Generator().manual_seed(2)
+    c_up = torch.randn(B, T, 80, generator=g)
+    x = torch.tanh(torch.randn(B, 1, T, generator=g) * 0.5)
+    tape = tape_for(kw, T, B, 6)
+    torch.set_num_threads(8)
+    _, wparams = o.incremental_forward(test_inputs=x, c=c_up.transpose(1, 2).contiguous(), T=T, noise=tape, return_params=True)
+    eng = m.to("cuda")._get_engine()
+    _, params, _ = run(eng, 2, B, T, c_up.cuda(), x.transpose(1, 2).contiguous().cuda(), tape.cuda())
+    err = (params.cpu() - wparams).abs().max().item()
+    assert err < TOL, err
+
+
 def test_ring_free_run_vs_oracle():
     name = "cfg2_mol"
     kw = CONFIGS[name]

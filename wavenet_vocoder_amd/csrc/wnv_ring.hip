@@ -785,14 +785,21 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
 __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // block i -> XCD i % 8 (observed, speed only): with rstride == 8 every workgroup of ring r sits on XCD r
+    // tap workgroup k (layer k % L, part k / L) sits in the k-th block that is not part of a live ring: first the slots of
+    // unused ring indices (they share an XCD with nothing but each other), then the blocks behind the rings
+    const int free_slots = (p.rstride - p.n_rings) * (p.S + 1);
     if ((int)blockIdx.x >= p.ring_blocks) {
-        const int k = (int)blockIdx.x - p.ring_blocks;
+        const int k = free_slots + (int)blockIdx.x - p.ring_blocks;
         run_tap(p, k % p.L, k / p.L, smem);
         return;
     }
     const int ring = blockIdx.x % p.rstride;
     const int pos = blockIdx.x / p.rstride;
-    if (ring >= p.n_rings) return;
+    if (ring >= p.n_rings) {
+        const int k = pos * (p.rstride - p.n_rings) + (ring - p.n_rings);
+        if (k < p.tap_parts * p.L) run_tap(p, k % p.L, k / p.L, smem);
+        return;
+    }
     if (pos < p.S) run_stage(p, ring, pos, smem);
     else run_head(p, ring, smem);
 }
@@ -991,11 +998,32 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     int ncu = 0;
     RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, st->device));
     // one workgroup per CU, one ring per utterance slot; at most 8 rings (one per XCD) and never more than fit
-    const int n_rings = std::max(1, std::min(std::min(B, 8), (ncu - st->L) / (st->S + 1)));
+    // Workgroups that must be co-resident: n_rings x (S + 1) ring workgroups + tap_parts x L tap workgroups, one per CU.
+    // Block b runs on XCD b % 8 (observed; 32 CUs each), ring r occupies blocks r, r + 8, ... = XCD r, so the budget is per
+    // XCD: (S + 1) + the tap workgroups that land there <= 32.  Tap workgroups first fill the block slots of unused ring
+    // indices, the rest follow behind the rings (round-robin over the XCDs).  A tap workgroup serves 8 utterances per
+    // pass (~4-5 us), so a second one per layer joins when there are more utterances and it fits.
+    const int cus_per_xcd = ncu / 8;
+    auto rings_that_fit = [&](int parts) {
+        for (int n = std::min(B, 8); n >= 1; --n) {
+            const int free_slots = (8 - n) * (st->S + 1);
+            const int extra = std::max(0, parts * st->L - free_slots);
+            if (st->S + 1 + (extra + 7) / 8 <= cus_per_xcd) return n;
+        }
+        return 0;
+    };
+    int tap_parts = B > TB ? 2 : 1;
+    int n_rings = rings_that_fit(tap_parts);
+    if (tap_parts == 2 && n_rings < std::min(B, 8) && rings_that_fit(1) > n_rings) {   // rather more rings than the second tap part
+        tap_parts = 1;
+        n_rings = rings_that_fit(1);
+    }
+    if (n_rings < 1) { err = "ring kernel: not enough CUs per XCD for one ring + the tap workgroups"; return WNV_ERR_UNSUPPORTED; }
     const int upr = (B + n_rings - 1) / n_rings;
-    // block b lands on XCD b % 8 (observed): a ring stride of 8 keeps every workgroup of a ring on one XCD, which the
-    // kernel verifies at run time before it uses the same-XCD hand-off; surplus workgroups exit at once
-    const int rstride = 8 * (st->S + 1) + st->L <= ncu ? 8 : n_rings;
+    // Block b lands on XCD b % 8 (observed): a ring stride of 8 keeps every workgroup of a ring on one XCD, which the
+    // kernel verifies at run time before it uses the same-XCD hand-off.  The grid always has 8 ring slots; the
+    // workgroups of unused slots exit at once and free their CUs (for the tap workgroups, which are dispatched last).
+    const int rstride = 8;
     RingParams p{};
     p.n_rings = n_rings; p.rstride = rstride; p.S = st->S; p.L = st->L; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.upr = upr;
     p.K = st->K; p.Kp = st->Kp; p.O = st->O; p.cin = st->cin; p.kw = st->kw; p.kpre = st->kpre; p.nz = ga.nz;
@@ -1059,10 +1087,9 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t lds = std::max(STAGE_LDS_FLOATS, tap_lds_floats(p.kper, p.klds_rows)) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
     RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // a tap workgroup serves 8 utterances per pass (~4-5 us); a second one per layer when there are more and the CUs allow
-    p.tap_parts = (B > TB && p.ring_blocks + 2 * st->L <= ncu) ? 2 : 1;
-    const int grid = p.ring_blocks + p.tap_parts * st->L;
-    if (grid > ncu || grid > 1024) { err = "ring kernel needs one CU per workgroup (rings + one tap workgroup per layer)"; return WNV_ERR_UNSUPPORTED; }
+    p.tap_parts = tap_parts;
+    const int grid = p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * (st->S + 1));
+    if (p.ring_blocks > ncu) { err = "ring kernel: too many layers for one ring per XCD"; return WNV_ERR_UNSUPPORTED; }
     // optional timeline (WNV_RING_TRACE=<file>): wall-clock stamps of utterance 0 for 8 steps in mid-run
     const char* trace_path = getenv("WNV_RING_TRACE");
     unsigned long long* d_trace = nullptr;
