@@ -12,6 +12,7 @@ step     : ONE pass of the hot path over one batch: wnv_upsample (mel -> sample 
            the timed region.
 scaling  : weak -- every rank synthesises its own 8 utterances; no collective on the data path (utterances
            are independent); only the barrier/max-reduce around the timed region uses RCCL.
+kernel   : auto = the pipelined ring kernel (csrc/wnv_ring.hip) for this configuration.
 roofline : the dominant kernel is the sample-loop kernel.  achieved = algorithmic bytes per launch
            (wnv_bytes_per_step(B) x T, SURVEY.md 8d: every weight once per step per utterance group + ring taps
            + conditioning row + sample) / the kernel's duration measured with HIP events on its own stream.
@@ -174,6 +175,22 @@ def main():
             "roofline_lds": {"bound": "lds", "achieved": round(ach, 2), "peak": LDS_PEAK_GBS, "unit": "GB/s",
                              "frac": round(ach / LDS_PEAK_GBS, 6)},
         }
+        if world == 1 and args.batch == B_PER_GPU and args.workload == WORKLOAD:
+            # informative only (not `value`): the same kernel with 32 utterances per GPU -- the rings pipeline four
+            # utterances each like a systolic array (DESIGN.md 5.2 "Throughput vs. batch")
+            try:
+                B2, T2 = 32, 8192
+                c2, g2 = inputs(name, B2, T2, seed=7)
+                c2 = c2.to(dev)
+                eng.generate(B=B2, T=T2, c_up=eng.upsample(c2, T_expected=T2), seed=1, kernel=args.kernel)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng.generate(B=B2, T=T2, c_up=eng.upsample(c2, T_expected=T2), seed=2, kernel=args.kernel)
+                torch.cuda.synchronize()
+                line["throughput_mode"] = {"batch_per_gpu": B2, "T": T2,
+                                           "kSamples_per_s_per_gpu": round(B2 * T2 / (time.perf_counter() - t1) / 1e3, 1)}
+            except Exception as e:  # the headline line must not depend on this extra
+                line["throughput_mode"] = {"error": str(e)[:120]}
         if world == 1 and args.cpu_steps > 0:
             line["cpu_baseline"] = cpu_baseline(model_cpu, kw, c, args.cpu_steps)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
