@@ -197,3 +197,83 @@ def test_ring_back_to_back_launches_with_changing_shapes():
     eng2 = build(name).to("cuda")._get_engine()
     ref = run(eng2, 2, 5, 129, cond(5, 129), None, tape_for(kw, 129, 5, 11).cuda())[0]
     assert torch.equal(outs[3], ref)
+
+
+# ---- one-hot (mu-law categorical) models on the ring kernel -----------------------------------------------------------
+ONEHOT = dict(out_channels=256, layers=8, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128,
+              kernel_size=3, dropout=0.0, cin_channels=80)
+
+
+def onehot_model(seed=21, **over):
+    kw = dict(ONEHOT, **over)
+    torch.manual_seed(seed)
+    return kw, tame_head_(wnv.WaveNet(**kw).eval())
+
+
+def cat_tape(T, B, seed):
+    return make_noise_tape(T, B, scalar_input=False, output_distribution="Logistic", out_channels=256,
+                           generator=torch.Generator().manual_seed(seed))
+
+
+def test_ring_onehot_teacher_forced_vs_oracle_and_generic():
+    kw, m = onehot_model()
+    o = Oracle(oracle_config(kw), m.state_dict())
+    B, T = 3, 128
+    g = torch.Generator().manual_seed(4)
+    c_up = torch.randn(B, T, 80, generator=g)
+    idx = torch.randint(0, 256, (B, T), generator=g)
+    x = torch.zeros(B, 256, T).scatter_(1, idx.unsqueeze(1), 1.0)
+    tape = cat_tape(T, B, 9)
+    torch.set_num_threads(8)
+    want, wparams = o.incremental_forward(test_inputs=x, c=c_up.transpose(1, 2).contiguous(), T=T, softmax=True,
+                                          quantize=False, noise=tape, return_params=True)
+    eng = m.to("cuda")._get_engine()
+    tin = x.transpose(1, 2).contiguous().cuda()
+    res = {}
+    for k in (1, 2):
+        res[k] = eng.generate(B=B, T=T, c_up=c_up.cuda(), teacher=tin, noise=tape.cuda(), softmax=True, quantize=False,
+                              want_params=True, kernel=k)
+    assert (res[2][1].cpu() - wparams).abs().max().item() < TOL            # head outputs vs the oracle
+    assert (res[2][0].cpu() - want).abs().max().item() < TOL               # probabilities vs the oracle
+    assert (res[2][1] - res[1][1]).abs().max().item() < 2e-5               # vs the generic kernel
+
+
+def test_ring_onehot_free_run_sampled_classes():
+    kw, m = onehot_model(seed=22)
+    o = Oracle(oracle_config(kw), m.state_dict())
+    B, T = 2, 160
+    c_up = torch.randn(B, T, 80, generator=torch.Generator().manual_seed(5))
+    tape = cat_tape(T, B, 10)
+    torch.set_num_threads(8)
+    want = o.incremental_forward(c=c_up.transpose(1, 2).contiguous(), T=T, noise=tape)      # (B, 256, T) one-hot
+    eng = m.to("cuda")._get_engine()
+    out, _, idx = eng.generate(B=B, T=T, c_up=c_up.cuda(), noise=tape.cuda(), want_index=True, kernel=2)
+    out1, _, idx1 = eng.generate(B=B, T=T, c_up=c_up.cuda(), noise=tape.cuda(), want_index=True, kernel=1)
+    assert torch.equal(out.sum(1), torch.ones(B, T, device="cuda")) and torch.equal(out.argmax(1).int(), idx.int())
+    agree = (idx.cpu().long() == want.argmax(1))
+    first_bad = T if bool(agree.all()) else int((~agree).nonzero()[:, 1].min())
+    print(f"ring one-hot free run: sampled classes equal the oracle's for {first_bad}/{T} steps")
+    assert first_bad >= 64                                                  # exact classes until an argmax tie flips
+    assert (idx == idx1).float().mean().item() > 0.6                        # and largely the generic kernel's trajectory
+
+
+def test_ring_mulaw256_intree_preset_properties():
+    """egs/mulaw256 as shipped (30 layers, 3 stacks, 80-mel upsampling): 7 rings + categorical head; properties at length."""
+    name = "cfg1b_mulaw256_intree"
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    B, T = 8, 2048
+    c, _ = inputs(name, B, T)
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    tape = cat_tape(T, B, 12).cuda()
+    full, _, idx = eng.generate(B=B, T=T, c_up=c_up, noise=tape, want_index=True, kernel=2)
+    assert torch.equal(full.sum(1), torch.ones(B, T, device="cuda"))
+    again, _, _ = eng.generate(B=B, T=T, c_up=c_up, noise=tape, want_index=True, kernel=2)
+    assert torch.equal(full, again), "determinism"
+    T2 = 512
+    pre, _, _ = eng.generate(B=B, T=T2, c_up=c_up[:, :T2].contiguous(), noise=tape[:T2].contiguous(), kernel=2)
+    assert torch.equal(pre, full[:, :, :T2]), "prefix property"
+    solo, _, _ = eng.generate(B=1, T=T2, c_up=c_up[3:4, :T2].contiguous(), noise=tape[:T2, 3:4].contiguous(), kernel=2)
+    assert torch.equal(solo[0], full[3, :, :T2]), "batch members must be independent"
+    gen, _, idx1 = eng.generate(B=B, T=256, c_up=c_up[:, :256].contiguous(), noise=tape[:256].contiguous(), want_index=True, kernel=1)
+    assert (idx[:, :256] == idx1).float().mean().item() > 0.5

@@ -66,7 +66,9 @@ struct RingParams {
     unsigned tag_base;                 // tags of this launch are tag_base + t + 1: unique across launches, no re-zeroing
     float skip_scale;
     const float *w2img, *wnimg, *woimg, *wsimg, *bo, *wpre, *bskip, *cvec;
-    const float *wh1img, *bh1, *wh2img, *bh2, *wfirst, *bfirst;
+    const float *wh1img, *bh1, *wh2img, *bh2, *wfirst, *bfirst;   // one-hot models: wh2img holds two row images (rows i, 128 + i), wfirst is K-major [cin1][128]
+    int cin1, softmax, quantize;       // first_conv input channels (1 = scalar input); categorical head switches (wavenet.py:332-335)
+    int* index_out;
     const float* zbias;
     long long zbias_bstride;
     const int *lay_dil, *lay_histoff;
@@ -782,6 +784,122 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
     }
 }
 
+// ---- head of one-hot (mu-law categorical) models: wavenet.py:315-319 head, :332-335 softmax + OneHotCategorical, :297-308
+// first_conv on the fed-back one-hot vector.  first_conv's matrix lives in LDS K-major, so the fed-back class is ONE row
+// gather (bit-identical to F.linear with a one-hot input); teacher-forced inputs and fed-back probabilities
+// (quantize = False, tests only) take the dense mat-vec.  Sampling is sample_categorical() of the generic kernel
+// (argmax(p_hat / e), e ~ Exp(1): what torch.multinomial does), wave 0.
+struct CatLds {
+    float* vs; float* hid; float* obuf; float* nzb; float* vin; float* part; int* ints; float* wfl;
+};
+__device__ __forceinline__ CatLds carve_cat(float* smem) {
+    CatLds s;
+    s.vs = smem; s.hid = smem + 4 * QS; s.obuf = smem + 8 * QS; s.nzb = s.obuf + 256; s.vin = s.nzb + 256;
+    s.part = s.vin + 256; s.ints = reinterpret_cast<int*>(s.part + 4 * RC); s.wfl = reinterpret_cast<float*>(s.ints + 16);
+    return s;
+}
+constexpr size_t CAT_LDS_FLOATS = (size_t)8 * QS + 3 * 256 + 4 * RC + 16 + (size_t)256 * RC;
+
+__device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
+    const CatLds s = carve_cat(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 3, i = wave * 16 + (lane >> 2);
+    const int S1 = p.S + 1, O = p.O;
+    f2 wh1[16], wh2a[16], wh2b[16];
+    load_image16(p.wh1img, tid, wh1);
+    load_image16(p.wh2img, tid, wh2a);
+    load_image16(p.wh2img + (size_t)8 * RT * 4, tid, wh2b);
+    const float bh1 = p.bh1[i], bh2a = p.bh2[i], bh2b = p.bh2[RC + i];
+    const float bf = tid < RC ? p.bfirst[tid] : 0.f;
+    for (int k = tid; k < O * RC; k += RT) s.wfl[k] = p.wfirst[k];
+    if (tid == 0) { s.ints[0] = 0; s.ints[1] = 0; }                  // ints[0] = abort flag, ints[1] = sampled class
+    const bool fast = same_xcd_as(p, ring, ring + (p.S > 1 ? p.rstride : 0), s.ints + 2);
+
+    // first_conv of `dense` (O floats in global memory or LDS) or of the one-hot class `idx`, sent as the input of `tag_next`
+    auto send_input = [&](int b, const float* dense, int idx, unsigned tag_next) {
+        if (dense == nullptr) {
+            if (tid < RC) st_granule(p.xmail + ((size_t)b * S1) * RC + tid, tag_next, s.wfl[(size_t)idx * RC + tid] + bf, fast);
+            return;
+        }
+        for (int k = tid; k < O; k += RT) s.vin[k] = dense[k];
+        __syncthreads();
+        {
+            const int r = tid & (RC - 1), part = tid >> 7;          // four K parts x 128 outputs
+            const int kper = (O + 3) / 4, ka = part * kper, kb = min(O, ka + kper);
+            float acc = 0.f;
+            for (int k = ka; k < kb; ++k) acc = fmaf(s.wfl[(size_t)k * RC + r], s.vin[k], acc);
+            s.part[part * RC + r] = acc;
+        }
+        __syncthreads();
+        if (tid < RC)
+            st_granule(p.xmail + ((size_t)b * S1) * RC + tid, tag_next,
+                       ((s.part[tid] + s.part[RC + tid]) + (s.part[2 * RC + tid] + s.part[3 * RC + tid])) + bf, fast);
+        __syncthreads();
+    };
+
+    // ---- prologue: the input of step 0 (wavenet.py:283-289: one-hot of class 127 unless given) ------------------
+    for (int j = 0; j < p.upr; ++j) {
+        const int b = ring + j * p.n_rings;
+        if (b >= p.B) continue;
+        const float* dense = p.Tt > 0 ? p.teacher + (size_t)b * p.Tt * O : (p.initial ? p.initial + (size_t)b * O : nullptr);
+        send_input(b, dense, 127, p.tag_base + 1u);
+        stamp(p, b, 0, p.S, 0);
+    }
+
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        for (int j = 0; j < p.upr; ++j) {
+            const int b = ring + j * p.n_rings;
+            if (b >= p.B) continue;
+            // noise of this step, while the ring works: e ~ Exp(1) per class
+            if (tid < O) s.nzb[tid] = head_noise(p, t, b, tid, 2);
+            if (wave < 2) {
+                float v = 0.f;
+                if (!wave_recv<false>(p.smail + ((size_t)b * S1 + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane))
+                    s.ints[0] = 1;
+                s.vs[qidx(tid)] = fmaxf(v * p.skip_scale, 0.f);                  // wavenet.py:313-316
+            }
+            __syncthreads();
+            stamp(p, b, t, p.S, 1);
+            float x[32];
+            lds_read32(s.vs + QS * q, x);
+            const float h1 = fmaxf(quad_allreduce(dot32p(wh1, x)) + bh1, 0.f);  // wavenet.py:317-318
+            if (q == 0) s.hid[qidx(i)] = h1;
+            __syncthreads();
+            lds_read32(s.hid + QS * q, x);
+            const float oa = quad_allreduce(dot32p(wh2a, x)) + bh2a;              // wavenet.py:319, rows i and 128 + i
+            const float ob = quad_allreduce(dot32p(wh2b, x)) + bh2b;
+            if (q == 0) {
+                if (i < O) { s.obuf[i] = oa; if (p.params_out) p.params_out[((size_t)b * O + i) * p.T + t] = oa; }
+                if (RC + i < O) { s.obuf[RC + i] = ob; if (p.params_out) p.params_out[((size_t)b * O + RC + i) * p.T + t] = ob; }
+            }
+            __syncthreads();
+            if (wave == 0) {                                                        // wavenet.py:332-335
+                const int idx = sample_categorical(O, s.obuf, s.nzb, p.softmax, p.quantize, lane);
+                if (p.quantize) {
+                    if (lane == 0) {
+                        p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;             // out is pre-zeroed by the host
+                        if (p.index_out) p.index_out[(size_t)b * p.T + t] = idx;
+                        s.ints[1] = idx;
+                    }
+                } else {
+                    for (int n = lane; n < O; n += 64) p.out[((size_t)b * O + n) * p.T + t] = s.obuf[n];
+                }
+            }
+            __syncthreads();
+            if (t + 1 < p.T) {                                                      // wavenet.py:297-308 for step t + 1
+                const float* dense = nullptr;
+                if (t + 1 < p.Tt) dense = p.teacher + ((size_t)b * p.Tt + t + 1) * O;
+                else if (!p.quantize) dense = s.obuf;                               // fed-back probabilities
+                send_input(b, dense, s.ints[1], tag + 1u);
+                stamp(p, b, t + 1, p.S, 0);
+            }
+            stamp(p, b, t, p.S, 2);
+            if (s.ints[0]) return;
+        }
+    }
+}
+
 __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // block i -> XCD i % 8 (observed, speed only): with rstride == 8 every workgroup of ring r sits on XCD r
@@ -801,6 +919,7 @@ __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
         return;
     }
     if (pos < p.S) run_stage(p, ring, pos, smem);
+    else if (p.cin1 > 1) run_head_cat(p, ring, smem);
     else run_head(p, ring, smem);
 }
 
@@ -811,7 +930,7 @@ __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
 // =================================================================================================
 struct WnvRingState {
     int device = 0;
-    int L = 0, S = 0, K = 0, Kp = 0, O = 0, cin = 0, kw = 0, kpre = 0;
+    int L = 0, S = 0, K = 0, Kp = 0, O = 0, cin = 0, kw = 0, kpre = 0, cin1 = 1;
     float* d_w = nullptr;          // one blob, offsets below (floats)
     size_t o_wn = 0, o_cvec = 0, o_w2 = 0, o_wo = 0, o_bo = 0, o_wpre = 0, o_ws = 0, o_bskip = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0,
            o_bh2 = 0, o_wf = 0, o_bf = 0;
@@ -825,10 +944,10 @@ struct WnvRingState {
 };
 
 static const char* why_not(const wnv_config& c, int B) {
-    if (!c.scalar_input) return "one-hot input models run on the generic kernel";
+    if (!c.scalar_input && c.out_channels > 256) return "one-hot models need out_channels <= 256";
     if (c.residual_channels != RC || c.gate_channels != GC) return "needs residual_channels == 128 and gate_channels == 256";
     if (c.skip_out_channels != 128) return "needs skip_out_channels == 128 (head kept in registers)";
-    if (c.out_channels > 128) return "needs out_channels <= 128";
+    if (c.scalar_input && c.out_channels > 128) return "needs out_channels <= 128";
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 512 - (c.kernel_size - 1) * RC) return "too many local-conditioning channels";
     if (c.layers + 1 > 240) return "too many layers for one ring";
@@ -969,12 +1088,20 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     put_image(blob, st->o_wh1, T("last_conv_layers.1.weight").data.data(), 0, K);
     st->o_bh1 = alloc(RC);
     std::copy(T("last_conv_layers.1.bias").data.begin(), T("last_conv_layers.1.bias").data.end(), blob.begin() + st->o_bh1);
-    st->o_wh2 = alloc((size_t)8 * RT * 4);
+    st->o_wh2 = alloc((size_t)2 * 8 * RT * 4);                      // rows i and (one-hot models, O up to 256) rows 128 + i
     put_image(blob, st->o_wh2, T("last_conv_layers.3.weight").data.data(), 0, O);
-    st->o_bh2 = alloc(RC);
+    put_image(blob, st->o_wh2 + (size_t)8 * RT * 4, T("last_conv_layers.3.weight").data.data(), RC, O);
+    st->o_bh2 = alloc(2 * RC);
     std::copy(T("last_conv_layers.3.bias").data.begin(), T("last_conv_layers.3.bias").data.end(), blob.begin() + st->o_bh2);
-    st->o_wf = alloc(RC);
-    std::copy(T("first_conv.weight").data.begin(), T("first_conv.weight").data.end(), blob.begin() + st->o_wf);   // (R,1,1)
+    // first_conv: (R, 1, 1) for scalar input; one-hot models: (R, cin1, 1) stored K-major [cin1][R] (row k = column k)
+    const int cin1 = c.scalar_input ? 1 : O;
+    st->cin1 = cin1;
+    st->o_wf = alloc((size_t)cin1 * RC);
+    {
+        const HostTensor& wf = T("first_conv.weight");
+        for (int r = 0; r < RC; ++r)
+            for (int k = 0; k < cin1; ++k) blob[st->o_wf + (size_t)k * RC + r] = wf.data[(size_t)r * cin1 + k];
+    }
     st->o_bf = alloc(RC);
     std::copy(T("first_conv.bias").data.begin(), T("first_conv.bias").data.end(), blob.begin() + st->o_bf);
     *out = st;
@@ -1028,6 +1155,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.n_rings = n_rings; p.rstride = rstride; p.S = st->S; p.L = st->L; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.upr = upr;
     p.K = st->K; p.Kp = st->Kp; p.O = st->O; p.cin = st->cin; p.kw = st->kw; p.kpre = st->kpre; p.nz = ga.nz;
     p.dist = c.output_distribution;
+    p.cin1 = st->cin1; p.softmax = ga.softmax; p.quantize = ga.quantize; p.index_out = ga.index_out;
     p.pstride = std::max(GC, st->Kp);
     p.hist_floats = st->hist_floats;
     p.skip_scale = (float)std::sqrt(1.0 / st->L);
@@ -1084,7 +1212,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);
     while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 150 * 1024) --p.klds_rows;
     p.ring_blocks = rstride * (st->S + 1);
-    const size_t lds = std::max(STAGE_LDS_FLOATS, tap_lds_floats(p.kper, p.klds_rows)) * sizeof(float);
+    const size_t lds = std::max(std::max(STAGE_LDS_FLOATS, tap_lds_floats(p.kper, p.klds_rows)), st->cin1 > 1 ? CAT_LDS_FLOATS : (size_t)0) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
     RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.tap_parts = tap_parts;
