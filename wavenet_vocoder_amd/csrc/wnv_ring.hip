@@ -143,6 +143,35 @@ __device__ __forceinline__ bool bulk_wait(const u64* flag, unsigned tag, unsigne
     }
 }
 
+// ONE wave receives a whole 128-value vector: two adjacent granules per lane in one 16-byte L1-bypassing load.  (Two
+// polling waves see an arrival at the later of two independent poll phases; one wave sees it at its own.)  The first
+// load may have been issued early with issue16() (the compiler neither moves nor waits for the inline-asm load).
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u4v issue16(const u64* p) {
+    u4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ void redeem16(u4v& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
+__device__ __forceinline__ bool wave_recv2(const u64* g2, unsigned tag, float& v0, float& v1, unsigned int* status,
+                                           unsigned code, int lane, bool have_first, u4v first) {
+    unsigned spins = 0;
+    for (;;) {
+        u4v x = first;
+        if (!have_first) { x = issue16(g2); redeem16(x); }
+        have_first = false;
+        v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z);
+        if (__all(x.y == tag && x.w == tag)) return true;
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) {
+                if (lane == 0) atomicCAS(status, 0u, code);
+                return false;
+            }
+        }
+    }
+}
+
 // One wave waits until the granule of every ACTIVE lane carries `tag`; returns false on abort/timeout.
 template <bool SLEEP>
 __device__ __forceinline__ bool wave_recv(const u64* g, bool active, unsigned tag, float& v, unsigned int* status,
@@ -534,8 +563,8 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             const int b = ring + j * p.n_rings;
             if (b >= p.B) continue;
             // every mailbox address of this step, pinned in registers before the first wait
-            const u64* x_in = p.xmail + ((size_t)b * S1 + sidx) * RC + tid;
-            u64 x_first = 0;
+            const u64* x_in = p.xmail + ((size_t)b * S1 + sidx) * RC + 2 * lane;      // wave 0: two granules per lane
+            u4v x_first = {0, 0, 0, 0};
             u64* x_out = p.xmail + ((size_t)b * S1 + sidx + 1) * RC + ch;
             const u64* h_in = p.hmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + ch;
             u64* h_out = p.hmail + (((size_t)b * 2 + par) * S1 + sidx + 1) * RC + ch;
@@ -555,14 +584,14 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             __syncthreads();
             zin_a = s.pre[ch]; zin_g = s.pre[RC + ch];
             if (!first_stage) {
-                if (wave < 2) {
+                if (wave == 0) {
                     // h_0 is the chain input of stage 0; h_{l-1} for l >= 2 comes from stage l-2's conv1x1_out
-                    const u64* hb_in = sidx == 1 ? p.xmail + ((size_t)b * S1) * RC + tid
-                                                 : p.hmail + (((size_t)b * 2 + par) * S1 + sidx - 1) * RC + tid;
-                    float v = 0.f;
-                    if (!wave_recv<false>(hb_in, true, tag, v, p.status, 0x400u + (unsigned)sidx, lane)) s.flags[0] = 1;
-                    s.hb[eidx(tid)] = v;
-                    x_first = ld_issue(x_in);       // the chain input is usually there already: fetch it under the N mat-vec
+                    const u64* hb_in = sidx == 1 ? p.xmail + ((size_t)b * S1) * RC + 2 * lane
+                                                 : p.hmail + (((size_t)b * 2 + par) * S1 + sidx - 1) * RC + 2 * lane;
+                    float v0 = 0.f, v1 = 0.f;
+                    if (!wave_recv2(hb_in, tag, v0, v1, p.status, 0x400u + (unsigned)sidx, lane, false, u4v{0, 0, 0, 0})) s.flags[0] = 1;
+                    *reinterpret_cast<float2*>(s.hb + eidx(2 * lane)) = make_float2(v0, v1);
+                    x_first = issue16(x_in);        // the chain input may be there already: fetch it under the N mat-vec
                 }
                 __syncthreads();
                 float x[16];
@@ -582,12 +611,11 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             stamp(p, b, t, sidx, 6);
 #endif
             // ---- the chain: receive X[l][t]  ->  M_l X + zin  ->  gate  ->  send u_l --------------------------------
-            if (wave < 2) {
-                float v = 0.f;
-                if (!first_stage) ld_redeem(x_first);
-                if (!wave_recv<false>(x_in, true, tag, v, p.status, 0x100u + (unsigned)sidx, lane, !first_stage, x_first))
-                    s.flags[0] = 1;
-                s.hx[eidx(tid)] = v;
+            if (wave == 0) {
+                float v0 = 0.f, v1 = 0.f;
+                if (!first_stage) redeem16(x_first);
+                if (!wave_recv2(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane, !first_stage, x_first)) s.flags[0] = 1;
+                *reinterpret_cast<float2*>(s.hx + eidx(2 * lane)) = make_float2(v0, v1);
             }
             __syncthreads();
             stamp(p, b, t, sidx, 0);
