@@ -564,7 +564,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             if (b >= p.B) continue;
             // every mailbox address of this step, pinned in registers before the first wait
             const u64* x_in = p.xmail + ((size_t)b * S1 + sidx) * RC + 2 * lane;      // wave 0: two granules per lane
-            u4v x_first = {0, 0, 0, 0};
+            u4v x_first = {0, 0, 0, 0}, x_second = {0, 0, 0, 0};
             u64* x_out = p.xmail + ((size_t)b * S1 + sidx + 1) * RC + ch;
             const u64* h_in = p.hmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + ch;
             u64* h_out = p.hmail + (((size_t)b * 2 + par) * S1 + sidx + 1) * RC + ch;
@@ -602,7 +602,11 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
 #pragma unroll
                     for (int row = 0; row < 4; ++row)
                         acc[row] = __builtin_elementwise_fma(wn[row][k], f2{x[2 * k], x[2 * k + 1]}, acc[row]);
-                const float a0 = acc[0].x + acc[0].y, g0 = acc[1].x + acc[1].y, a1 = acc[2].x + acc[2].y, g1 = acc[3].x + acc[3].y;
+                float a0 = acc[0].x + acc[0].y, g0 = acc[1].x + acc[1].y, a1 = acc[2].x + acc[2].y, g1 = acc[3].x + acc[3].y;
+                if (wave == 0) {                    // a second poll for the chain input, one reduction ahead of its use: the
+                    asm volatile("" : "+v"(a0), "+v"(g0), "+v"(a1), "+v"(g1));      // vector tends to land during this mat-vec
+                    x_second = issue16(x_in);
+                }
                 zin_a += quad_allreduce((hi ? a1 : a0) + dpp_mov<0x141>(hi ? a0 : a1));
                 zin_g += quad_allreduce((hi ? g1 : g0) + dpp_mov<0x141>(hi ? g0 : g1));
             }
@@ -613,7 +617,10 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             // ---- the chain: receive X[l][t]  ->  M_l X + zin  ->  gate  ->  send u_l --------------------------------
             if (wave == 0) {
                 float v0 = 0.f, v1 = 0.f;
-                if (!first_stage) redeem16(x_first);
+                if (!first_stage) {                 // both early polls have been outstanding since before / during the N mat-vec
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x_first), "+v"(x_second) :: "memory");
+                    if (__all(x_second.y == tag && x_second.w == tag)) x_first = x_second;
+                }
                 if (!wave_recv2(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane, !first_stage, x_first)) s.flags[0] = 1;
                 *reinterpret_cast<float2*>(s.hx + eidx(2 * lane)) = make_float2(v0, v1);
             }
