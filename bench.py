@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--cpu-steps", type=int, default=1024, help="T of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--workload", default=WORKLOAD)
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed steps (no throughput_mode, no cpu_baseline): what the rocprofv3 summaries are taken with")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -175,7 +177,7 @@ def main():
             "roofline_lds": {"bound": "lds", "achieved": round(ach, 2), "peak": LDS_PEAK_GBS, "unit": "GB/s",
                              "frac": round(ach / LDS_PEAK_GBS, 6)},
         }
-        if world == 1 and args.batch == B_PER_GPU and args.workload == WORKLOAD:
+        if world == 1 and args.batch == B_PER_GPU and args.workload == WORKLOAD and not args.no_extras:
             # informative only (not `value`): the same kernel with 32 utterances per GPU -- the rings pipeline four
             # utterances each like a systolic array (DESIGN.md 5.2 "Throughput vs. batch")
             try:
@@ -191,7 +193,7 @@ def main():
                                            "kSamples_per_s_per_gpu": round(B2 * T2 / (time.perf_counter() - t1) / 1e3, 1)}
             except Exception as e:  # the headline line must not depend on this extra
                 line["throughput_mode"] = {"error": str(e)[:120]}
-        if world == 1 and args.cpu_steps > 0:
+        if world == 1 and args.cpu_steps > 0 and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(model_cpu, kw, c, args.cpu_steps)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)

@@ -12,7 +12,7 @@ cd /tmp
 run() {  # name, counters...
   local name=$1; shift
   timeout 600 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/pmc_$name -o p -- \
-      python $ROOT/bench.py --steps 1 --warmup 1 --cpu-steps 0 ${BENCH_ARGS:-} > $OUT/pmc_$name.log 2>&1
+      python $ROOT/bench.py --steps 1 --warmup 1 --no-extras ${BENCH_ARGS:-} > $OUT/pmc_$name.log 2>&1
   echo "== $name: $(grep -c . $(find $OUT/pmc_$name -name '*counter_collection.csv' | head -1) 2>/dev/null) rows"
 }
 BENCH_ARGS="$*"

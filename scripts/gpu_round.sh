@@ -26,7 +26,7 @@ if [[ $WHAT == all || $WHAT == bench || $WHAT == ring ]]; then
 fi
 if [[ $WHAT == all || $WHAT == prof ]]; then
   echo "== rocprofv3 kernel stats"
-  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o wnv -- python $ROOT/bench.py --steps 2 --warmup 1 --cpu-steps 0 "$@" > $ROOT/$OUT/prof_bench.log 2>&1 )
+  ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/$OUT/prof -o wnv -- python $ROOT/bench.py --steps 3 --warmup 1 --no-extras "$@" > $ROOT/$OUT/prof_bench.log 2>&1 )
   grep '^{' $OUT/prof_bench.log | tail -1
   for f in $(find $OUT/prof -name "*kernel_stats.csv" | head -1); do echo $f; head -12 $f | cut -c1-240; done
 fi
