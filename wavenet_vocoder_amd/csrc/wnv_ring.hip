@@ -84,7 +84,6 @@ struct RingParams {
     unsigned int* status;
     unsigned long long* trace;         // optional [T_trace][S+1][8] wall-clock stamps of utterance 0 (debug)
     int trace_t0, trace_n;
-    const RingParams* self;            // device-memory copy of this block (see reread())
 };
 
 using u64 = unsigned long long;
@@ -222,19 +221,9 @@ __device__ __forceinline__ bool same_xcd_as(const RingParams& p, int reader_a, i
     return *flag != 0;
 }
 
-// The parameter block is passed twice: by value (kernel-argument segment) for the chain, and as a copy in device memory
-// (p.self) for the deferred work, which reads its fields through a pointer made opaque once per step -- re-read with
-// scalar loads off the chain instead of being hoisted out of the time loop into ~40 long-lived SGPRs that would spill
-// into VGPR lanes (and come back through v_readlane on the chain).
-__device__ __forceinline__ const RingParams& reread(const RingParams& p) {
-    const RingParams* q = p.self;
-    asm volatile("" : "+s"(q));
-    return *q;
-}
-
 // debug timeline: stamp slot k of (step t, position pos) with the device-wide 100 MHz wall clock
 __device__ __forceinline__ void stamp(const RingParams& p, int b, int t, int pos, int k, int who = 0) {
-    if (p.trace && b == 0 && threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
+    if (p.trace && b == 0 && (int)threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
         p.trace[((size_t)(t - p.trace_t0) * (p.S + 1) + pos) * 8 + k] = wall_clock64();
 }
 
@@ -1203,7 +1192,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
     // state: [status 64 B][placement table 4 KiB][xmail B*(S+1)*128 u64][hmail B*2*(S+1)*128 u64][smail B*(S+1)*Kp u64]
     //        [hist B*hist_floats f32]
-    const size_t head_bytes = 64 + 4096 + 1024;                    // status, placement table, parameter-block copy
+    const size_t head_bytes = 64 + 4096;                           // status word, placement table
     const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
     const size_t n_f = (size_t)B * st->L * (4 + RC), n_p = (size_t)B * st->L * (4 + GC);   // stage <-> tap-workgroup bulk records (floats)
     const size_t mail_bytes = (3 * n_h + n_s) * sizeof(u64) + (n_f + n_p) * sizeof(float);
@@ -1264,9 +1253,6 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         RING_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
     }
-    static_assert(sizeof(RingParams) <= 1024, "parameter-block copy area");
-    p.self = reinterpret_cast<const RingParams*>(base + 64 + 4096);
-    RING_HIP(hipMemcpyAsync(base + 64 + 4096, &p, sizeof p, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(wnv_ring_kernel, dim3(grid), dim3(RT), lds, stream, p);
     RING_HIP(hipGetLastError());
     // the ring path is synchronous: a bounded spin that gave up must be reported to the caller
