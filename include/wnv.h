@@ -183,6 +183,23 @@ wnv_status wnv_glu_step(wnv_glu_handle g, const float* x, const float* c, const 
 wnv_status wnv_glu_reset(wnv_glu_handle g);              /* modules.py:165-169 clear_buffer */
 wnv_status wnv_glu_destroy(wnv_glu_handle g);
 
+/* ---- teacher-forced batch evaluation ------------------------------------------
+ * Replaces WaveNet.forward (wavenet.py:164-213) after the upsampling step: first_conv, the L gated layers over all T at
+ * once (f32 MFMA GEMMs), skip sum, head, optional softmax.  Needs residual_channels == 128, gate_channels == 256,
+ * skip_out_channels % 128 == 0, out_channels <= 256 (else WNV_ERR_UNSUPPORTED: the Python host then uses torch ops). */
+typedef struct wnv_forward_args {
+    int32_t B;
+    int64_t T;
+    const float* x;            /* device (B, Cin, T): Cin = 1 (scalar input) or out_channels (one-hot)      */
+    const float* c_up;         /* device (B, T, cin) time-major (wnv_upsample's output), or NULL            */
+    const float* g;            /* device (B, gin) or NULL                                                   */
+    const int64_t* g_ids;      /* device (B) speaker ids or NULL                                            */
+    float* out;                /* device (B, out_channels, T)                                               */
+    int32_t softmax;           /* F.softmax(x, dim=1) at the end (wavenet.py:211)                           */
+    void* stream;
+} wnv_forward_args;
+wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* args);
+
 /* ---- post-chain ------------------------------------------------------------
  * Replaces the tail of synthesis.batch_wavegen (synthesis.py:66-84) and the clip / int16 conversion of
  * evaluate.py:238, :43-48 on the device: argmax + inv_mulaw_quantize | inv_mulaw | raw, then the optional

@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-__all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "LIB_PATH",
+__all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "ForwardArgs", "LIB_PATH",
            "WNV_ABI_VERSION", "DIST", "UPSAMPLE"]
 
 WNV_ABI_VERSION = 1
@@ -61,6 +61,13 @@ class GenerateArgs(C.Structure):
     ]
 
 
+class ForwardArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("T", C.c_int64), ("x", C.c_void_p), ("c_up", C.c_void_p), ("g", C.c_void_p),
+        ("g_ids", C.c_void_p), ("out", C.c_void_p), ("softmax", C.c_int32), ("stream", C.c_void_p),
+    ]
+
+
 class PostArgs(C.Structure):
     _fields_ = [
         ("B", C.c_int32), ("C", C.c_int32), ("T", C.c_int64), ("y", C.c_void_p), ("input_type", C.c_int32),
@@ -99,6 +106,7 @@ _PROTOS = {
     "wnv_glu_reset": (C.c_int, [C.c_void_p]),
     "wnv_glu_destroy": (C.c_int, [C.c_void_p]),
     "wnv_postprocess": (C.c_int, [C.c_int32, C.POINTER(PostArgs)]),
+    "wnv_forward": (C.c_int, [C.c_void_p, C.POINTER(ForwardArgs)]),
     "wnv_bytes_per_step": (C.c_int64, [C.c_void_p, C.c_int32]),
     "wnv_macs_per_sample": (C.c_int64, [C.c_void_p]),
 }

@@ -1,0 +1,342 @@
+// wnv_forward.hip -- teacher-forced batch evaluation, WaveNet.forward (wavenet.py:164-213), SURVEY.md 8f row f3.
+//
+// Unlike the sample loop this IS a GEMM workload: per layer  Z[T x 256] = X[T x (kw*128 + cin)] W  with X the kw dilated
+// taps of the layer input and the conditioning row (conv.py / modules.py:127-150 evaluated for all t at once), the gate,
+// then [T x 128] x [128 x (128 + K)] for conv1x1_out | conv1x1_skip (modules.py:157-162).  f32 in, f32 out (the parity bar is
+// 1e-4 against an f32 reference), so the matrix cores run v_mfma_f32_32x32x2_f32: exact f32 FMAs at the f32 vector rate
+// (157 TFLOP/s peak) -- the bound of this kernel is that MFMA issue rate, not HBM (58 GFLOP against ~0.4 GB per layer at
+// the bench size).
+//
+// One workgroup (4 waves) owns a tile of 64 time steps of one utterance for one layer and runs the whole layer on it:
+// GEMM1 (K chunks of 32 staged K-major through LDS, taps gathered straight from the time-major activations) -> bias
+// (+ global conditioning, hoisted) -> tanh . sigmoid in registers -> U tile K-major in LDS -> GEMM2 in column blocks of
+// 256 -> residual / skip epilogue.  Activations ping-pong between two (B, T, 128) buffers (a layer reads rows t - k d of its
+// input), the skip sum accumulates in a (B, T, K) buffer, the head is a third kernel of the same shape.
+// Lane layout of the 32x32x2 MFMA (checked on the device by scripts/ubench_mfma.hip): A[i = lane % 32][k = lane / 32],
+// B[k = lane / 32][j = lane % 32], D[8 (v / 4) + 4 (lane / 32) + v % 4][lane % 32] for accumulator register v.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <string>
+
+#include "wnv_dev.h"
+#include "wnv_forward.h"
+
+namespace {
+
+constexpr int FT = 256;            // threads per workgroup (4 waves)
+constexpr int TM = 64;             // time steps per tile
+constexpr int KC = 32;             // K rows per LDS chunk
+constexpr int XS = TM + 1;         // padded row stride of the K-major activation tiles
+constexpr int WS = 256;            // row stride of a weight chunk
+constexpr int HC = 128;            // residual channels = gate half width this kernel is specialised for
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+struct Lds {
+    float* xt;                     // [KC][XS]   activation chunk, K-major
+    float* wc;                     // [KC][WS]   weight chunk
+    float* ut;                     // [128][XS]  gate output / hidden block, K-major
+};
+__device__ __forceinline__ Lds carve(float* smem) { return {smem, smem + KC * XS, smem + KC * XS + KC * WS}; }
+constexpr size_t LDS_FLOATS = (size_t)KC * XS + (size_t)KC * WS + (size_t)HC * XS;
+
+// acc[i] += X[m0 .. m0+32)[chunk] * W[chunk][ncol[i] .. ncol[i]+32)  for the whole KC chunk
+template <int NT>
+__device__ __forceinline__ void mfma_chunk(f16v (&acc)[NT], const float* xt, int m0, const float* wc, const int (&ncol)[NT], int lane) {
+    const int kl = lane >> 5, jl = lane & 31;
+#pragma unroll 4
+    for (int ks = 0; ks < KC / 2; ++ks) {
+        const float a = xt[(2 * ks + kl) * XS + m0 + jl];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const float b = wc[(2 * ks + kl) * WS + ncol[i] + jl];
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+        }
+    }
+}
+
+// weight chunk: rows [k0, k0 + KC) x columns [c0, c0 + 256) of a K-major matrix [nrows][ld] -> wc (zeros outside)
+__device__ __forceinline__ void load_w_chunk(float* wc, const float* __restrict__ W, int ld, int nrows, int ncols, int k0, int c0, int tid) {
+    const int row = tid >> 3, col0 = (tid & 7) * 32;
+    const int k = k0 + row;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = c0 + col0 + 4 * q;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < nrows && c + 3 < ncols) v = *reinterpret_cast<const float4*>(W + (size_t)k * ld + c);
+        else if (k < nrows) {
+            if (c < ncols) v.x = W[(size_t)k * ld + c];
+            if (c + 1 < ncols) v.y = W[(size_t)k * ld + c + 1];
+            if (c + 2 < ncols) v.z = W[(size_t)k * ld + c + 2];
+        }
+        *reinterpret_cast<float4*>(wc + row * WS + col0 + 4 * q) = v;
+    }
+}
+
+__device__ __forceinline__ int acc_row(int v, int lane) { return 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3); }
+
+struct LayerArgs {
+    const float* Hin; float* Hout; float* Skip;        // (B, T, 128), (B, T, 128), (B, T, K)
+    const float* c_up;                                  // (B, T, cin) or null
+    const float* zbias; long long zb_bstride;           // per utterance [256]: conv bias (+ Wg g), this layer
+    const float *w_in, *w_os, *b_os;                    // K-major [kw*128 + cin][256], [128][nosp], [nosp]
+    long long T; int tiles_per_utt, d, kw, cin, K, nosp;
+};
+
+__global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Lds s = carve(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / a.tiles_per_utt;
+    const long long t0 = (long long)(blockIdx.x % a.tiles_per_utt) * TM;
+    const int rb = wave & 1, cb = wave >> 1;
+    const int m0 = 32 * rb;
+    const float* Hin = a.Hin + (size_t)b * a.T * HC;
+    const int Kin = a.kw * HC + a.cin;
+    const int nchunk = (Kin + KC - 1) / KC;
+
+    // ---- GEMM1: Z = [taps | c] W_in -----------------------------------------------------------------------------------
+    f16v acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+    const int ncol1[4] = {64 * cb, 64 * cb + 32, HC + 64 * cb, HC + 64 * cb + 32};      // tanh tiles, sigmoid tiles of the same channels
+    for (int kc = 0; kc < nchunk; ++kc) {
+        {   // activation chunk -> xt (K-major): thread = (time row m, eight K values)
+            const int m = tid >> 2, sub = tid & 3;
+            const long long t = t0 + m;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            if (t < a.T) {
+                if (kc < 4 * a.kw) {                                   // tap j of the dilated conv (oldest first, conv.py:55-61)
+                    const int j = kc >> 2, ch0 = 32 * (kc & 3) + 8 * sub;
+                    const long long tt = t - (long long)(a.kw - 1 - j) * a.d;
+                    if (tt >= 0) {
+                        const float4 p = *reinterpret_cast<const float4*>(Hin + (size_t)tt * HC + ch0);
+                        const float4 q = *reinterpret_cast<const float4*>(Hin + (size_t)tt * HC + ch0 + 4);
+                        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+                    }
+                } else if (a.c_up) {                                   // local conditioning row c[t] (modules.py:141-144)
+                    const int c0 = 32 * (kc - 4 * a.kw) + 8 * sub;
+                    const float* cr = a.c_up + ((size_t)b * a.T + t) * a.cin;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (c0 + e < a.cin) v[e] = cr[c0 + e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s.xt[(8 * sub + e) * XS + m] = v[e];
+        }
+        load_w_chunk(s.wc, a.w_in, 256, Kin, 256, kc * KC, 0, tid);
+        __syncthreads();
+        mfma_chunk<4>(acc, s.xt, m0, s.wc, ncol1, lane);
+        __syncthreads();
+    }
+    // ---- bias (+ global conditioning), tanh . sigmoid -> U tile, K-major ---------------------------------------------------
+    {
+        const float* zb = a.zbias + (size_t)b * a.zb_bstride;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = 64 * cb + 32 * j + (lane & 31);
+            const float za = zb[ch], zg = zb[HC + ch];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float x = acc[j][v] + za, g = acc[2 + j][v] + zg;
+                s.ut[ch * XS + m0 + acc_row(v, lane)] = tanhf(x) * (1.0f / (1.0f + expf(-g)));      // modules.py:152-154
+            }
+        }
+    }
+    __syncthreads();
+    // ---- GEMM2: [out | skip] = U [W_out | W_skip], in column blocks of 256 ---------------------------------------------------
+    const int ntot = HC + a.K;
+    for (int c0 = 0; c0 < ntot; c0 += 256) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+        const int ncol2[4] = {128 * cb, 128 * cb + 32, 128 * cb + 64, 128 * cb + 96};
+        for (int kc = 0; kc < HC / KC; ++kc) {
+            load_w_chunk(s.wc, a.w_os, a.nosp, HC, ntot, kc * KC, c0, tid);
+            __syncthreads();
+            mfma_chunk<4>(acc, s.ut + kc * KC * XS, m0, s.wc, ncol2, lane);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gc = c0 + 128 * cb + 32 * i + (lane & 31);
+            if (gc >= ntot) continue;
+            const float bias = a.b_os[gc];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const long long t = t0 + m0 + acc_row(v, lane);
+                if (t >= a.T) continue;
+                if (gc < HC) {                                           // (out + residual) * sqrt(0.5), modules.py:157-162
+                    a.Hout[((size_t)b * a.T + t) * HC + gc] = (acc[i][v] + bias + Hin[(size_t)t * HC + gc]) * 0.70710678118654752440f;
+                } else {                                                 // skips += s, wavenet.py:196-198
+                    float* sp = a.Skip + ((size_t)b * a.T + t) * a.K + (gc - HC);
+                    *sp += acc[i][v] + bias;
+                }
+            }
+        }
+    }
+}
+
+struct HeadArgs {
+    const float* Skip; float* out;                      // (B, T, K) -> (B, O, T)
+    const float *w_h1, *b_h1, *w_h2, *b_h2;             // K-major [K][kp], [kp], [K][op], [op]
+    long long T; int tiles_per_utt, K, kp, O, op;
+    float scale;
+};
+
+__global__ void __launch_bounds__(FT, 2) wnv_fwd_head_kernel(const HeadArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const Lds s = carve(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / a.tiles_per_utt;
+    const long long t0 = (long long)(blockIdx.x % a.tiles_per_utt) * TM;
+    const int rb = wave & 1, cb = wave >> 1, m0 = 32 * rb;
+    f16v oacc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) oacc[i][v] = 0.f;
+    const int ncolo[4] = {128 * cb, 128 * cb + 32, 128 * cb + 64, 128 * cb + 96};
+    for (int hb = 0; hb < a.K / HC; ++hb) {                  // hidden columns [128 hb, 128 hb + 128)
+        f16v hacc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) hacc[i][v] = 0.f;
+        const int ncolh[2] = {64 * cb, 64 * cb + 32};
+        for (int kc = 0; kc < a.K / KC; ++kc) {
+            {   // relu(skips * sqrt(1/L)) chunk (wavenet.py:200-203), K-major
+                const int m = tid >> 2, sub = tid & 3;
+                const long long t = t0 + m;
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+                if (t < a.T) {
+                    const float* sp = a.Skip + ((size_t)b * a.T + t) * a.K + kc * KC + 8 * sub;
+                    const float4 p = *reinterpret_cast<const float4*>(sp), q = *reinterpret_cast<const float4*>(sp + 4);
+                    v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s.xt[(8 * sub + e) * XS + m] = fmaxf(v[e] * a.scale, 0.f);
+            }
+            load_w_chunk(s.wc, a.w_h1, a.kp, a.K, a.K, kc * KC, HC * hb, tid);
+            __syncthreads();
+            mfma_chunk<2>(hacc, s.xt, m0, s.wc, ncolh, lane);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                        // + bias, ReLU -> hidden block, K-major
+            const int hc = 64 * cb + 32 * j + (lane & 31);
+            const float bias = a.b_h1[HC * hb + hc];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) s.ut[hc * XS + m0 + acc_row(v, lane)] = fmaxf(hacc[j][v] + bias, 0.f);
+        }
+        __syncthreads();
+        for (int kc = 0; kc < HC / KC; ++kc) {               // out += hidden block . W_h2[rows of the block]
+            load_w_chunk(s.wc, a.w_h2 + (size_t)HC * hb * a.op, a.op, HC, a.O, kc * KC, 0, tid);
+            __syncthreads();
+            mfma_chunk<4>(oacc, s.ut + kc * KC * XS, m0, s.wc, ncolo, lane);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int o = 128 * cb + 32 * i + (lane & 31);
+        if (o >= a.O) continue;
+        const float bias = a.b_h2[o];
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const long long t = t0 + m0 + acc_row(v, lane);
+            if (t < a.T) a.out[((size_t)b * a.O + o) * a.T + t] = oacc[i][v] + bias;
+        }
+    }
+}
+
+// first_conv (wavenet.py:192): x (B, cin1, T) -> H (B, T, 128)
+__global__ void wnv_fwd_first_kernel(const float* __restrict__ x, const float* __restrict__ wf, const float* __restrict__ bf,
+                                     float* __restrict__ H, int cin1, long long T, long long n) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const int r = (int)(idx % HC);
+    const long long bt = idx / HC, b = bt / T, t = bt % T;
+    float acc = bf[r];
+    const float* xb = x + (size_t)b * cin1 * T + t;
+    for (int k = 0; k < cin1; ++k) acc = fmaf(wf[(size_t)k * HC + r], xb[(size_t)k * T], acc);
+    H[idx] = acc;
+}
+
+// F.softmax(x, dim=1) in place on (B, O, T) (wavenet.py:211)
+__global__ void wnv_fwd_softmax_kernel(float* __restrict__ out, int O, long long T, long long n) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    const long long b = idx / T, t = idx % T;
+    float* p = out + (size_t)b * O * T + t;
+    float mx = -INFINITY;
+    for (int o = 0; o < O; ++o) mx = fmaxf(mx, p[(size_t)o * T]);
+    float sum = 0.f;
+    for (int o = 0; o < O; ++o) sum += expf(p[(size_t)o * T] - mx);
+    for (int o = 0; o < O; ++o) p[(size_t)o * T] = expf(p[(size_t)o * T] - mx) / sum;
+}
+
+}  // namespace
+
+const char* wnv_forward_why_not(const WnvModelDev& m) {
+    if (m.R != HC || m.G != 2 * HC) return "needs residual_channels == 128 and gate_channels == 256";
+    if (m.K % HC != 0) return "needs skip_out_channels to be a multiple of 128";
+    if (m.O > 256) return "needs out_channels <= 256";
+    if (m.Rp != m.R) return "padded residual width";
+    return nullptr;
+}
+
+size_t wnv_forward_scratch_floats(const WnvModelDev& m, int B, long long T) {
+    return (size_t)B * T * (2 * HC + m.K);
+}
+
+hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_host, const float* d_W, const WnvForwardArgs& a,
+                              hipStream_t s) {
+    const long long T = a.T;
+    const int B = a.B;
+    float* H0 = a.scratch;
+    float* H1 = H0 + (size_t)B * T * HC;
+    float* Skip = H1 + (size_t)B * T * HC;
+    hipError_t e = hipMemsetAsync(Skip, 0, (size_t)B * T * m.K * sizeof(float), s);
+    if (e != hipSuccess) return e;
+    {
+        const long long n = (long long)B * T * HC;
+        hipLaunchKernelGGL(wnv_fwd_first_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.x, d_W + m.w_first, d_W + m.b_first,
+                           H0, m.cin1, T, n);
+    }
+    const int tiles = (int)((T + TM - 1) / TM);
+    const size_t lds = LDS_FLOATS * sizeof(float);
+    e = hipFuncSetAttribute((const void*)wnv_fwd_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)wnv_fwd_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    float *in = H0, *out = H1;
+    for (int l = 0; l < m.L; ++l) {
+        const WnvLayerDev& Ld = layers_host[l];
+        LayerArgs la{};
+        la.Hin = in; la.Hout = out; la.Skip = Skip; la.c_up = m.cin > 0 ? a.c_up : nullptr;
+        la.zbias = a.zbias + (size_t)l * m.Gp; la.zb_bstride = a.zbias_bstride;
+        la.w_in = d_W + Ld.w_in; la.w_os = d_W + Ld.w_os; la.b_os = d_W + Ld.b_os;
+        la.T = T; la.tiles_per_utt = tiles; la.d = Ld.dilation; la.kw = m.kw; la.cin = m.cin; la.K = m.K; la.nosp = m.NOSp;
+        hipLaunchKernelGGL(wnv_fwd_layer_kernel, dim3((unsigned)(B * tiles)), dim3(FT), lds, s, la);
+        std::swap(in, out);
+    }
+    HeadArgs ha{};
+    ha.Skip = Skip; ha.out = a.out; ha.w_h1 = d_W + m.w_h1; ha.b_h1 = d_W + m.b_h1; ha.w_h2 = d_W + m.w_h2; ha.b_h2 = d_W + m.b_h2;
+    ha.T = T; ha.tiles_per_utt = tiles; ha.K = m.K; ha.kp = m.Kp; ha.O = m.O; ha.op = m.Op; ha.scale = m.skip_scale;
+    hipLaunchKernelGGL(wnv_fwd_head_kernel, dim3((unsigned)(B * tiles)), dim3(FT), lds, s, ha);
+    if (a.softmax) {
+        const long long n = (long long)B * T;
+        hipLaunchKernelGGL(wnv_fwd_softmax_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.out, m.O, T, n);
+    }
+    return hipGetLastError();
+}

@@ -16,6 +16,7 @@
 #include "wnv_internal.h"
 #include "wnv_store.h"
 #include "wnv_ring.h"
+#include "wnv_forward.h"
 
 #include "wnv_hostutil.h"
 
@@ -36,7 +37,7 @@ struct wnv_engine {
     long long embed_off = -1;          // inside d_W
     int64_t core_weights = 0;          // unpadded parameter count of the sample-loop network (with biases)
     int64_t core_macs = 0;
-    Scratch ring, zbias, upA, upB;
+    Scratch ring, zbias, upA, upB, fwd;
     WnvRingState* ring_state = nullptr;   // pipelined kernel (wnv_ring.hip), built lazily
 };
 
@@ -179,7 +180,7 @@ extern "C" wnv_status wnv_destroy(wnv_handle h) {
     if (!h) return WNV_OK;
     DeviceGuard g(h->device);
     free_dev(h);
-    h->ring.release(); h->zbias.release(); h->upA.release(); h->upB.release();
+    h->ring.release(); h->zbias.release(); h->upA.release(); h->upB.release(); h->fwd.release();
     delete h;
     return WNV_OK;
 }
@@ -188,7 +189,7 @@ extern "C" wnv_status wnv_reset(wnv_handle h) {
     if (!h) return fail(WNV_ERR_INVALID_ARG, "handle is NULL");
     DeviceGuard g(h->device);
     HIP_TRY(hipDeviceSynchronize());
-    h->ring.release(); h->zbias.release(); h->upA.release(); h->upB.release();
+    h->ring.release(); h->zbias.release(); h->upA.release(); h->upB.release(); h->fwd.release();
     return WNV_OK;
 }
 
@@ -398,6 +399,35 @@ extern "C" wnv_status wnv_upsample(wnv_handle h, const float* c_in, int32_t B, i
         cur = dst; which ^= 1;
         Tcur *= sc;
     }
+    return WNV_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// teacher-forced batch evaluation
+// ------------------------------------------------------------------------------------------------
+extern "C" wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* a) {
+    if (!h || !a) return fail(WNV_ERR_INVALID_ARG, "NULL handle or args");
+    if (!h->packed) return fail(WNV_ERR_NOT_LOADED, "weights are not loaded");
+    const WnvModelDev& m = h->m;
+    if (a->B <= 0 || a->T <= 0 || a->T > 0x7fffffffLL) return fail(WNV_ERR_INVALID_ARG, "B and T must be positive (T < 2^31)");
+    if (!a->x || !a->out) return fail(WNV_ERR_INVALID_ARG, "x / out is NULL");
+    if (m.cin > 0 && !a->c_up) return fail(WNV_ERR_INVALID_ARG, "model has local conditioning but c_up is NULL");
+    if (m.cin == 0 && a->c_up) return fail(WNV_ERR_INVALID_ARG, "c_up given but the model has no local conditioning");
+    if (m.gin > 0 && !a->g && !a->g_ids) return fail(WNV_ERR_INVALID_ARG, "model has global conditioning but neither g nor g_ids is given");
+    if (m.gin == 0 && (a->g || a->g_ids)) return fail(WNV_ERR_INVALID_ARG, "g given but the model has no global conditioning");
+    if (const char* why = wnv_forward_why_not(m)) return fail(WNV_ERR_UNSUPPORTED, "the MFMA forward kernel does not cover this configuration: %s", why);
+    DeviceGuard g(h->device);
+    hipStream_t s = (hipStream_t)a->stream;
+    const bool has_g = m.gin > 0;
+    const int Bz = has_g ? a->B : 1;
+    HIP_TRY(h->zbias.ensure((size_t)Bz * m.L * m.Gp * sizeof(float)));
+    HIP_TRY(wnv_launch_zbias(m, h->d_layers, h->d_W, has_g ? a->g : nullptr, (has_g && !a->g) ? (const long long*)a->g_ids : nullptr,
+                             h->embed_off >= 0 ? h->d_W + h->embed_off : nullptr, Bz, (float*)h->zbias.p, s));
+    HIP_TRY(h->fwd.ensure(wnv_forward_scratch_floats(m, a->B, a->T) * sizeof(float)));
+    WnvForwardArgs fa{};
+    fa.B = a->B; fa.T = a->T; fa.x = a->x; fa.c_up = a->c_up; fa.zbias = (const float*)h->zbias.p;
+    fa.zbias_bstride = has_g ? (long long)m.L * m.Gp : 0; fa.scratch = (float*)h->fwd.p; fa.out = a->out; fa.softmax = a->softmax;
+    HIP_TRY(wnv_launch_forward(m, h->layers.data(), h->d_W, fa, s));
     return WNV_OK;
 }
 

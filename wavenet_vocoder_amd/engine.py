@@ -140,6 +140,18 @@ class Engine:
                                       _stream(c.device)))
         return out
 
+    def forward(self, x: torch.Tensor, c_up=None, g=None, g_ids=None, softmax: bool = False) -> torch.Tensor:
+        """Teacher-forced batch evaluation on the device (wnv_forward, f32 MFMA): x (B, Cin, T) -> (B, out_channels, T).
+        Raises NotImplementedError for shapes the MFMA path does not cover."""
+        require_gpu_tensor(x, "x")
+        x = x.detach().float().contiguous()
+        B, _, T = x.shape
+        out = torch.empty(B, self.cfg.out_channels, T, device=self.device, dtype=torch.float32)
+        a = _lib.ForwardArgs(B=B, T=T, x=_ptr(x), c_up=_ptr(c_up), g=_ptr(g), g_ids=_ptr(g_ids), out=out.data_ptr(),
+                             softmax=int(bool(softmax)), stream=_stream(self.device))
+        check(_lib.lib().wnv_forward(self._h, C.byref(a)))
+        return out
+
     def generate(self, *, B: int, T: int, c_up=None, g=None, g_ids=None, initial=None, teacher=None,
                  noise=None, seed: int = 0, softmax: bool = True, quantize: bool = True,
                  want_params: bool = False, want_index: bool = False, kernel: int = 0):

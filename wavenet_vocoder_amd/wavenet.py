@@ -64,6 +64,7 @@ class WaveNet(nn.Module):
         self.output_distribution = output_distribution
         self.kernel_size = kernel_size
         self.layers, self.stacks = layers, stacks
+        self.residual_channels, self.gate_channels, self.skip_out_channels = residual_channels, gate_channels, skip_out_channels
         assert layers % stacks == 0
         per_stack = layers // stacks
         self.first_conv = Conv1d1x1(1 if scalar_input else out_channels, residual_channels)
@@ -131,9 +132,26 @@ class WaveNet(nn.Module):
 
     def forward(self, x, c=None, g=None, softmax=False):
         """Teacher-forced batch evaluation (B,C,T) -> (B,out_channels,T), reference wavenet.py:164-213.
-        torch ops on whatever device the module lives on; it is the online==offline parity oracle
-        (reference tests/test_model.py:147-366) and not part of the accelerated path."""
+
+        On a GPU, in eval mode and without autograd, the L gated layers run as hand-written f32-MFMA GEMM kernels
+        (``wnv_forward``, csrc/wnv_forward.hip) for the shapes they cover; everything else
+        (CPU modules -- the online == offline parity oracle of the tests --, training, odd channel counts) evaluates the
+        same graph with torch ops."""
         B, _, T = x.size()
+        if (x.is_cuda and not self.training and not torch.is_grad_enabled()
+                and self.residual_channels == 128 and self.gate_channels == 256
+                and self.skip_out_channels % 128 == 0 and self.out_channels <= 256):
+            eng = self._get_engine()
+            c_up = None
+            if c is not None:
+                c_up = eng.upsample(c, T_expected=T) if self.upsample_net is not None else c.transpose(1, 2).contiguous()
+            g_ids = g_feat = None
+            if g is not None:
+                if self.embed_speakers is not None:
+                    g_ids = g.view(B).long().contiguous()
+                else:
+                    g_feat = g.reshape(B, -1).float().contiguous()
+            return eng.forward(x, c_up=c_up, g=g_feat, g_ids=g_ids, softmax=softmax)
         if g is not None and self.embed_speakers is not None:
             g = self.embed_speakers(g.view(B, -1)).transpose(1, 2)
             assert g.dim() == 3
