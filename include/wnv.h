@@ -220,6 +220,46 @@ typedef struct wnv_post_args {
 } wnv_post_args;
 wnv_status wnv_postprocess(int32_t device, const wnv_post_args* args);
 
+/* ---- mel front end ------------------------------------------------------------
+ * Replaces audio.logmelspectrogram (audio.py:101-109: librosa.stft -> |D| -> librosa.filters.mel -> log10(max(., 1e-10)))
+ * and the per-bin StandardScaler.transform of preprocess_normalize.py:44, i.e. what turns a waveform into the
+ * "*-feats.npy" rows the synthesis path takes as `c` (datasets/wavallin.py:62).  librosa / scikit-learn are the
+ * reference's un-vendored dependencies (setup.py:22-26); the engine implements their published definitions
+ * (periodic Hann window centred in the frame, center=True framing with reflect / zero padding, Slaney mel scale with
+ * unit-area triangular filters).  Fields mirror hparams.py:32-44. */
+typedef struct wnv_mel_config {
+    int32_t sample_rate;       /* hparams.sample_rate                                                       */
+    int32_t fft_size;          /* hparams.fft_size: a power of two in [64, 4096]                            */
+    int32_t hop_size;          /* audio.get_hop_size()                                                      */
+    int32_t win_length;        /* audio.get_win_length() <= fft_size                                        */
+    int32_t num_mels;          /* hparams.num_mels                                                          */
+    float   fmin, fmax;        /* hparams.fmin / fmax; fmax <= 0 means sample_rate / 2                      */
+    int32_t pad_mode;          /* 0 "constant" (zeros), 1 "reflect" (logmelspectrogram's default)           */
+    float   floor;             /* the 1e-10 of audio.py:108; <= 0 selects 1e-10                             */
+    int32_t reserved[4];
+} wnv_mel_config;
+typedef struct wnv_mel* wnv_mel_handle;
+/* device < 0 creates a host-only handle (filterbank introspection via wnv_mel_basis; wnv_logmel refuses it). */
+wnv_status wnv_mel_create(const wnv_mel_config* cfg, int32_t device, wnv_mel_handle* out);   /* synchronous */
+wnv_status wnv_mel_destroy(wnv_mel_handle h);
+/* StandardScaler.mean_ / scale_ (host, num_mels each): out = (logmel - mean) / scale.  Synchronous. */
+wnv_status wnv_mel_set_scaler(wnv_mel_handle h, const float* mean, const float* scale);
+/* Number of frames librosa.stft(center=True) yields for n samples: 1 + n / hop_size; -1 on bad arguments. */
+int64_t wnv_mel_frames(const wnv_mel_config* cfg, int64_t n);
+/* The filterbank the engine uses, host (num_mels, fft_size / 2 + 1) float32 = librosa.filters.mel(...). */
+wnv_status wnv_mel_basis(wnv_mel_handle h, float* host_out);
+typedef struct wnv_logmel_args {
+    int32_t B;
+    int64_t n;                 /* samples per utterance                                                     */
+    int64_t wav_stride;        /* floats between utterances (0 = n)                                         */
+    const float* wav;          /* device (B, n)                                                             */
+    float* out;                /* device (B, frames, num_mels) [feats layout] or (B, num_mels, frames)      */
+    int32_t transpose;         /* 1: (B, num_mels, frames) = what logmelspectrogram itself returns          */
+    int32_t normalize;         /* 1: apply the scaler (needs wnv_mel_set_scaler)                            */
+    void* stream;
+} wnv_logmel_args;
+wnv_status wnv_logmel(wnv_mel_handle h, const wnv_logmel_args* args);
+
 /* ---- misc --------------------------------------------------------------------------------------- */
 const char* wnv_last_error(void);
 int32_t wnv_abi_version(void);

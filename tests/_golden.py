@@ -8,7 +8,7 @@ import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-CASE_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "layers.npz")
+CASE_NAMES = sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("layers.npz", "mel_preset.npz"))
 
 
 class Case:

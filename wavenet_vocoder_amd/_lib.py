@@ -10,7 +10,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-__all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "ForwardArgs", "LIB_PATH",
+__all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "ForwardArgs", "MelConfig", "LogmelArgs", "LIB_PATH",
            "WNV_ABI_VERSION", "DIST", "UPSAMPLE"]
 
 WNV_ABI_VERSION = 1
@@ -76,6 +76,21 @@ class PostArgs(C.Structure):
     ]
 
 
+class MelConfig(C.Structure):
+    _fields_ = [
+        ("sample_rate", C.c_int32), ("fft_size", C.c_int32), ("hop_size", C.c_int32), ("win_length", C.c_int32),
+        ("num_mels", C.c_int32), ("fmin", C.c_float), ("fmax", C.c_float), ("pad_mode", C.c_int32), ("floor", C.c_float),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+class LogmelArgs(C.Structure):
+    _fields_ = [
+        ("B", C.c_int32), ("n", C.c_int64), ("wav_stride", C.c_int64), ("wav", C.c_void_p), ("out", C.c_void_p),
+        ("transpose", C.c_int32), ("normalize", C.c_int32), ("stream", C.c_void_p),
+    ]
+
+
 class GluConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("residual_channels", "gate_channels", "kernel_size",
                                          "skip_out_channels", "cin_channels", "gin_channels", "dilation",
@@ -107,6 +122,12 @@ _PROTOS = {
     "wnv_glu_destroy": (C.c_int, [C.c_void_p]),
     "wnv_postprocess": (C.c_int, [C.c_int32, C.POINTER(PostArgs)]),
     "wnv_forward": (C.c_int, [C.c_void_p, C.POINTER(ForwardArgs)]),
+    "wnv_mel_create": (C.c_int, [C.POINTER(MelConfig), C.c_int32, C.POINTER(C.c_void_p)]),
+    "wnv_mel_destroy": (C.c_int, [C.c_void_p]),
+    "wnv_mel_set_scaler": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "wnv_mel_frames": (C.c_int64, [C.POINTER(MelConfig), C.c_int64]),
+    "wnv_mel_basis": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "wnv_logmel": (C.c_int, [C.c_void_p, C.POINTER(LogmelArgs)]),
     "wnv_bytes_per_step": (C.c_int64, [C.c_void_p, C.c_int32]),
     "wnv_macs_per_sample": (C.c_int64, [C.c_void_p]),
 }
