@@ -75,6 +75,23 @@ def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0):
             "all_threads_kSamples_s": {str(k): round(v, 4) for k, v in results.items()}}
 
 
+def describe(kw):
+    """One-line shape of a tests/_configs.py entry, e.g. 'L24/S4 R128/G256/K128 O30 10-mix MoL, 80-mel + ConvInUpsample x256'."""
+    O = kw["out_channels"]
+    if not kw.get("scalar_input", False):
+        head = f"O{O} softmax (one-hot input)"
+    elif kw.get("output_distribution", "Logistic") == "Logistic":
+        head = f"O{O} {O // 3}-mix MoL"
+    else:
+        head = f"O{O} Gaussian"
+    s = (f"L{kw['layers']}/S{kw['stacks']} R{kw['residual_channels']}/G{kw['gate_channels']}/K{kw['skip_out_channels']} {head}")
+    if kw.get("cin_channels", -1) > 0:
+        s += f", {kw['cin_channels']}-mel + ConvInUpsample x256"
+    if kw.get("gin_channels", -1) > 0:
+        s += f", speaker embedding gin={kw['gin_channels']}"
+    return s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,8 +181,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded N(0,1) mel, random-init weights of the egs/mol architecture, in-kernel Philox noise)",
-            "config": {"workload": f"{name}: L24/S4 R128/G256/K128 O30 10-mix MoL, 80-mel + ConvInUpsample x256, "
-                                   f"B={B} utterances/GPU x T={T} samples", "batch_per_gpu": B, "T": T,
+            "config": {"workload": f"{name}: {describe(kw)}, B={B} utterances/GPU x T={T} samples", "batch_per_gpu": B, "T": T,
                        "kernel": "auto" if args.kernel == 0 else ("generic" if args.kernel == 1 else "ring"),
                        "parallelism": f"utterance-sharded x{world}"},
             "kSamples_per_s_per_gpu": round(value / world, 3),

@@ -277,3 +277,79 @@ def test_ring_mulaw256_intree_preset_properties():
     assert torch.equal(solo[0], full[3, :, :T2]), "batch members must be independent"
     gen, _, idx1 = eng.generate(B=B, T=256, c_up=c_up[:, :256].contiguous(), noise=tape[:256].contiguous(), want_index=True, kernel=1)
     assert (idx[:, :256] == idx1).float().mean().item() > 0.5
+
+
+# ---- skip_out_channels 256 / 512: several skip passes per stage, one head workgroup per 128 hidden units -----------------
+@pytest.mark.parametrize("name", ["cfg1_mulaw256", "cfg4_mol_multispeaker"])
+def test_ring_wide_skip_baseline_configs_vs_oracle(name):
+    """BASELINE.json's cfg1 (one-hot, 256 skip channels: two head parts) and cfg4 (MoL + speaker embedding, 512 skip channels:
+    four head parts, two skip passes streamed) at full size: teacher-forced head outputs against the oracle."""
+    from tests.test_gpu_configs import teacher
+    kw = CONFIGS[name]
+    B, T = 3, 256
+    m = build(name)
+    o = Oracle(oracle_config(kw), m.state_dict())
+    c, gids = inputs(name, B, T)
+    x = teacher(kw, B, T)
+    scalar = kw.get("scalar_input", False)
+    tape = make_noise_tape(T, B, scalar_input=scalar, output_distribution=kw.get("output_distribution", "Logistic"),
+                           out_channels=kw["out_channels"], generator=torch.Generator().manual_seed(2))
+    torch.set_num_threads(8)
+    want, wparams = o.incremental_forward(test_inputs=x, c=c, g=gids, T=T, softmax=True, quantize=False, noise=tape,
+                                          return_params=True)
+    eng = m.to("cuda")._get_engine()
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    gi = None if gids is None else gids[:, 0].cuda()
+    res = {}
+    for k in (1, 2):
+        res[k] = eng.generate(B=B, T=T, c_up=c_up, g_ids=gi, teacher=x.transpose(1, 2).contiguous().cuda(), noise=tape.cuda(),
+                              softmax=True, quantize=False, want_params=True, kernel=k)
+    err = (res[2][1].cpu() - wparams).abs().max().item()
+    assert err < TOL, f"{name}: ring head outputs differ from the oracle by {err}"
+    assert (res[2][1] - res[1][1]).abs().max().item() < 3e-5               # vs the generic kernel
+    if scalar:
+        assert ((res[2][0].cpu() - want).abs() < TOL).float().mean().item() > 0.98
+    else:
+        assert (res[2][0].cpu() - want).abs().max().item() < TOL           # probabilities
+
+
+@pytest.mark.parametrize("K,B", [(256, 1), (256, 11), (512, 2), (512, 8), (512, 16), (512, 24)])
+def test_ring_wide_skip_equals_generic_kernel(K, B):
+    kw = dict(out_channels=30, layers=6, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=K,
+              kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=80)
+    torch.manual_seed(31)
+    m = tame_head_(wnv.WaveNet(**kw).eval()).to("cuda")
+    eng = m._get_engine()
+    T = 384
+    g = torch.Generator().manual_seed(B)
+    c_up = torch.randn(B, T, 80, generator=g).cuda()
+    tape = tape_for(kw, T, B, 3).cuda()
+    x = torch.tanh(torch.randn(B, 128, 1, generator=g) * 0.5).cuda()
+    o1, p1, _ = run(eng, 1, B, T, c_up, x, tape)
+    o2, p2, _ = run(eng, 2, B, T, c_up, x, tape)
+    assert (p1[:, :, :128] - p2[:, :, :128]).abs().max().item() < 3e-5
+    assert (o1 - o2).abs().max().item() < 1e-3
+    o3, _, _ = run(eng, 2, B, T, c_up, x, tape)
+    assert torch.equal(o2, o3)
+
+
+def test_ring_wide_skip_onehot_free_run_and_properties():
+    """cfg1 at full size, free running: sampled classes against the generic kernel, determinism, prefix, independence."""
+    name = "cfg1_mulaw256"
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    B, T = 4, 1024
+    c, _ = inputs(name, B, T)
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    tape = cat_tape(T, B, 12).cuda()
+    full, _, idx = eng.generate(B=B, T=T, c_up=c_up, noise=tape, want_index=True, kernel=2)
+    assert torch.equal(full.sum(1), torch.ones(B, T, device="cuda"))
+    again, _, _ = eng.generate(B=B, T=T, c_up=c_up, noise=tape, want_index=True, kernel=2)
+    assert torch.equal(full, again), "determinism"
+    T2 = 256
+    pre, _, _ = eng.generate(B=B, T=T2, c_up=c_up[:, :T2].contiguous(), noise=tape[:T2].contiguous(), kernel=2)
+    assert torch.equal(pre, full[:, :, :T2]), "prefix property"
+    solo, _, _ = eng.generate(B=1, T=T2, c_up=c_up[3:4, :T2].contiguous(), noise=tape[:T2, 3:4].contiguous(), kernel=2)
+    assert torch.equal(solo[0], full[3, :, :T2]), "batch members must be independent"
+    _, _, idx1 = eng.generate(B=B, T=T2, c_up=c_up[:, :T2].contiguous(), noise=tape[:T2].contiguous(), want_index=True, kernel=1)
+    assert (idx[:, :T2] == idx1).float().mean().item() > 0.5

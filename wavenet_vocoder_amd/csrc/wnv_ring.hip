@@ -60,6 +60,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 struct RingParams {
     int n_rings, rstride, S, L, B, T, Tt, upr;
     int K, Kp, O, cin, kw, kpre, nz, dist;
+    int NH, Op;                        // head parts per ring (= K / 128: part j owns hidden units [128 j, 128 j + 128)); partial-output stride
     int pstride;                       // LDS partial stride (floats) = max(256, Kp)
     int hist_floats;
     int allow_fast;                    // same-XCD hand-off through the XCD's L2 (plain stores) when placement allows
@@ -73,6 +74,7 @@ struct RingParams {
     long long zbias_bstride;
     const int *lay_dil, *lay_histoff;
     unsigned long long *xmail, *hmail, *smail;   // chain inputs X[b][S+1][128]; layer inputs H[b][2 (t parity)][S+1][128]; skip sums
+    unsigned long long *omail;                   // head parts j > 0 -> part 0: partial head outputs O[b][NH][Op]
     float *fmail, *pmail;                        // bulk records: stage -> tap workgroup h_l[t]: F[b][L][4 + 128]; tap workgroup -> stage pre_l[t+1]: P[b][L][4 + 256]
     int ring_blocks, tap_parts;                  // blocks [0, ring_blocks) = rings, then tap_parts tap workgroups per layer (part q serves passes q, q + parts, ...)
     int kper, kreg_rows, klds_rows;              // tap workgroup: K rows per wave; of those resident in VGPRs / in LDS (the rest streams)
@@ -199,17 +201,18 @@ __device__ __forceinline__ bool wave_recv(const u64* g, bool active, unsigned ta
 
 // Placement handshake: publish this workgroup's XCC id, read those of the (up to two) workgroups that read what this one
 // sends; true when all share an XCD (and its L2).
-__device__ __forceinline__ bool same_xcd_as(const RingParams& p, int reader_a, int reader_b, int* flag) {
+__device__ __forceinline__ bool same_xcd_as(const RingParams& p, int reader_a, int n_a, int reader_b, int* flag) {
+    // readers: blocks reader_a, reader_a + rstride, ... (n_a of them) and reader_b
     if (threadIdx.x == 0) {
         unsigned x;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
         x = (x & 0xfu) + 1u;
         __hip_atomic_store(p.xcc + blockIdx.x, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool same = true;
-        const int rd[2] = {reader_a, reader_b};
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k <= n_a; ++k) {
+            const int rdk = k < n_a ? reader_a + k * p.rstride : reader_b;
             unsigned y = 0, spins = 0;
-            while ((y = __hip_atomic_load(p.xcc + rd[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+            while ((y = __hip_atomic_load(p.xcc + rdk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
                 if (++spins > SPIN_LIMIT) break;                   // unknown placement: take the placement-independent path
                 __builtin_amdgcn_s_sleep(2);
             }
@@ -321,8 +324,14 @@ struct StageLds {
     float* hh;       // h_l[t], collected for the tap workgroup
     float* pre;      // [256] pre_l[t] from the layer's tap workgroup
     int* flags;
-    float4* wsk;     // [2 rows][4 chunks][512 threads] image of conv1x1_skip (64 KiB; off the chain)
+    float* bsk;      // [512] conv1x1_skip bias
+    float4* wsk;     // [passes in LDS][2 rows][4 chunks][512 threads] image of conv1x1_skip (64 KiB per 128 skip channels; off the chain)
 };
+// conv1x1_skip with K = 128 NK output channels = NK passes over the 128-channel thread mapping.  Passes [0, lds_passes(NK))
+// live in LDS; K = 512: the last stage keeps pass 2 in the registers that hold conv1x1_out elsewhere (its residual output is
+// never used), whatever is left streams from the L2 behind the send (64 KiB per pass and step, off the chain except at the
+// last stage).
+__host__ __device__ constexpr int lds_passes(int NK) { return NK < 2 ? NK : 2; }
 
 __device__ __forceinline__ StageLds carve_stage(float* smem) {
     StageLds s;
@@ -332,10 +341,11 @@ __device__ __forceinline__ StageLds carve_stage(float* smem) {
     s.hh = smem + 24 * ES;
     s.pre = smem + 32 * ES;
     s.flags = reinterpret_cast<int*>(s.pre + GC);
-    s.wsk = reinterpret_cast<float4*>(s.flags + 16);
+    s.bsk = reinterpret_cast<float*>(s.flags + 16);
+    s.wsk = reinterpret_cast<float4*>(s.bsk + 512);
     return s;
 }
-constexpr size_t STAGE_LDS_FLOATS = (size_t)32 * ES + GC + 16 + (size_t)8 * RT * 4;
+__host__ __device__ constexpr size_t stage_lds_floats(int NK) { return (size_t)32 * ES + GC + 16 + 512 + (size_t)lds_passes(NK) * 8 * RT * 4; }
 
 // ---- tap workgroup (one per layer, shared by all rings) -----------------------------------------------------------------
 // Everything of a layer that is known a step ahead -- the dilated conv's older taps and the local-conditioning 1x1,
@@ -512,7 +522,9 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
 // Thread mapping: eight adjacent lanes split the K = 128 contraction (16 floats each), a group of eight lanes owns
 // channels 2og and 2og + 1; reductions are reduce-scatters (first DPP step row_half_mirror, lane j <-> 7 - j, hands
 // lanes 0-3 the sums of channel 2og and lanes 4-7 those of 2og + 1; two quad_perm steps finish).
+template <int NK>
 __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
+    constexpr int NLDS = lds_passes(NK);
     const StageLds s = carve_stage(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ks = tid & 7, og = tid >> 3;                      // K-slice; lane group = channels 2og, 2og + 1
@@ -532,18 +544,23 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
         load_image8(p.w2img + ((size_t)l * 4 + row) * 4 * RT * 4, tid, wm[row]);
         load_image8(p.wnimg + ((size_t)l * 4 + row) * 4 * RT * 4, tid, wn[row]);      // zeros at stage 0
     }
+    const float4* wsk_g = reinterpret_cast<const float4*>(p.wsimg) + (size_t)l * NK * 8 * RT;    // this layer's conv1x1_skip image
 #pragma unroll
-    for (int row = 0; row < 2; ++row) load_image8(p.woimg + ((size_t)l * 2 + row) * 4 * RT * 4, tid, wo[row]);
-    {
-        const float4* ssrc = reinterpret_cast<const float4*>(p.wsimg) + (size_t)l * 8 * RT;
-        for (int c = 0; c < 8; ++c) s.wsk[(size_t)c * RT + tid] = ssrc[(size_t)c * RT + tid];
+    for (int row = 0; row < 2; ++row) {
+        if (NK > NLDS && last_stage)     // K = 512: the last layer's conv1x1_out is never used; its registers hold skip pass NLDS
+            load_image8(reinterpret_cast<const float*>(wsk_g + ((size_t)NLDS * 2 + row) * 4 * RT), tid, wo[row]);
+        else
+            load_image8(p.woimg + ((size_t)l * 2 + row) * 4 * RT * 4, tid, wo[row]);
     }
+    for (int c = 0; c < NLDS * 8; ++c) s.wsk[(size_t)c * RT + tid] = wsk_g[(size_t)c * RT + tid];
     const float bo_r = p.bo[(size_t)l * RC + ch];
-    const float bs_r = p.bskip[(size_t)l * p.Kp + ch];
+    const float bs_r = p.bskip[(size_t)l * p.Kp + ch];                 // passes >= 1 read their bias from LDS (register budget)
+    for (int k = tid; k < RC * NK; k += RT) s.bsk[k] = p.bskip[(size_t)l * p.Kp + k];
     if (tid == 0) s.flags[0] = 0;
     // readers of what this stage sends: the next stage (X, H) and the one behind it (H); the head behind the last stage
+    // (every head part reads the skip sum)
     const int rd1 = ring + (sidx + 1) * p.rstride, rd2 = ring + (sidx + 2 <= p.S ? sidx + 2 : sidx + 1) * p.rstride;
-    const bool fast = same_xcd_as(p, rd1, rd2, s.flags + 1);
+    const bool fast = same_xcd_as(p, rd1, last_stage ? p.NH : 1, rd2, s.flags + 1);
 
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
@@ -671,13 +688,23 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             };
             // skip 1x1, accumulated stage to stage in the reference's layer order (wavenet.py:312)
             auto skip_phase = [&]() {
-                const float m0 = dot16l(s.wsk + (size_t)0 * RT + tid, xu), m1 = dot16l(s.wsk + (size_t)4 * RT + tid, xu);
-                const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + bs_r;
-                float acc = 0.f;
                 bool ok = true;
-                if (sidx > 0)
-                    ok = wave_recv<false>(sm_in, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
-                if (writer && ok) st_granule(sm_out, tag, acc + mine, fast);
+#pragma unroll
+                for (int pp = 0; pp < NK; ++pp) {                               // skip channels 128 pp + ch
+                    float m0, m1;
+                    if (pp < NLDS) {
+                        m0 = dot16l(s.wsk + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(s.wsk + (size_t)(8 * pp + 4) * RT + tid, xu);
+                    } else if (last_stage && pp == NLDS) {
+                        m0 = dot16p(wo[0], xu); m1 = dot16p(wo[1], xu);
+                    } else {                                                    // streams from the L2 (image layout: coalesced 16-B loads)
+                        m0 = dot16l(wsk_g + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(wsk_g + (size_t)(8 * pp + 4) * RT + tid, xu);
+                    }
+                    const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + (pp == 0 ? bs_r : s.bsk[RC * pp + ch]);
+                    float acc = 0.f;
+                    if (sidx > 0 && ok)
+                        ok = wave_recv<false>(sm_in + RC * pp, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
+                    if (writer && ok) st_granule(sm_out + RC * pp, tag, acc + mine, fast);
+                }
                 if (!ok) s.flags[0] = 1;
             };
             // the h recurrence is what the next-but-one stage waits for; only at the last stage the skip sum (the head's
@@ -700,30 +727,124 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     }
 }
 
+// ---- head -----------------------------------------------------------------------------------------------------------
+// skip sum -> ReLU -> 1x1 (K x K) -> ReLU -> 1x1 (O x K) -> sampler -> first_conv of the next step (wavenet.py:313-336).
+// With K = 128 NK skip channels the K x K matrix does not fit one CU, so the head is NK workgroups ("parts"): part j owns
+// hidden units [128 j, 128 j + 128): it reads the whole skip vector, computes its hidden slice (W1 rows in VGPRs, 32 NK
+// floats per thread) and the partial outputs W2[:, 128 j ..] . hidden_j; parts j > 0 send their partials to part 0, which adds
+// them in part order, samples and feeds the ring.  NK = 1 is the single-workgroup head.
 struct HeadLds {
-    float* vs;     // strided relu(skip * scale)
-    float* hid;    // strided hidden
-    float* obuf;   // [128] head output
+    float* vs;     // strided relu(skip * scale), 4 NK K-quarters
+    float* hid;    // strided hidden slice
+    float* obuf;   // [256] head output
     float* vbuf;   // [48]  mixture logit + Gumbel noise, padded with -inf
     int* flags;
 };
+__device__ __forceinline__ HeadLds carve_head(float* smem, int NK) {
+    HeadLds s;
+    s.vs = smem; s.hid = smem + 4 * NK * QS; s.obuf = s.hid + 4 * QS; s.vbuf = s.obuf + 256;
+    s.flags = reinterpret_cast<int*>(s.vbuf + 48);
+    return s;
+}
+__host__ __device__ constexpr size_t head_lds_floats(int NK) { return (size_t)(4 * NK + 4) * QS + 256 + 48 + 16; }
 
 // noise value `idx` of (t, b): from the tape (rng = "replay") or the in-kernel Philox stream
 __device__ __forceinline__ float head_noise(const RingParams& p, int t, int b, int idx, int kind) {
     return p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + idx] : wnv_noise_gen(p.seed, t, b, idx, kind);
 }
 
+// the slice of the output MLP one head part owns: W1 rows [128 part, +128) x K and W2[:, 128 part .. +128) (NW2 row images: rows i,
+// and rows 128 + i for one-hot models)
+template <int NK, int NW2> struct HeadSlice {
+    f2 wh1[NK][16];
+    f2 wh2[NW2][16];
+    float bh1;
+    __device__ __forceinline__ void load(const RingParams& p, int part, int tid, int i) {
+#pragma unroll
+        for (int blk = 0; blk < NK; ++blk) load_image16(p.wh1img + ((size_t)part * NK + blk) * 8 * RT * 4, tid, wh1[blk]);
+#pragma unroll
+        for (int r = 0; r < NW2; ++r) load_image16(p.wh2img + ((size_t)part * 2 + r) * 8 * RT * 4, tid, wh2[r]);
+        bh1 = p.bh1[RC * part + i];
+    }
+};
+
+// skip sum of (b, t) -> s.vs (all parts);  returns false on abort
+template <int NK>
+__device__ __forceinline__ bool head_recv_skip(const RingParams& p, int b, unsigned tag, float* vs, int tid, int lane, int wave) {
+    bool ok = true;
+    if (wave < 2 * NK) {
+        float v = 0.f;
+        ok = wave_recv<false>(p.smail + ((size_t)b * (p.S + 1) + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane);
+        vs[qidx(tid)] = fmaxf(v * p.skip_scale, 0.f);                           // wavenet.py:313-316
+    }
+    return ok;
+}
+// hidden slice (wavenet.py:317-318) into s.hid; needs a barrier before and after
+template <int NK, int NW2>
+__device__ __forceinline__ void head_hidden(const HeadSlice<NK, NW2>& w, const float* vs, float* hid, int q, int i) {
+    float x[32];
+    float acc = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < NK; ++blk) {
+        lds_read32(vs + QS * (4 * blk + q), x);
+        acc += dot32p(w.wh1[blk], x);
+    }
+    const float h1 = fmaxf(quad_allreduce(acc) + w.bh1, 0.f);
+    if (q == 0) hid[qidx(i)] = h1;
+}
+
+// head parts j > 0: hidden slice + partial outputs, sent to part 0
+template <int NK, int NW2>
+__device__ void run_head_part(const RingParams& p, int ring, int part, float* smem) {
+    const HeadLds s = carve_head(smem, NK);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q = lane & 3, i = wave * 16 + (lane >> 2);
+    HeadSlice<NK, NW2> w;
+    w.load(p, part, tid, i);
+    if (tid == 0) s.flags[0] = 0;
+    const bool fast = same_xcd_as(p, ring + p.S * p.rstride, 1, ring + p.S * p.rstride, s.flags + 1);   // read by part 0
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        for (int j = 0; j < p.upr; ++j) {
+            const int b = ring + j * p.n_rings;
+            if (b >= p.B) continue;
+            if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.flags[0] = 1;
+            __syncthreads();
+            head_hidden<NK, NW2>(w, s.vs, s.hid, q, i);
+            __syncthreads();
+            float x[32];
+            lds_read32(s.hid + QS * q, x);
+            u64* om = p.omail + ((size_t)b * p.NH + part) * p.Op;
+#pragma unroll
+            for (int r = 0; r < NW2; ++r) {
+                const float o = quad_allreduce(dot32p(w.wh2[r], x));              // rows i (and 128 + i) of W2, columns of this part
+                if (q == 0 && RC * r + i < p.O) st_granule(om + RC * r + i, tag, o, fast);
+            }
+            if (s.flags[0]) return;                 // uniform: written before the barriers above
+        }
+    }
+}
+
+// part 0 collects the partial outputs of parts 1 .. NH-1 (lanes q == 0 own output row `row`); in part order
+__device__ __forceinline__ bool head_collect(const RingParams& p, int b, unsigned tag, int row, bool active, float& o, int lane) {
+    bool ok = true;
+    for (int part = 1; part < p.NH && ok; ++part) {
+        float v = 0.f;
+        ok = wave_recv<false>(p.omail + ((size_t)b * p.NH + part) * p.Op + row, active, tag, v, p.status, 0x380u + (unsigned)part, lane);
+        o += v;
+    }
+    return ok;
+}
+
+template <int NK>
 __device__ void run_head(const RingParams& p, int ring, float* smem) {
-    HeadLds s;
-    s.vs = smem; s.hid = smem + 4 * QS; s.obuf = smem + 8 * QS; s.vbuf = s.obuf + 128;
-    s.flags = reinterpret_cast<int*>(s.vbuf + 48);
+    const HeadLds s = carve_head(smem, NK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, i = wave * 16 + (lane >> 2);
     const int S1 = p.S + 1;
-    f2 wh1[16], wh2[16];
-    load_image16(p.wh1img, tid, wh1);
-    load_image16(p.wh2img, tid, wh2);
-    const float bh1 = p.bh1[i], bh2 = p.bh2[i];
+    HeadSlice<NK, 1> w;
+    w.load(p, 0, tid, i);
+    const float bh2 = p.bh2[i];
     float wf = 0.f, bf = 0.f;
     if (tid < RC) { wf = p.wfirst[tid]; bf = p.bfirst[tid]; }
     // output distribution (mixture.py:118-156 / :221-270): which head outputs are mean / log-scale
@@ -733,7 +854,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
     const int nchunk = (nmix + 3) >> 2;
     if (tid < 48) s.vbuf[tid] = -INFINITY;
     if (tid == 0) s.flags[0] = 0;
-    const bool fast = same_xcd_as(p, ring, ring + (p.S > 1 ? p.rstride : 0), s.flags + 1);   // h_0 is read by stages 0 and 1
+    const bool fast = same_xcd_as(p, ring, 1, ring + (p.S > 1 ? p.rstride : 0), s.flags + 1);   // h_0 is read by stages 0 and 1
 
     // ---- prologue: the input of step 0 (wavenet.py:283-289, :297-308) ----------------------------------------
     for (int j = 0; j < p.upr; ++j) {
@@ -758,21 +879,16 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
                 if (t + 1 < p.Tt) forced = p.teacher[(size_t)b * p.Tt + t + 1];
             }
             // ---- wait for the accumulated skip vector of (b, t) -----------------------------------------------
-            if (wave < 2) {
-                float v = 0.f;
-                if (!wave_recv<false>(p.smail + ((size_t)b * S1 + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane))
-                    s.flags[0] = 1;
-                s.vs[qidx(tid)] = fmaxf(v * p.skip_scale, 0.f);                  // wavenet.py:313-316
-            }
+            if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.flags[0] = 1;
             __syncthreads();
             stamp(p, b, t, p.S, 1);
-            float x[32];
-            lds_read32(s.vs + QS * q, x);
-            const float h1 = fmaxf(quad_allreduce(dot32p(wh1, x)) + bh1, 0.f);  // wavenet.py:317-318
-            if (q == 0) s.hid[qidx(i)] = h1;
+            head_hidden<NK, 1>(w, s.vs, s.hid, q, i);
             __syncthreads();
+            float x[32];
             lds_read32(s.hid + QS * q, x);
-            const float o = quad_allreduce(dot32p(wh2, x)) + bh2;                 // wavenet.py:319
+            float o = quad_allreduce(dot32p(w.wh2[0], x));                        // wavenet.py:319
+            if (NK > 1 && !head_collect(p, b, tag, i, q == 0 && i < p.O, o, lane)) s.flags[0] = 1;
+            o += bh2;
             if (q == 0 && i < p.O) {
                 s.obuf[i] = o;
                 if (i < nmix) s.vbuf[i] = o + gum;
@@ -816,28 +932,27 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
 struct CatLds {
     float* vs; float* hid; float* obuf; float* nzb; float* vin; float* part; int* ints; float* wfl;
 };
-__device__ __forceinline__ CatLds carve_cat(float* smem) {
+__device__ __forceinline__ CatLds carve_cat(float* smem, int NK) {
     CatLds s;
-    s.vs = smem; s.hid = smem + 4 * QS; s.obuf = smem + 8 * QS; s.nzb = s.obuf + 256; s.vin = s.nzb + 256;
+    s.vs = smem; s.hid = smem + 4 * NK * QS; s.obuf = s.hid + 4 * QS; s.nzb = s.obuf + 256; s.vin = s.nzb + 256;
     s.part = s.vin + 256; s.ints = reinterpret_cast<int*>(s.part + 4 * RC); s.wfl = reinterpret_cast<float*>(s.ints + 16);
     return s;
 }
-constexpr size_t CAT_LDS_FLOATS = (size_t)8 * QS + 3 * 256 + 4 * RC + 16 + (size_t)256 * RC;
+__host__ __device__ constexpr size_t cat_lds_floats(int NK) { return (size_t)(4 * NK + 4) * QS + 3 * 256 + 4 * RC + 16 + (size_t)256 * RC; }
 
+template <int NK>
 __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
-    const CatLds s = carve_cat(smem);
+    const CatLds s = carve_cat(smem, NK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, i = wave * 16 + (lane >> 2);
     const int S1 = p.S + 1, O = p.O;
-    f2 wh1[16], wh2a[16], wh2b[16];
-    load_image16(p.wh1img, tid, wh1);
-    load_image16(p.wh2img, tid, wh2a);
-    load_image16(p.wh2img + (size_t)8 * RT * 4, tid, wh2b);
-    const float bh1 = p.bh1[i], bh2a = p.bh2[i], bh2b = p.bh2[RC + i];
+    HeadSlice<NK, 2> w;
+    w.load(p, 0, tid, i);
+    const float bh2a = p.bh2[i], bh2b = p.bh2[RC + i];
     const float bf = tid < RC ? p.bfirst[tid] : 0.f;
     for (int k = tid; k < O * RC; k += RT) s.wfl[k] = p.wfirst[k];
     if (tid == 0) { s.ints[0] = 0; s.ints[1] = 0; }                  // ints[0] = abort flag, ints[1] = sampled class
-    const bool fast = same_xcd_as(p, ring, ring + (p.S > 1 ? p.rstride : 0), s.ints + 2);
+    const bool fast = same_xcd_as(p, ring, 1, ring + (p.S > 1 ? p.rstride : 0), s.ints + 2);
 
     // first_conv of `dense` (O floats in global memory or LDS) or of the one-hot class `idx`, sent as the input of `tag_next`
     auto send_input = [&](int b, const float* dense, int idx, unsigned tag_next) {
@@ -877,22 +992,20 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
             if (b >= p.B) continue;
             // noise of this step, while the ring works: e ~ Exp(1) per class
             if (tid < O) s.nzb[tid] = head_noise(p, t, b, tid, 2);
-            if (wave < 2) {
-                float v = 0.f;
-                if (!wave_recv<false>(p.smail + ((size_t)b * S1 + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane))
-                    s.ints[0] = 1;
-                s.vs[qidx(tid)] = fmaxf(v * p.skip_scale, 0.f);                  // wavenet.py:313-316
-            }
+            if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.ints[0] = 1;
             __syncthreads();
             stamp(p, b, t, p.S, 1);
-            float x[32];
-            lds_read32(s.vs + QS * q, x);
-            const float h1 = fmaxf(quad_allreduce(dot32p(wh1, x)) + bh1, 0.f);  // wavenet.py:317-318
-            if (q == 0) s.hid[qidx(i)] = h1;
+            head_hidden<NK, 2>(w, s.vs, s.hid, q, i);
             __syncthreads();
+            float x[32];
             lds_read32(s.hid + QS * q, x);
-            const float oa = quad_allreduce(dot32p(wh2a, x)) + bh2a;              // wavenet.py:319, rows i and 128 + i
-            const float ob = quad_allreduce(dot32p(wh2b, x)) + bh2b;
+            float oa = quad_allreduce(dot32p(w.wh2[0], x));                       // wavenet.py:319, rows i and 128 + i
+            float ob = quad_allreduce(dot32p(w.wh2[1], x));
+            if (NK > 1) {
+                if (!head_collect(p, b, tag, i, q == 0 && i < O, oa, lane)) s.ints[0] = 1;
+                if (!head_collect(p, b, tag, RC + i, q == 0 && RC + i < O, ob, lane)) s.ints[0] = 1;
+            }
+            oa += bh2a; ob += bh2b;
             if (q == 0) {
                 if (i < O) { s.obuf[i] = oa; if (p.params_out) p.params_out[((size_t)b * O + i) * p.T + t] = oa; }
                 if (RC + i < O) { s.obuf[RC + i] = ob; if (p.params_out) p.params_out[((size_t)b * O + RC + i) * p.T + t] = ob; }
@@ -924,12 +1037,14 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
     }
 }
 
+template <int NK>
 __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int P = p.S + p.NH;                   // workgroups of one ring: S stages + NH head parts
     // block i -> XCD i % 8 (observed, speed only): with rstride == 8 every workgroup of ring r sits on XCD r
     // tap workgroup k (layer k % L, part k / L) sits in the k-th block that is not part of a live ring: first the slots of
     // unused ring indices (they share an XCD with nothing but each other), then the blocks behind the rings
-    const int free_slots = (p.rstride - p.n_rings) * (p.S + 1);
+    const int free_slots = (p.rstride - p.n_rings) * P;
     if ((int)blockIdx.x >= p.ring_blocks) {
         const int k = free_slots + (int)blockIdx.x - p.ring_blocks;
         run_tap(p, k % p.L, k / p.L, smem);
@@ -942,9 +1057,16 @@ __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
         if (k < p.tap_parts * p.L) run_tap(p, k % p.L, k / p.L, smem);
         return;
     }
-    if (pos < p.S) run_stage(p, ring, pos, smem);
-    else if (p.cin1 > 1) run_head_cat(p, ring, smem);
-    else run_head(p, ring, smem);
+    if (pos < p.S) run_stage<NK>(p, ring, pos, smem);
+    else if (p.cin1 > 1) {
+        if constexpr (NK <= 2) {                // one-hot models with 512 skip channels stay on the generic kernel (why_not)
+            if (pos == p.S) run_head_cat<NK>(p, ring, smem);
+            else run_head_part<NK, 2>(p, ring, pos - p.S, smem);
+        }
+    } else {
+        if (pos == p.S) run_head<NK>(p, ring, smem);
+        else run_head_part<NK, 1>(p, ring, pos - p.S, smem);
+    }
 }
 
 }  // namespace
@@ -970,11 +1092,13 @@ struct WnvRingState {
 static const char* why_not(const wnv_config& c, int B) {
     if (!c.scalar_input && c.out_channels > 256) return "one-hot models need out_channels <= 256";
     if (c.residual_channels != RC || c.gate_channels != GC) return "needs residual_channels == 128 and gate_channels == 256";
-    if (c.skip_out_channels != 128) return "needs skip_out_channels == 128 (head kept in registers)";
+    if (c.skip_out_channels != 128 && c.skip_out_channels != 256 && c.skip_out_channels != 512)
+        return "needs skip_out_channels in {128, 256, 512} (one head workgroup per 128 hidden units)";
+    if (!c.scalar_input && c.skip_out_channels > 256) return "one-hot models need skip_out_channels <= 256";
     if (c.scalar_input && c.out_channels > 128) return "needs out_channels <= 128";
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 512 - (c.kernel_size - 1) * RC) return "too many local-conditioning channels";
-    if (c.layers + 1 > 240) return "too many layers for one ring";
+    if (c.layers + c.skip_out_channels / 128 > 32) return "too many layers for one ring per XCD";
     if (B > 64) return "more than 64 utterances per call";
     return nullptr;
 }
@@ -1006,14 +1130,15 @@ static inline void tid_map(int tid, int& i, int& q) { i = 16 * (tid >> 6) + ((ti
 
 // image of a (rows x 128) matrix M (row-major, M[o][k]) for the (o, q) register mapping:
 // chunk c (0..7) of thread tid = M[row_of(tid)][32q + 4c .. +4]
-static void put_image(std::vector<float>& blob, size_t off, const float* M, int row_offset, int n_rows) {
+// of the 128-column block starting at column col_offset of a row-major matrix with leading dimension ld
+static void put_image(std::vector<float>& blob, size_t off, const float* M, int ld, int row_offset, int n_rows, int col_offset) {
     for (int tid = 0; tid < RT; ++tid) {
         int i, q;
         tid_map(tid, i, q);
         const int row = row_offset + i;
         for (int c = 0; c < 8; ++c)
             for (int e = 0; e < 4; ++e)
-                blob[off + ((size_t)c * RT + tid) * 4 + e] = row < n_rows ? M[(size_t)row * RC + 32 * q + 4 * c + e] : 0.f;
+                blob[off + ((size_t)c * RT + tid) * 4 + e] = row < n_rows ? M[(size_t)row * ld + col_offset + 32 * q + 4 * c + e] : 0.f;
     }
 }
 
@@ -1045,7 +1170,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     st->o_wo = alloc((size_t)L * 8 * RT * 4);
     st->o_bo = alloc((size_t)L * RC);
     st->o_wpre = alloc((size_t)L * st->kpre * GC);
-    st->o_ws = alloc((size_t)L * 8 * RT * 4);
+    const int NK = K / RC;                                          // skip passes per stage = head parts per ring
+    st->o_ws = alloc((size_t)L * NK * 8 * RT * 4);
     st->o_bskip = alloc((size_t)L * Kp);
     std::vector<int> dil(L), hoff(L);
     int hist = 0;
@@ -1097,9 +1223,11 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
             for (int jx = 0; jx < cin; ++jx)
                 for (int o = 0; o < GC; ++o) wp[(size_t)((kw - 1) * RC + jx) * GC + o] = wcc.data[(size_t)o * cin + jx];
         }
-        const HostTensor& ws = T(pfx + "conv1x1_skip.weight");         // (K = 128, G/2, 1)
-        put_row8(blob, st->o_ws + ((size_t)l * 2 + 0) * rowsz, ws.data.data(), 0, 0);
-        put_row8(blob, st->o_ws + ((size_t)l * 2 + 1) * rowsz, ws.data.data(), 0, 1);
+        const HostTensor& ws = T(pfx + "conv1x1_skip.weight");         // (K, G/2, 1): pass pp = skip channels [128 pp, 128 pp + 128)
+        for (int pp = 0; pp < NK; ++pp) {
+            put_row8(blob, st->o_ws + (((size_t)l * NK + pp) * 2 + 0) * rowsz, ws.data.data(), RC * pp, 0);
+            put_row8(blob, st->o_ws + (((size_t)l * NK + pp) * 2 + 1) * rowsz, ws.data.data(), RC * pp, 1);
+        }
         const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
         std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bskip + (size_t)l * Kp);
         dil[l] = 1 << (l % per);
@@ -1107,14 +1235,21 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
         hist += (kw - 1) * dil[l] * RC;
     }
     st->hist_floats = hist;
-    // head (K == 128): both 1x1s in the (o, q) register mapping, the second zero-padded to 128 rows
-    st->o_wh1 = alloc((size_t)8 * RT * 4);
-    put_image(blob, st->o_wh1, T("last_conv_layers.1.weight").data.data(), 0, K);
-    st->o_bh1 = alloc(RC);
+    // head: both 1x1s in the (o, q) register mapping.  Part j of the head (one workgroup per 128 hidden units) holds rows
+    // [128 j, 128 j + 128) of the K x K matrix as NK column-block images and columns [128 j, 128 j + 128) of the O x K matrix
+    // as two row images (rows i, and rows 128 + i for one-hot models), zero-padded
+    const size_t imgsz = (size_t)8 * RT * 4;
+    st->o_wh1 = alloc((size_t)NK * NK * imgsz);
+    for (int part = 0; part < NK; ++part)
+        for (int blk = 0; blk < NK; ++blk)
+            put_image(blob, st->o_wh1 + ((size_t)part * NK + blk) * imgsz, T("last_conv_layers.1.weight").data.data(), K, RC * part, K, RC * blk);
+    st->o_bh1 = alloc(K);
     std::copy(T("last_conv_layers.1.bias").data.begin(), T("last_conv_layers.1.bias").data.end(), blob.begin() + st->o_bh1);
-    st->o_wh2 = alloc((size_t)2 * 8 * RT * 4);                      // rows i and (one-hot models, O up to 256) rows 128 + i
-    put_image(blob, st->o_wh2, T("last_conv_layers.3.weight").data.data(), 0, O);
-    put_image(blob, st->o_wh2 + (size_t)8 * RT * 4, T("last_conv_layers.3.weight").data.data(), RC, O);
+    st->o_wh2 = alloc((size_t)NK * 2 * imgsz);
+    for (int part = 0; part < NK; ++part) {
+        put_image(blob, st->o_wh2 + ((size_t)part * 2 + 0) * imgsz, T("last_conv_layers.3.weight").data.data(), K, 0, O, RC * part);
+        put_image(blob, st->o_wh2 + ((size_t)part * 2 + 1) * imgsz, T("last_conv_layers.3.weight").data.data(), K, RC, O, RC * part);
+    }
     st->o_bh2 = alloc(2 * RC);
     std::copy(T("last_conv_layers.3.bias").data.begin(), T("last_conv_layers.3.bias").data.end(), blob.begin() + st->o_bh2);
     // first_conv: (R, 1, 1) for scalar input; one-hot models: (R, cin1, 1) stored K-major [cin1][R] (row k = column k)
@@ -1155,11 +1290,13 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     // indices, the rest follow behind the rings (round-robin over the XCDs).  A tap workgroup serves 8 utterances per
     // pass (~4-5 us), so a second one per layer joins when there are more utterances and it fits.
     const int cus_per_xcd = ncu / 8;
+    const int NK = st->K / RC;                                     // skip passes per stage = head parts per ring
+    const int P = st->S + NK;                                      // workgroups of one ring
     auto rings_that_fit = [&](int parts) {
         for (int n = std::min(B, 8); n >= 1; --n) {
-            const int free_slots = (8 - n) * (st->S + 1);
+            const int free_slots = (8 - n) * P;
             const int extra = std::max(0, parts * st->L - free_slots);
-            if (st->S + 1 + (extra + 7) / 8 <= cus_per_xcd) return n;
+            if (P + (extra + 7) / 8 <= cus_per_xcd) return n;
         }
         return 0;
     };
@@ -1177,6 +1314,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const int rstride = 8;
     RingParams p{};
     p.n_rings = n_rings; p.rstride = rstride; p.S = st->S; p.L = st->L; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.upr = upr;
+    p.NH = NK; p.Op = 256;
     p.K = st->K; p.Kp = st->Kp; p.O = st->O; p.cin = st->cin; p.kw = st->kw; p.kpre = st->kpre; p.nz = ga.nz;
     p.dist = c.output_distribution;
     p.cin1 = st->cin1; p.softmax = ga.softmax; p.quantize = ga.quantize; p.index_out = ga.index_out;
@@ -1190,12 +1328,13 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.wh2img = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf;
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
-    // state: [status 64 B][placement table 4 KiB][xmail B*(S+1)*128 u64][hmail B*2*(S+1)*128 u64][smail B*(S+1)*Kp u64]
+    // state: [status 64 B][placement table 4 KiB][xmail B*(S+1)*128 u64][hmail B*2*(S+1)*128 u64][smail B*(S+1)*Kp u64][omail B*NK*256 u64]
     //        [hist B*hist_floats f32]
     const size_t head_bytes = 64 + 4096;                           // status word, placement table
     const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
     const size_t n_f = (size_t)B * st->L * (4 + RC), n_p = (size_t)B * st->L * (4 + GC);   // stage <-> tap-workgroup bulk records (floats)
-    const size_t mail_bytes = (3 * n_h + n_s) * sizeof(u64) + (n_f + n_p) * sizeof(float);
+    const size_t n_o = (size_t)B * NK * p.Op;                      // partial head outputs of parts 1 .. NK-1
+    const size_t mail_bytes = (3 * n_h + n_s + n_o) * sizeof(u64) + (n_f + n_p) * sizeof(float);
     const size_t hist_bytes = (size_t)B * st->hist_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -1224,7 +1363,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.xmail = (u64*)(base + head_bytes);
     p.hmail = p.xmail + n_h;
     p.smail = p.hmail + 2 * n_h;
-    p.fmail = (float*)(p.smail + n_s);
+    p.omail = p.smail + n_s;
+    p.fmail = (float*)(p.omail + n_o);
     p.pmail = p.fmail + n_f;
     p.hist = p.pmail + n_p;
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
@@ -1235,12 +1375,14 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.kreg_rows = std::min(p.kper, KR_MAX);
     p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);
     while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 150 * 1024) --p.klds_rows;
-    p.ring_blocks = rstride * (st->S + 1);
-    const size_t lds = std::max(std::max(STAGE_LDS_FLOATS, tap_lds_floats(p.kper, p.klds_rows)), st->cin1 > 1 ? CAT_LDS_FLOATS : (size_t)0) * sizeof(float);
+    p.ring_blocks = rstride * P;
+    const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
+                                st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
-    RING_HIP(hipFuncSetAttribute((const void*)wnv_ring_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const void* kfn = NK == 1 ? (const void*)wnv_ring_kernel<1> : NK == 2 ? (const void*)wnv_ring_kernel<2> : (const void*)wnv_ring_kernel<4>;
+    RING_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.tap_parts = tap_parts;
-    const int grid = p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * (st->S + 1));
+    const int grid = p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);
     if (p.ring_blocks > ncu) { err = "ring kernel: too many layers for one ring per XCD"; return WNV_ERR_UNSUPPORTED; }
     // optional timeline (WNV_RING_TRACE=<file>): wall-clock stamps of utterance 0 for 8 steps in mid-run
     const char* trace_path = getenv("WNV_RING_TRACE");
@@ -1253,7 +1395,9 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         RING_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
     }
-    hipLaunchKernelGGL(wnv_ring_kernel, dim3(grid), dim3(RT), lds, stream, p);
+    if (NK == 1) hipLaunchKernelGGL(wnv_ring_kernel<1>, dim3(grid), dim3(RT), lds, stream, p);
+    else if (NK == 2) hipLaunchKernelGGL(wnv_ring_kernel<2>, dim3(grid), dim3(RT), lds, stream, p);
+    else hipLaunchKernelGGL(wnv_ring_kernel<4>, dim3(grid), dim3(RT), lds, stream, p);
     RING_HIP(hipGetLastError());
     // the ring path is synchronous: a bounded spin that gave up must be reported to the caller
     unsigned int status = 0;
