@@ -146,3 +146,37 @@ def test_product_never_imports_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
                 assert "wavenet_oracle" not in txt, f
                 assert "/root/reference" not in txt, f
+
+
+def test_ring_kernel_keeps_its_poll_registers_out_of_the_compilers_hands(tmp_path):
+    """wnv_ring.hip lets early-issued polls land in v244..v255 and caps the NK <= 2 kernels at 244 VGPRs so that the compiler
+    never allocates those registers (a load in flight into a compiler-allocated register can be copied or re-used before it
+    lands).  Check the generated ISA: inside wnv_ring_kernel<1> / <2> those registers appear only in the helpers' own
+    instructions (the sc1 loads that fill a slot and the v_mov that empties it), and nothing spills."""
+    import re
+    import subprocess
+    from wavenet_vocoder_amd import build as wbuild
+    src = os.path.join(wbuild.CSRC, "wnv_ring.hip")
+    out = tmp_path / "ring.s"
+    subprocess.run([wbuild.hipcc_path(), f"--offload-arch={wbuild.ARCH}", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-x", "hip",
+                    src, "-o", str(out)], check=True)
+    text = out.read_text()
+    helper = re.compile(r"^\s*(global_load_dwordx[24] v\[2(4[4-9]|5[0-5]):2(4[4-9]|5[0-5])\], v\[\d+:\d+\], off sc1|"
+                        r"v_mov_b32(_e32)? v\d+, v2(4[4-9]|5[0-5]))\s*$")
+    uses = re.compile(r"\bv2(4[4-9]|5[0-5])\b|v\[2(4[4-9]|5[0-5]):|:2(4[4-9]|5[0-5])\]")
+    checked = 0
+    for nk in (1, 2):
+        m = re.search(rf"^_ZN\S*wnv_ring_kernelILi{nk}E\S*:[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+        assert m, f"kernel <{nk}> not found"
+        body = m.group(1)
+        n_helper = 0
+        for line in body.splitlines():
+            code = line.split(";")[0]
+            if uses.search(code):
+                assert helper.match(code), f"wnv_ring_kernel<{nk}> touches a reserved register outside the poll helpers: {line.strip()}"
+                n_helper += 1
+        assert n_helper > 10
+        checked += 1
+        meta = re.search(rf"\.name:\s+_ZN\S*wnv_ring_kernelILi{nk}E\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+        assert meta and int(meta.group(1)) == 0, "the capped kernel spills"
+    assert checked == 2

@@ -102,15 +102,6 @@ __device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v, bool f
     else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
 }
 
-// A poll whose first load is issued early (inline asm: the compiler neither moves it nor waits for it) so that its L2
-// round trip (~0.25 us even when the granule is already there) overlaps the work in between; redeem() waits for it.
-__device__ __forceinline__ u64 ld_issue(const u64* p) {
-    u64 v;
-    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void ld_redeem(u64& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
-
 // BULK hand-off for the traffic nobody waits for (stage <-> tap workgroup, any XCD): raw floats in 16-B write-through
 // stores, the producer drains them (vmcnt(0)) and then publishes ONE tag granule; the consumer polls that granule from a
 // single lane at a relaxed cadence and reads the payload with L1-bypassing loads.  A quarter of the fabric writes of the
@@ -144,22 +135,16 @@ __device__ __forceinline__ bool bulk_wait(const u64* flag, unsigned tag, unsigne
     }
 }
 
-// ONE wave receives a whole 128-value vector: two adjacent granules per lane in one 16-byte L1-bypassing load.  (Two
-// polling waves see an arrival at the later of two independent poll phases; one wave sees it at its own.)  The first
-// load may have been issued early with issue16() (the compiler neither moves nor waits for the inline-asm load).
+// ONE wave receives a whole 128-value vector: two adjacent granules per lane in one 16-byte L1-bypassing load (load and wait
+// are one asm statement: no register is ever in flight where the compiler can see it).  (Two polling waves see an arrival at
+// the later of two independent poll phases; one wave sees it at its own.)
 typedef unsigned u4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ u4v issue16(const u64* p) {
-    u4v v;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-__device__ __forceinline__ void redeem16(u4v& v) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(v) :: "memory"); }
 __device__ __forceinline__ bool wave_recv2(const u64* g2, unsigned tag, float& v0, float& v1, unsigned int* status,
                                            unsigned code, int lane, bool have_first, u4v first) {
     unsigned spins = 0;
     for (;;) {
         u4v x = first;
-        if (!have_first) { x = issue16(g2); redeem16(x); }
+        if (!have_first) asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(g2) : "memory");
         have_first = false;
         v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z);
         if (__all(x.y == tag && x.w == tag)) return true;
@@ -197,6 +182,115 @@ __device__ __forceinline__ bool wave_recv(const u64* g, bool active, unsigned ta
         }
         if (SLEEP) __builtin_amdgcn_s_sleep(1);
     }
+}
+
+// ---- POLLS IN RESERVED REGISTERS ------------------------------------------------------------------------------------------
+// A poll whose load is issued EARLY (so that its L2 round trip, ~0.25 us even when the granule is already there, overlaps the
+// work in between) writes its destination registers whenever it lands, which the compiler knows nothing about: with a
+// compiler-allocated destination it may copy or re-use the register while the load is still out (it did: a v_mov of the
+// in-flight pair ahead of the wait).  So these polls land in PHYSICAL registers the compiler never allocates: the kernel is
+// capped at 244 VGPRs (amdgpu_num_vgpr; tests/test_host_cpu.py checks the ISA) and v244 .. v255 -- three slots of up to 16 bytes
+// per lane -- belong to the helpers below; values leave them through v_mov after an s_waitcnt.  Loads return in order, so
+// "s_waitcnt vmcnt(n)" = everything but the n youngest polls has landed; older leftovers (stores) only make that wait longer,
+// never shorter, and a re-issue into a slot whose previous load is still out is harmless (the younger load lands last).
+// Nothing ever has to be drained.
+//
+// Measured and dropped: keeping SEVERAL polls of the same vector in flight while waiting (to see an arrival within a fraction of
+// a round trip instead of a uniformly distributed 0 .. 1 round trips late).  egs/mol, B = 8: one poll at a time 432 kSamples/s,
+// two in flight 408, three 391, two in flight on a replicated vector (different cache lines, a second store on the chain) 397:
+// the hop itself gets slower when the line is polled harder.
+#define WNV_RSV_CLOBBERS "memory", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255"
+template <int SLOT> __device__ __forceinline__ void rpoll16_issue(const u64* p) {
+    if constexpr (SLOT == 0) asm volatile("global_load_dwordx4 v[244:247], %0, off sc1" :: "v"(p) : WNV_RSV_CLOBBERS);
+    else if constexpr (SLOT == 1) asm volatile("global_load_dwordx4 v[248:251], %0, off sc1" :: "v"(p) : WNV_RSV_CLOBBERS);
+    else asm volatile("global_load_dwordx4 v[252:255], %0, off sc1" :: "v"(p) : WNV_RSV_CLOBBERS);
+}
+// waits until at most YOUNGER polls issued after this slot's are outstanding, then copies the slot out
+template <int SLOT, int YOUNGER> __device__ __forceinline__ u4v rpoll16_take() {
+    static_assert(YOUNGER == 2 || YOUNGER == 1 || YOUNGER == 0, "");
+    unsigned x, y, z, w;
+#define WNV_TAKE16(R0, R1, R2, R3)                                                                                        \
+    if constexpr (YOUNGER == 2) asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 "\n\tv_mov_b32 %2, " R2 "\n\tv_mov_b32 %3, " R3 \
+                                             : "=v"(x), "=v"(y), "=v"(z), "=v"(w) :: WNV_RSV_CLOBBERS);                   \
+    else if constexpr (YOUNGER == 1) asm volatile("s_waitcnt vmcnt(1)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 "\n\tv_mov_b32 %2, " R2 "\n\tv_mov_b32 %3, " R3 \
+                                             : "=v"(x), "=v"(y), "=v"(z), "=v"(w) :: WNV_RSV_CLOBBERS);                   \
+    else asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 "\n\tv_mov_b32 %2, " R2 "\n\tv_mov_b32 %3, " R3 \
+                      : "=v"(x), "=v"(y), "=v"(z), "=v"(w) :: WNV_RSV_CLOBBERS);
+    if constexpr (SLOT == 0) { WNV_TAKE16("v244", "v245", "v246", "v247") }
+    else if constexpr (SLOT == 1) { WNV_TAKE16("v248", "v249", "v250", "v251") }
+    else { WNV_TAKE16("v252", "v253", "v254", "v255") }
+#undef WNV_TAKE16
+    return u4v{x, y, z, w};
+}
+template <int SLOT> __device__ __forceinline__ void rpoll8_issue(const u64* p) {
+    if constexpr (SLOT == 0) asm volatile("global_load_dwordx2 v[244:245], %0, off sc1" :: "v"(p) : WNV_RSV_CLOBBERS);
+    else if constexpr (SLOT == 1) asm volatile("global_load_dwordx2 v[248:249], %0, off sc1" :: "v"(p) : WNV_RSV_CLOBBERS);
+    else asm volatile("global_load_dwordx2 v[252:253], %0, off sc1" :: "v"(p) : WNV_RSV_CLOBBERS);
+}
+template <int SLOT, int YOUNGER> __device__ __forceinline__ void rpoll8_take(unsigned& val, unsigned& tg) {
+#define WNV_TAKE8(R0, R1)                                                                                                                  \
+    if constexpr (YOUNGER == 2) asm volatile("s_waitcnt vmcnt(2)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 : "=v"(val), "=v"(tg) :: WNV_RSV_CLOBBERS); \
+    else if constexpr (YOUNGER == 1) asm volatile("s_waitcnt vmcnt(1)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 : "=v"(val), "=v"(tg) :: WNV_RSV_CLOBBERS); \
+    else asm volatile("s_waitcnt vmcnt(0)\n\tv_mov_b32 %0, " R0 "\n\tv_mov_b32 %1, " R1 : "=v"(val), "=v"(tg) :: WNV_RSV_CLOBBERS);
+    if constexpr (SLOT == 0) { WNV_TAKE8("v244", "v245") }
+    else if constexpr (SLOT == 1) { WNV_TAKE8("v248", "v249") }
+    else { WNV_TAKE8("v252", "v253") }
+#undef WNV_TAKE8
+}
+
+// ONE wave receives a 128-value vector, two granules per lane.  PRE: the caller issued slot 0, then slot 1, earlier; both are
+// looked at first, oldest first, while a third poll (slot 2) is already on its way; after that one poll at a time.
+template <bool PRE>
+__device__ __forceinline__ bool rpoll_recv2(const u64* g2, unsigned tag, float& v0, float& v1, unsigned int* status, unsigned code, int lane) {
+#define WNV_HIT16(x) if (__all(x.y == tag && x.w == tag)) { v0 = __uint_as_float(x.x); v1 = __uint_as_float(x.z); return true; }
+    rpoll16_issue<2>(g2);
+    if (PRE) {
+        u4v x = rpoll16_take<0, 2>();
+        WNV_HIT16(x)
+        x = rpoll16_take<1, 1>();
+        WNV_HIT16(x)
+    }
+    unsigned spins = 0;
+    for (;;) {
+        const u4v x = rpoll16_take<2, 0>();
+        WNV_HIT16(x)
+        rpoll16_issue<2>(g2);
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+    }
+#undef WNV_HIT16
+}
+// One wave waits until the granule of every ACTIVE lane carries `tag`.  NPRE = how many of the slots 0, 1, 2 the caller has
+// already issued (in that order, active lanes only): they are looked at first, oldest first; after that one poll at a time.
+template <int NPRE>
+__device__ __forceinline__ bool rpoll_recv(const u64* g, bool active, unsigned tag, float& v, unsigned int* status, unsigned code, int lane) {
+#define WNV_RPOLL8(SLOT, YOUNGER, REISSUE)                                    \
+    {                                                                         \
+        bool ok = true;                                                       \
+        if (active) {                                                         \
+            unsigned val, tg;                                                 \
+            rpoll8_take<SLOT, YOUNGER>(val, tg);                              \
+            v = __uint_as_float(val);                                         \
+            ok = tg == tag;                                                   \
+        }                                                                     \
+        if (__all(ok)) return true;                                           \
+        if (REISSUE && active) rpoll8_issue<SLOT>(g);                         \
+    }
+    if (NPRE == 1) { WNV_RPOLL8(0, 0, false) }
+    if (NPRE == 2) { WNV_RPOLL8(0, 1, false) WNV_RPOLL8(1, 0, false) }
+    if (NPRE == 3) { WNV_RPOLL8(0, 2, false) WNV_RPOLL8(1, 1, false) WNV_RPOLL8(2, 0, false) }
+    unsigned spins = 0;
+    if (active) rpoll8_issue<0>(g);
+    for (;;) {
+        WNV_RPOLL8(0, 0, true)
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+    }
+#undef WNV_RPOLL8
 }
 
 // Placement handshake: publish this workgroup's XCC id, read those of the (up to two) workgroups that read what this one
@@ -525,6 +619,7 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
 template <int NK>
 __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
     constexpr int NLDS = lds_passes(NK);
+    constexpr bool RP = NK <= 2;                // pipelined polls in the reserved registers (the K = 512 instantiation needs them itself)
     const StageLds s = carve_stage(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ks = tid & 7, og = tid >> 3;                      // K-slice; lane group = channels 2og, 2og + 1
@@ -570,7 +665,6 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             if (b >= p.B) continue;
             // every mailbox address of this step, pinned in registers before the first wait
             const u64* x_in = p.xmail + ((size_t)b * S1 + sidx) * RC + 2 * lane;      // wave 0: two granules per lane
-            u4v x_first = {0, 0, 0, 0}, x_second = {0, 0, 0, 0};
             u64* x_out = p.xmail + ((size_t)b * S1 + sidx + 1) * RC + ch;
             const u64* h_in = p.hmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + ch;
             u64* h_out = p.hmail + (((size_t)b * 2 + par) * S1 + sidx + 1) * RC + ch;
@@ -597,7 +691,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                     float v0 = 0.f, v1 = 0.f;
                     if (!wave_recv2(hb_in, tag, v0, v1, p.status, 0x400u + (unsigned)sidx, lane, false, u4v{0, 0, 0, 0})) s.flags[0] = 1;
                     *reinterpret_cast<float2*>(s.hb + eidx(2 * lane)) = make_float2(v0, v1);
-                    x_first = issue16(x_in);        // the chain input may be there already: fetch it under the N mat-vec
+                    if constexpr (RP) rpoll16_issue<0>(x_in);         // the chain input may be there already: fetch it under the N mat-vec
                 }
                 __syncthreads();
                 float x[16];
@@ -611,7 +705,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 float a0 = acc[0].x + acc[0].y, g0 = acc[1].x + acc[1].y, a1 = acc[2].x + acc[2].y, g1 = acc[3].x + acc[3].y;
                 if (wave == 0) {                    // a second poll for the chain input, one reduction ahead of its use: the
                     asm volatile("" : "+v"(a0), "+v"(g0), "+v"(a1), "+v"(g1));      // vector tends to land during this mat-vec
-                    x_second = issue16(x_in);
+                    if constexpr (RP) rpoll16_issue<1>(x_in);
                 }
                 zin_a += quad_allreduce((hi ? a1 : a0) + dpp_mov<0x141>(hi ? a0 : a1));
                 zin_g += quad_allreduce((hi ? g1 : g0) + dpp_mov<0x141>(hi ? g0 : g1));
@@ -622,12 +716,14 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
 #endif
             // ---- the chain: receive X[l][t]  ->  M_l X + zin  ->  gate  ->  send u_l --------------------------------
             if (wave == 0) {
-                float v0 = 0.f, v1 = 0.f;
-                if (!first_stage) {                 // both early polls have been outstanding since before / during the N mat-vec
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(x_first), "+v"(x_second) :: "memory");
-                    if (__all(x_second.y == tag && x_second.w == tag)) x_first = x_second;
-                }
-                if (!wave_recv2(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane, !first_stage, x_first)) s.flags[0] = 1;
+                float v0 = 0.f, v1 = 0.f;           // two early polls have been outstanding since before / during the N mat-vec
+                bool got;
+                if constexpr (RP)
+                    got = first_stage ? rpoll_recv2<false>(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane)
+                                      : rpoll_recv2<true>(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane);
+                else
+                    got = wave_recv2(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane, false, u4v{0, 0, 0, 0});
+                if (!got) s.flags[0] = 1;
                 *reinterpret_cast<float2*>(s.hx + eidx(2 * lane)) = make_float2(v0, v1);
             }
             __syncthreads();
@@ -656,9 +752,9 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             // h_l[t] (from stage l-1, normally a hop behind its u) is awaited by the very lanes that own the channel and
             // added in registers: the h recurrence costs one hop + one add per layer.  Its first poll is issued here, under
             // the barrier and the conv1x1_out mat-vec.
-            u64 h_first = 0;
-            if (!first_stage && writer) h_first = ld_issue(h_in);
+            if constexpr (RP) { if (!first_stage && writer) rpoll8_issue<0>(h_in); }
             __syncthreads();                                                    // u_l complete in LDS
+            if constexpr (RP) { if (!first_stage && !last_stage && writer) rpoll8_issue<1>(h_in); }
 #ifdef WNV_FINE_TRACE
             stamp(p, b, t, sidx, 7);
 #endif
@@ -669,6 +765,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 float o = 0.f;
                 if (!last_stage) {                  // the last layer's residual output is never used (wavenet.py:310-313)
                     const float o0 = dot16p(wo[0], xu), o1 = dot16p(wo[1], xu);
+                    if constexpr (RP) { if (!first_stage && writer) rpoll8_issue<2>(h_in); }
                     o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1)) + bo_r;
                 }
                 float h = 0.f;
@@ -676,8 +773,11 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 if (first_stage) {
                     h = s.hx[eidx(ch)];                                          // h_0 is the chain input itself
                 } else {
-                    if (writer) ld_redeem(h_first);
-                    ok = wave_recv<false>(h_in, writer, tag, h, p.status, 0x500u + (unsigned)sidx, lane, true, h_first);
+                    if constexpr (RP)
+                        ok = last_stage ? rpoll_recv<1>(h_in, writer, tag, h, p.status, 0x500u + (unsigned)sidx, lane)
+                                        : rpoll_recv<3>(h_in, writer, tag, h, p.status, 0x500u + (unsigned)sidx, lane);
+                    else
+                        ok = wave_recv<false>(h_in, writer, tag, h, p.status, 0x500u + (unsigned)sidx, lane);
                 }
                 if (writer) {
                     if (!last_stage && ok)
@@ -774,7 +874,8 @@ __device__ __forceinline__ bool head_recv_skip(const RingParams& p, int b, unsig
     bool ok = true;
     if (wave < 2 * NK) {
         float v = 0.f;
-        ok = wave_recv<false>(p.smail + ((size_t)b * (p.S + 1) + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane);
+        if constexpr (NK <= 2) ok = rpoll_recv<0>(p.smail + ((size_t)b * (p.S + 1) + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane);
+        else ok = wave_recv<false>(p.smail + ((size_t)b * (p.S + 1) + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane);
         vs[qidx(tid)] = fmaxf(v * p.skip_scale, 0.f);                           // wavenet.py:313-316
     }
     return ok;
@@ -1038,7 +1139,7 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
 }
 
 template <int NK>
-__global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
+__device__ __forceinline__ void ring_body(const RingParams& p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int P = p.S + p.NH;                   // workgroups of one ring: S stages + NH head parts
     // block i -> XCD i % 8 (observed, speed only): with rstride == 8 every workgroup of ring r sits on XCD r
@@ -1068,6 +1169,12 @@ __global__ void __launch_bounds__(RT) wnv_ring_kernel(const RingParams p) {
         else run_head_part<NK, 1>(p, ring, pos - p.S, smem);
     }
 }
+
+// NK <= 2: capped at 244 VGPRs -- v244 .. v255 are the poll slots (see "POLLS IN RESERVED REGISTERS")
+template <int NK>
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK>(p); }
+// K = 512: needs the whole register file; polls one load at a time in compiler-allocated registers
+__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4>(p); }
 
 }  // namespace
 
@@ -1379,7 +1486,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
                                 st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
-    const void* kfn = NK == 1 ? (const void*)wnv_ring_kernel<1> : NK == 2 ? (const void*)wnv_ring_kernel<2> : (const void*)wnv_ring_kernel<4>;
+    const void* kfn = NK == 1 ? (const void*)wnv_ring_kernel<1> : NK == 2 ? (const void*)wnv_ring_kernel<2> : (const void*)wnv_ring_kernel_k512;
     RING_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.tap_parts = tap_parts;
     const int grid = p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);
@@ -1397,7 +1504,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     }
     if (NK == 1) hipLaunchKernelGGL(wnv_ring_kernel<1>, dim3(grid), dim3(RT), lds, stream, p);
     else if (NK == 2) hipLaunchKernelGGL(wnv_ring_kernel<2>, dim3(grid), dim3(RT), lds, stream, p);
-    else hipLaunchKernelGGL(wnv_ring_kernel<4>, dim3(grid), dim3(RT), lds, stream, p);
+    else hipLaunchKernelGGL(wnv_ring_kernel_k512, dim3(grid), dim3(RT), lds, stream, p);
     RING_HIP(hipGetLastError());
     // the ring path is synchronous: a bounded spin that gave up must be reported to the caller
     unsigned int status = 0;
