@@ -42,40 +42,76 @@ struct Lds {
 __device__ __forceinline__ Lds carve(float* smem) { return {smem, smem + KC * XS, smem + KC * XS + KC * WS}; }
 constexpr size_t LDS_FLOATS = (size_t)KC * XS + (size_t)KC * WS + (size_t)HC * XS;
 
-// acc[i] += X[m0 .. m0+32)[chunk] * W[chunk][ncol[i] .. ncol[i]+32)  for the whole KC chunk
+// acc[i] += X[m0 .. m0+32)[chunk] * W[chunk][ncol[i] .. ncol[i]+32)  for the whole KC chunk.  The LDS operands of step ks + 1 are
+// requested before the MFMAs of step ks are issued; the sched_group_barrier sequence pins that order ([DS reads of the next
+// step][MFMAs of this step] ...) against the machine scheduler, which otherwise sinks every read next to its use and lets the
+// matrix pipe wait for an LDS round trip after every second MFMA.
 template <int NT>
 __device__ __forceinline__ void mfma_chunk(f16v (&acc)[NT], const float* xt, int m0, const float* wc, const int (&ncol)[NT], int lane) {
     const int kl = lane >> 5, jl = lane & 31;
-#pragma unroll 4
-    for (int ks = 0; ks < KC / 2; ++ks) {
-        const float a = xt[(2 * ks + kl) * XS + m0 + jl];
+    const float* xa = xt + kl * XS + m0 + jl;
+    const float* wb = wc + kl * WS + jl;
+    float a = xa[0];
+    float b[NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const float b = wc[(2 * ks + kl) * WS + ncol[i] + jl];
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    for (int i = 0; i < NT; ++i) b[i] = wb[ncol[i]];
+    __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+#pragma unroll
+    for (int ks = 0; ks < KC / 2; ++ks) {
+        float an = 0.f, bn[NT];
+        if (ks + 1 < KC / 2) {
+            an = xa[(2 * ks + 2) * XS];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) bn[i] = wb[(2 * ks + 2) * WS + ncol[i]];
+            __builtin_amdgcn_sched_group_barrier(0x100, NT + 1, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[i], acc[i], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        if (ks + 1 < KC / 2) {
+            a = an;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) b[i] = bn[i];
         }
     }
 }
 
-// weight chunk: rows [k0, k0 + KC) x columns [c0, c0 + 256) of a K-major matrix [nrows][ld] -> wc (zeros outside)
-__device__ __forceinline__ void load_w_chunk(float* wc, const float* __restrict__ W, int ld, int nrows, int ncols, int k0, int c0, int tid) {
-    const int row = tid >> 3, col0 = (tid & 7) * 32;
-    const int k = k0 + row;
+// A chunk travels global -> registers -> LDS in two steps so that the global loads of chunk k + 1 are in flight while the
+// matrix cores work on chunk k (the LDS copy is single; the registers are the second buffer).
+// weight chunk: rows [k0, k0 + KC) x columns [c0, c0 + 256) of a K-major matrix [nrows][ld] (zeros outside)
+// thread tid owns the float4s f = q * 256 + tid (q = 0 .. 7) of the 32 x 64-float4 chunk: a wave reads one contiguous 1 KiB row
+// segment per load and writes 64 consecutive 16-byte LDS slots per store (conflict-free; the earlier row-per-8-lanes mapping put
+// all 64 lanes of a ds_write_b128 on the same four banks: 65 % of the LDS cycles were bank conflicts, profiles/r01_forward_v1_pmc.txt)
+struct WChunk { float4 v[8]; };
+__device__ __forceinline__ void fetch_w_chunk(WChunk& r, const float* __restrict__ W, int ld, int nrows, int ncols, int k0, int c0, int tid) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const int c = c0 + col0 + 4 * q;
+        const int f = q * FT + tid;
+        const int k = k0 + (f >> 6), c = c0 + 4 * (f & 63);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < nrows && c + 3 < ncols) v = *reinterpret_cast<const float4*>(W + (size_t)k * ld + c);
-        else if (k < nrows) {
-            if (c < ncols) v.x = W[(size_t)k * ld + c];
-            if (c + 1 < ncols) v.y = W[(size_t)k * ld + c + 1];
-            if (c + 2 < ncols) v.z = W[(size_t)k * ld + c + 2];
-        }
-        *reinterpret_cast<float4*>(wc + row * WS + col0 + 4 * q) = v;
+        if (k < nrows && c < ncols) v = *reinterpret_cast<const float4*>(W + (size_t)k * ld + c);     // ncols % 4 == 0 (padded widths)
+        r.v[q] = v;
     }
+}
+__device__ __forceinline__ void commit_w_chunk(float* wc, const WChunk& r, int tid) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) reinterpret_cast<float4*>(wc)[q * FT + tid] = r.v[q];
+}
+__device__ __forceinline__ void load_w_chunk(float* wc, const float* __restrict__ W, int ld, int nrows, int ncols, int k0, int c0, int tid) {
+    WChunk r;
+    fetch_w_chunk(r, W, ld, nrows, ncols, k0, c0, tid);
+    commit_w_chunk(wc, r, tid);
 }
 
 __device__ __forceinline__ int acc_row(int v, int lane) { return 8 * (v >> 2) + 4 * (lane >> 5) + (v & 3); }
+
+// tanh(a) * sigmoid(g) with the hardware exp2 / rcp (absolute error ~1e-7, as in the sample-loop kernel)
+__device__ __forceinline__ float fwd_gate(float a, float g) {
+    const float e = __builtin_amdgcn_exp2f(fabsf(a) * -2.8853900817779268f);
+    const float f = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
+    const float r = __builtin_amdgcn_rcpf((1.0f + e) * (1.0f + f));
+    return copysignf((1.0f - e) * r, a);
+}
 
 struct LayerArgs {
     const float* Hin; float* Hout; float* Skip;        // (B, T, 128), (B, T, 128), (B, T, K)
@@ -84,6 +120,33 @@ struct LayerArgs {
     const float *w_in, *w_os, *b_os;                    // K-major [kw*128 + cin][256], [128][nosp], [nosp]
     long long T; int tiles_per_utt, d, kw, cin, K, nosp;
 };
+
+// activation chunk kc of GEMM1 for time row m (thread = (m, eight K values)): tap j of the dilated conv (oldest first,
+// conv.py:55-61) or the local conditioning row c[t] (modules.py:141-144)
+__device__ __forceinline__ void fetch_x_chunk(float (&v)[8], const LayerArgs& a, const float* Hin, int b, long long t, int kc, int sub) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (t >= a.T) return;
+    if (kc < 4 * a.kw) {
+        const int j = kc >> 2, ch0 = 32 * (kc & 3) + 8 * sub;
+        const long long tt = t - (long long)(a.kw - 1 - j) * a.d;
+        if (tt >= 0) {
+            const float4 p = *reinterpret_cast<const float4*>(Hin + (size_t)tt * HC + ch0);
+            const float4 q = *reinterpret_cast<const float4*>(Hin + (size_t)tt * HC + ch0 + 4);
+            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+        }
+    } else if (a.c_up) {
+        const int c0 = 32 * (kc - 4 * a.kw) + 8 * sub;
+        const float* cr = a.c_up + ((size_t)b * a.T + t) * a.cin;
+        if (c0 + 7 < a.cin && (a.cin & 3) == 0) {
+            const float4 p = *reinterpret_cast<const float4*>(cr + c0), q = *reinterpret_cast<const float4*>(cr + c0 + 4);
+            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (c0 + e < a.cin) v[e] = cr[c0 + e];
+        }
+    }
+}
 
 __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -96,6 +159,8 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
     const float* Hin = a.Hin + (size_t)b * a.T * HC;
     const int Kin = a.kw * HC + a.cin;
     const int nchunk = (Kin + KC - 1) / KC;
+    const int xm = tid >> 2, xsub = tid & 3;                    // this thread's slice of an activation chunk
+    const int ntot = HC + a.K;
 
     // ---- GEMM1: Z = [taps | c] W_in -----------------------------------------------------------------------------------
     f16v acc[4];
@@ -104,36 +169,23 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
     const int ncol1[4] = {64 * cb, 64 * cb + 32, HC + 64 * cb, HC + 64 * cb + 32};      // tanh tiles, sigmoid tiles of the same channels
+    float xr[8];
+    WChunk wr;
+    fetch_x_chunk(xr, a, Hin, b, t0 + xm, 0, xsub);
+    fetch_w_chunk(wr, a.w_in, 256, Kin, 256, 0, 0, tid);
     for (int kc = 0; kc < nchunk; ++kc) {
-        {   // activation chunk -> xt (K-major): thread = (time row m, eight K values)
-            const int m = tid >> 2, sub = tid & 3;
-            const long long t = t0 + m;
-            float v[8];
+        if (kc > 0) __syncthreads();                              // the matrix cores are done with the previous chunk
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-            if (t < a.T) {
-                if (kc < 4 * a.kw) {                                   // tap j of the dilated conv (oldest first, conv.py:55-61)
-                    const int j = kc >> 2, ch0 = 32 * (kc & 3) + 8 * sub;
-                    const long long tt = t - (long long)(a.kw - 1 - j) * a.d;
-                    if (tt >= 0) {
-                        const float4 p = *reinterpret_cast<const float4*>(Hin + (size_t)tt * HC + ch0);
-                        const float4 q = *reinterpret_cast<const float4*>(Hin + (size_t)tt * HC + ch0 + 4);
-                        v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
-                    }
-                } else if (a.c_up) {                                   // local conditioning row c[t] (modules.py:141-144)
-                    const int c0 = 32 * (kc - 4 * a.kw) + 8 * sub;
-                    const float* cr = a.c_up + ((size_t)b * a.T + t) * a.cin;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) if (c0 + e < a.cin) v[e] = cr[c0 + e];
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s.xt[(8 * sub + e) * XS + m] = v[e];
+        for (int e = 0; e < 8; ++e) s.xt[(8 * xsub + e) * XS + xm] = xr[e];
+        commit_w_chunk(s.wc, wr, tid);
+        __syncthreads();
+        if (kc + 1 < nchunk) {                                    // next chunk: in flight under this chunk's MFMAs
+            fetch_x_chunk(xr, a, Hin, b, t0 + xm, kc + 1, xsub);
+            fetch_w_chunk(wr, a.w_in, 256, Kin, 256, (kc + 1) * KC, 0, tid);
+        } else {
+            fetch_w_chunk(wr, a.w_os, a.nosp, HC, ntot, 0, 0, tid);                    // first chunk of GEMM2
         }
-        load_w_chunk(s.wc, a.w_in, 256, Kin, 256, kc * KC, 0, tid);
-        __syncthreads();
         mfma_chunk<4>(acc, s.xt, m0, s.wc, ncol1, lane);
-        __syncthreads();
     }
     // ---- bias (+ global conditioning), tanh . sigmoid -> U tile, K-major ---------------------------------------------------
     {
@@ -143,15 +195,11 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
             const int ch = 64 * cb + 32 * j + (lane & 31);
             const float za = zb[ch], zg = zb[HC + ch];
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const float x = acc[j][v] + za, g = acc[2 + j][v] + zg;
-                s.ut[ch * XS + m0 + acc_row(v, lane)] = tanhf(x) * (1.0f / (1.0f + expf(-g)));      // modules.py:152-154
-            }
+            for (int v = 0; v < 16; ++v)
+                s.ut[ch * XS + m0 + acc_row(v, lane)] = fwd_gate(acc[j][v] + za, acc[2 + j][v] + zg);      // modules.py:152-154
         }
     }
-    __syncthreads();
     // ---- GEMM2: [out | skip] = U [W_out | W_skip], in column blocks of 256 ---------------------------------------------------
-    const int ntot = HC + a.K;
     for (int c0 = 0; c0 < ntot; c0 += 256) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -159,10 +207,12 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
             for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
         const int ncol2[4] = {128 * cb, 128 * cb + 32, 128 * cb + 64, 128 * cb + 96};
         for (int kc = 0; kc < HC / KC; ++kc) {
-            load_w_chunk(s.wc, a.w_os, a.nosp, HC, ntot, kc * KC, c0, tid);
+            __syncthreads();                                      // previous chunk consumed (first pass: the U tile is complete)
+            commit_w_chunk(s.wc, wr, tid);
             __syncthreads();
+            if (kc + 1 < HC / KC) fetch_w_chunk(wr, a.w_os, a.nosp, HC, ntot, (kc + 1) * KC, c0, tid);
+            else if (c0 + 256 < ntot) fetch_w_chunk(wr, a.w_os, a.nosp, HC, ntot, 0, c0 + 256, tid);
             mfma_chunk<4>(acc, s.ut + kc * KC * XS, m0, s.wc, ncol2, lane);
-            __syncthreads();
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -240,7 +290,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_head_kernel(const HeadArgs a) {
         }
         __syncthreads();
         for (int kc = 0; kc < HC / KC; ++kc) {               // out += hidden block . W_h2[rows of the block]
-            load_w_chunk(s.wc, a.w_h2 + (size_t)HC * hb * a.op, a.op, HC, a.O, kc * KC, 0, tid);
+            load_w_chunk(s.wc, a.w_h2 + (size_t)HC * hb * a.op, a.op, HC, a.op, kc * KC, 0, tid);      // padded columns are zero
             __syncthreads();
             mfma_chunk<4>(oacc, s.ut + kc * KC * XS, m0, s.wc, ncolo, lane);
             __syncthreads();
