@@ -52,7 +52,8 @@ def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0):
     B = c.shape[0]
     frames = T_cpu // 256
     c_cpu = c[:, :, : frames + 2 * kw["cin_pad"]].contiguous()
-    tape = make_noise_tape(T_cpu, B, scalar_input=True, output_distribution="Logistic", out_channels=30,
+    tape = make_noise_tape(T_cpu, B, scalar_input=kw.get("scalar_input", False),
+                           output_distribution=kw.get("output_distribution", "Logistic"), out_channels=kw["out_channels"],
                            generator=torch.Generator().manual_seed(2))
     results, steps = {}, {}
     ncores = os.cpu_count() or 1

@@ -68,3 +68,30 @@ def test_batch_wavegen_end_to_end():
     want = P.post_chain(y_hat.cpu().numpy(), "raw", postprocess="inv_preemphasis", coef=0.85, global_gain_scale=0.55)
     assert want.shape == wav.shape
     del o
+
+
+def test_wavegen_single_utterance():
+    """synthesis.wavegen (one utterance, (Tc, cin) numpy features, no context frames): same samples as incremental_forward on
+    the same inputs + the post-chain, and the documented quirk (mu = quantize_channels for the mu-law decoders)."""
+    import wavenet_vocoder_amd as wnv
+    from tests._configs import tame_head_
+    kw = dict(out_channels=30, layers=6, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
+              dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=80, cin_pad=0,
+              upsample_conditional_features=True, upsample_params=dict(upsample_scales=[4, 4, 4, 4], cin_channels=80, cin_pad=0))
+    torch.manual_seed(3)
+    m = tame_head_(wnv.WaveNet(**kw).eval()).to("cuda")
+    feats = np.random.default_rng(0).standard_normal((3, 80)).astype(np.float32)            # (Tc, D)
+    h = hp(cin_pad=0, hop_size=256)
+    torch.manual_seed(11)
+    wav = synthesis.wavegen(m, c=feats, hparams=h, fast=True)
+    assert wav.shape == (3 * 256,) and wav.dtype == np.float32 and np.isfinite(wav).all()
+    torch.manual_seed(11)                                                                    # same in-kernel noise seed
+    with torch.no_grad():
+        y_hat = m.incremental_forward(torch.zeros(1, 1, 1).cuda(), c=torch.from_numpy(feats.T).unsqueeze(0).cuda(), T=768,
+                                      softmax=True, quantize=True)
+    want = P.post_chain(y_hat.cpu().numpy(), "raw", postprocess="inv_preemphasis", coef=0.85, global_gain_scale=0.55)
+    np.testing.assert_allclose(wav, want.reshape(-1), rtol=2e-5, atol=2e-6)
+    # mu-law quirk: wavegen decodes with mu = quantize_channels, batch_wavegen with quantize_channels - 1
+    y = (torch.rand(1, 1, 500) * 2 - 1).cuda()
+    hq = hp(input_type="mulaw", quantize_channels=256, postprocess=None, global_gain_scale=0.0)
+    np.testing.assert_allclose(synthesis.postprocess(y, hq, mu=256).cpu().numpy(), P.inv_mulaw(y.cpu().numpy()[:, 0], 256), rtol=3e-5, atol=1e-6)

@@ -58,3 +58,26 @@ def test_post_chain_modes():
     np.testing.assert_allclose(y, P.inv_mulaw_quantize(idx, 255), rtol=1e-6)
     y = P.post_chain(raw * 2, "mulaw", quantize_channels=256, postprocess=None, global_gain_scale=0.0)
     np.testing.assert_allclose(y, P.inv_mulaw(raw.reshape(B, T) * 2, 255), rtol=1e-6)
+
+
+def test_wavegen_argument_errors_need_no_gpu():
+    """synthesis.wavegen's checks (sanity_check, 2-dim features, missing length) fire before anything touches a device."""
+    import pytest
+    import torch
+    import wavenet_vocoder_amd as wnv
+    from wavenet_vocoder_amd import synthesis
+    local = wnv.WaveNet(out_channels=30, layers=2, stacks=1, residual_channels=8, gate_channels=16, skip_out_channels=8,
+                        cin_channels=4, scalar_input=True).eval()
+    plain = wnv.WaveNet(out_channels=30, layers=2, stacks=1, residual_channels=8, gate_channels=16, skip_out_channels=8,
+                        scalar_input=True).eval()
+    with pytest.raises(RuntimeError, match="conditional features, but not given"):
+        synthesis.wavegen(local, length=10)
+    with pytest.raises(RuntimeError, match="no conditional features, but given"):
+        synthesis.wavegen(plain, c=np.zeros((3, 4), np.float32))
+    with pytest.raises(RuntimeError, match="no speaker embedding"):
+        synthesis.wavegen(plain, length=4, g=1)
+    with pytest.raises(RuntimeError, match="Expected 2-dim shape"):
+        synthesis.wavegen(local, c=np.zeros((1, 3, 4), np.float32)[:, :, :, None])
+    with pytest.raises(AssertionError):
+        synthesis.wavegen(plain)                                     # neither length nor features
+    assert synthesis._to_numpy(torch.zeros(1, 3, 4)).shape == (3, 4)
