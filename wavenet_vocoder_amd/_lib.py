@@ -15,7 +15,8 @@ __all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluC
 
 WNV_ABI_VERSION = 1
 WNV_MAX_UPSAMPLE_STAGES = 8
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwnv_hip.so")
+# WNV_LIB selects another build of the same sources (debug/trace builds: python -m wavenet_vocoder_amd.build --out ... --flags ...)
+LIB_PATH = os.environ.get("WNV_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwnv_hip.so")
 
 DIST = {"categorical": 0, "Logistic": 1, "Normal": 2}
 UPSAMPLE = {None: 0, "none": 0, "ConvInUpsampleNetwork": 1, "UpsampleNetwork": 2}

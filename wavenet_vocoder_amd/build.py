@@ -32,20 +32,23 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    """Compile every HIP translation unit for gfx950 and link the C-ABI shared library."""
-    if not force and not _stale():
+def build(force: bool = False, verbose: bool = True, out: str = OUT, extra_flags=()) -> str:
+    """Compile every HIP translation unit for gfx950 and link the C-ABI shared library (``out`` / ``extra_flags``: debug or
+    trace builds next to the product library, selected at run time with WNV_LIB)."""
+    if out == OUT and not force and not _stale():
         return OUT
     cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function", "-o", OUT + ".tmp", "-x", "hip"]
+           "-Wall", "-Wno-unused-function", *extra_flags, "-o", out + ".tmp", "-x", "hip"]
     cmd += [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print("[wnv build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(OUT + ".tmp", OUT)
-    return OUT
+    os.replace(out + ".tmp", out)
+    return out
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    argv = sys.argv[1:]
+    out = argv[argv.index("--out") + 1] if "--out" in argv else OUT
+    flags = argv[argv.index("--flags") + 1].split() if "--flags" in argv else ()
+    print(build(force="--force" in argv, out=os.path.abspath(out), extra_flags=flags))

@@ -472,8 +472,10 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         if (!wnv_ring_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the pipelined ring kernel does not cover this configuration: %s", wnv_ring_why_not(c, a->B));
         std::string err;
         wnv_status st = wnv_ring_generate(&h->ring_state, h->device, c, h->store, ga, s, err);
-        if (st != WNV_OK) return fail(st, "%s", err.c_str());
-        return WNV_OK;
+        if (st == WNV_OK) return WNV_OK;
+        // auto mode on a device that cannot host the persistent pipeline (fewer CUs than one ring + its tap workgroups per
+        // XCD, e.g. a partitioned GPU): the generic kernel still covers the call; an explicit kernel = 2 reports the reason
+        if (!(a->kernel == 0 && st == WNV_ERR_UNSUPPORTED)) return fail(st, "%s", err.c_str());
     }
     const size_t ring_bytes = std::max<size_t>((size_t)a->B * m.ring_floats * sizeof(float), 16);
     HIP_TRY(h->ring.ensure(ring_bytes));
