@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <string>
 
 #include "wnv_dev.h"
@@ -68,6 +69,8 @@ __device__ __forceinline__ void mfma_chunk(f16v (&acc)[NT], const float* xt, int
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b[i], acc[i], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one global load of the caller's next-chunk fetch per step: their
+                                                                // issue (it blocks while the L1 is busy) hides behind the MFMAs
         if (ks + 1 < KC / 2) {
             a = an;
 #pragma unroll
@@ -88,9 +91,12 @@ __device__ __forceinline__ void fetch_w_chunk(WChunk& r, const float* __restrict
     for (int q = 0; q < 8; ++q) {
         const int f = q * FT + tid;
         const int k = k0 + (f >> 6), c = c0 + 4 * (f & 63);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < nrows && c < ncols) v = *reinterpret_cast<const float4*>(W + (size_t)k * ld + c);     // ncols % 4 == 0 (padded widths)
-        r.v[q] = v;
+        // branch-free (a clamped, always valid address + a select): every load of the chunk sits in one basic block, so the
+        // compiler issues them back to back and waits once; ncols % 4 == 0 (padded widths)
+        // (the mask is a MULTIPLICATION: a select would let the compiler sink the load back under a branch; the data are finite)
+        const float ok = k < nrows && c < ncols ? 1.0f : 0.0f;
+        const float4 v = *reinterpret_cast<const float4*>(W + (size_t)min(k, nrows - 1) * ld + min(c, ncols - 4));
+        r.v[q] = make_float4(v.x * ok, v.y * ok, v.z * ok, v.w * ok);
     }
 }
 __device__ __forceinline__ void commit_w_chunk(float* wc, const WChunk& r, int tid) {
@@ -113,6 +119,14 @@ __device__ __forceinline__ float fwd_gate(float a, float g) {
     return copysignf((1.0f - e) * r, a);
 }
 
+#ifdef WNV_FWD_TRACE
+// debug build: per-phase cycles of wave 0 of every workgroup, summed (s_memtime), read back by the host after the last layer
+__device__ unsigned long long g_fwd_phase[16];
+#define FWD_STAMP(k) do { const unsigned long long now__ = __builtin_readcyclecounter(); ph__[k] += now__ - t_prev__; t_prev__ = now__; } while (0)
+#else
+#define FWD_STAMP(k) do { } while (0)
+#endif
+
 struct LayerArgs {
     const float* Hin; float* Hout; float* Skip;        // (B, T, 128), (B, T, 128), (B, T, K)
     const float* c_up;                                  // (B, T, cin) or null
@@ -124,28 +138,24 @@ struct LayerArgs {
 // activation chunk kc of GEMM1 for time row m (thread = (m, eight K values)): tap j of the dilated conv (oldest first,
 // conv.py:55-61) or the local conditioning row c[t] (modules.py:141-144)
 __device__ __forceinline__ void fetch_x_chunk(float (&v)[8], const LayerArgs& a, const float* Hin, int b, long long t, int kc, int sub) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    if (t >= a.T) return;
-    if (kc < 4 * a.kw) {
-        const int j = kc >> 2, ch0 = 32 * (kc & 3) + 8 * sub;
-        const long long tt = t - (long long)(a.kw - 1 - j) * a.d;
-        if (tt >= 0) {
-            const float4 p = *reinterpret_cast<const float4*>(Hin + (size_t)tt * HC + ch0);
-            const float4 q = *reinterpret_cast<const float4*>(Hin + (size_t)tt * HC + ch0 + 4);
-            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
-        }
-    } else if (a.c_up) {
-        const int c0 = 32 * (kc - 4 * a.kw) + 8 * sub;
-        const float* cr = a.c_up + ((size_t)b * a.T + t) * a.cin;
-        if (c0 + 7 < a.cin && (a.cin & 3) == 0) {
-            const float4 p = *reinterpret_cast<const float4*>(cr + c0), q = *reinterpret_cast<const float4*>(cr + c0 + 4);
-            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = p.w; v[4] = q.x; v[5] = q.y; v[6] = q.z; v[7] = q.w;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) if (c0 + e < a.cin) v[e] = cr[c0 + e];
-        }
-    }
+    // branch-free (selected pointers, clamped addresses, zeros selected afterwards: rows before t = 0, rows past T, channels past
+    // cin), so that the two loads share a basic block with the MFMAs they are scheduled between
+    const long long tc = min(t, a.T - 1);
+    const bool tap = kc < 4 * a.kw;                               // uniform across the workgroup
+    const int j = kc >> 2, ch0 = 32 * (kc & 3) + 8 * sub;
+    const long long tt = tc - (long long)(a.kw - 1 - j) * a.d;
+    const int c0 = 32 * (kc - 4 * a.kw) + 8 * sub;                // cin % 4 == 0 on this path (checked by the host)
+    const float* cr = a.c_up ? a.c_up + ((size_t)b * a.T + tc) * a.cin : Hin;
+    const int cmax = a.cin > 4 ? a.cin - 4 : 0;
+    const float* tsrc = Hin + (size_t)max(tt, 0ll) * HC + ch0;
+    const float* src_p = tap ? tsrc : cr + min(max(c0, 0), cmax);
+    const float* src_q = tap ? tsrc + 4 : cr + min(max(c0 + 4, 0), cmax);
+    const float4 p = *reinterpret_cast<const float4*>(src_p);
+    const float4 q = *reinterpret_cast<const float4*>(src_q);
+    const float ok_p = t < a.T && (tap ? tt >= 0 : c0 < a.cin) ? 1.0f : 0.0f;          // masks by multiplication (see fetch_w_chunk)
+    const float ok_q = t < a.T && (tap ? tt >= 0 : c0 + 4 < a.cin) ? 1.0f : 0.0f;
+    v[0] = p.x * ok_p; v[1] = p.y * ok_p; v[2] = p.z * ok_p; v[3] = p.w * ok_p;
+    v[4] = q.x * ok_q; v[5] = q.y * ok_q; v[6] = q.z * ok_q; v[7] = q.w * ok_q;
 }
 
 __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a) {
@@ -171,21 +181,30 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
     const int ncol1[4] = {64 * cb, 64 * cb + 32, HC + 64 * cb, HC + 64 * cb + 32};      // tanh tiles, sigmoid tiles of the same channels
     float xr[8];
     WChunk wr;
+#ifdef WNV_FWD_TRACE
+    unsigned long long ph__[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // accumulated locally, published once at the end
+    unsigned long long t_prev__ = __builtin_readcyclecounter();
+#endif
     fetch_x_chunk(xr, a, Hin, b, t0 + xm, 0, xsub);
     fetch_w_chunk(wr, a.w_in, 256, Kin, 256, 0, 0, tid);
     for (int kc = 0; kc < nchunk; ++kc) {
         if (kc > 0) __syncthreads();                              // the matrix cores are done with the previous chunk
+        FWD_STAMP(kc == 0 ? 0 : 1);                               // 0: prologue  1: wait for the slowest wave's MFMAs
 #pragma unroll
         for (int e = 0; e < 8; ++e) s.xt[(8 * xsub + e) * XS + xm] = xr[e];
         commit_w_chunk(s.wc, wr, tid);
+        FWD_STAMP(2);                                             // 2: vmcnt wait + LDS commit
         __syncthreads();
-        if (kc + 1 < nchunk) {                                    // next chunk: in flight under this chunk's MFMAs
-            fetch_x_chunk(xr, a, Hin, b, t0 + xm, kc + 1, xsub);
-            fetch_w_chunk(wr, a.w_in, 256, Kin, 256, (kc + 1) * KC, 0, tid);
-        } else {
-            fetch_w_chunk(wr, a.w_os, a.nosp, HC, ntot, 0, 0, tid);                    // first chunk of GEMM2
+        FWD_STAMP(3);                                             // 3: commit barrier
+        {   // next chunk (after the last one: the first chunk of GEMM2), selected without a branch so that its loads can be
+            // scheduled between this chunk's MFMAs
+            const bool more = kc + 1 < nchunk;
+            fetch_x_chunk(xr, a, Hin, b, t0 + xm, more ? kc + 1 : kc, xsub);           // (after the last chunk: re-read, unused)
+            fetch_w_chunk(wr, more ? a.w_in : a.w_os, more ? 256 : a.nosp, more ? Kin : HC, more ? 256 : ntot, more ? (kc + 1) * KC : 0, 0, tid);
         }
+        FWD_STAMP(4);                                             // 4: issue of the next fetch
         mfma_chunk<4>(acc, s.xt, m0, s.wc, ncol1, lane);
+        FWD_STAMP(5);                                             // 5: GEMM1 MFMA phase
     }
     // ---- bias (+ global conditioning), tanh . sigmoid -> U tile, K-major ---------------------------------------------------
     {
@@ -199,6 +218,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
                 s.ut[ch * XS + m0 + acc_row(v, lane)] = fwd_gate(acc[j][v] + za, acc[2 + j][v] + zg);      // modules.py:152-154
         }
     }
+    FWD_STAMP(6);                                                 // 6: gate
     // ---- GEMM2: [out | skip] = U [W_out | W_skip], in column blocks of 256 ---------------------------------------------------
     for (int c0 = 0; c0 < ntot; c0 += 256) {
 #pragma unroll
@@ -214,24 +234,72 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
             else if (c0 + 256 < ntot) fetch_w_chunk(wr, a.w_os, a.nosp, HC, ntot, 0, c0 + 256, tid);
             mfma_chunk<4>(acc, s.ut + kc * KC * XS, m0, s.wc, ncol2, lane);
         }
+        FWD_STAMP(7);                                             // 7: GEMM2 (barriers, commits, MFMAs)
+        // epilogue in two passes: every residual / skip value this thread needs is requested first (64 loads in flight), then the
+        // results are combined and stored.  (Load -> add -> store per element serialises on the memory latency: the compiler
+        // cannot prove that Hout / Skip do not alias Hin; the phase trace showed 43 % of a workgroup's time here.)
+        const bool interior = t0 + TM <= a.T && c0 + 256 <= ntot;        // uniform: no per-element conditions, no branches
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gc = c0 + 128 * cb + 32 * i + (lane & 31);
-            if (gc >= ntot) continue;
-            const float bias = a.b_os[gc];
+        for (int half = 0; half < 2; ++half) {                          // two tiles at a time: 32 loads in flight, 32 registers
+            float prev[2][16];
+            if (interior) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const long long t = t0 + m0 + acc_row(v, lane);
-                if (t >= a.T) continue;
-                if (gc < HC) {                                           // (out + residual) * sqrt(0.5), modules.py:157-162
-                    a.Hout[((size_t)b * a.T + t) * HC + gc] = (acc[i][v] + bias + Hin[(size_t)t * HC + gc]) * 0.70710678118654752440f;
-                } else {                                                 // skips += s, wavenet.py:196-198
-                    float* sp = a.Skip + ((size_t)b * a.T + t) * a.K + (gc - HC);
-                    *sp += acc[i][v] + bias;
+                for (int j = 0; j < 2; ++j) {
+                    const int gc = c0 + 128 * cb + 32 * (2 * half + j) + (lane & 31);
+                    const float* src = gc < HC ? Hin + gc : a.Skip + (size_t)b * a.T * a.K + (gc - HC);
+                    const long long ld = gc < HC ? HC : a.K;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) prev[j][v] = src[(size_t)(t0 + m0 + acc_row(v, lane)) * ld];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int i = 2 * half + j;
+                    const int gc = c0 + 128 * cb + 32 * i + (lane & 31);
+                    const float bias = a.b_os[gc];
+                    float* dst = gc < HC ? a.Hout + (size_t)b * a.T * HC + gc : a.Skip + (size_t)b * a.T * a.K + (gc - HC);
+                    const long long ld = gc < HC ? HC : a.K;
+                    const float scale = gc < HC ? 0.70710678118654752440f : 1.0f;     // (out + residual) * sqrt(0.5) | skips += s
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) dst[(size_t)(t0 + m0 + acc_row(v, lane)) * ld] = (prev[j][v] + (acc[i][v] + bias)) * scale;
+                }
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int gc = c0 + 128 * cb + 32 * (2 * half + j) + (lane & 31);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const long long t = t0 + m0 + acc_row(v, lane);
+                    prev[j][v] = 0.f;
+                    if (gc < ntot && t < a.T)
+                        prev[j][v] = gc < HC ? Hin[(size_t)t * HC + gc] : a.Skip[((size_t)b * a.T + t) * a.K + (gc - HC)];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = 2 * half + j;
+                const int gc = c0 + 128 * cb + 32 * i + (lane & 31);
+                if (gc >= ntot) continue;
+                const float bias = a.b_os[gc];
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const long long t = t0 + m0 + acc_row(v, lane);
+                    if (t >= a.T) continue;
+                    if (gc < HC)                                         // (out + residual) * sqrt(0.5), modules.py:157-162
+                        a.Hout[((size_t)b * a.T + t) * HC + gc] = (prev[j][v] + (acc[i][v] + bias)) * 0.70710678118654752440f;
+                    else                                                 // skips += s, wavenet.py:196-198
+                        a.Skip[((size_t)b * a.T + t) * a.K + (gc - HC)] = prev[j][v] + (acc[i][v] + bias);
                 }
             }
         }
+        FWD_STAMP(8);                                             // 8: epilogue (residual / skip read-modify-write)
     }
+#ifdef WNV_FWD_TRACE
+    if (tid == 0) {
+        for (int k = 0; k < 9; ++k) atomicAdd(&g_fwd_phase[k], ph__[k]);
+        atomicAdd(&g_fwd_phase[15], 1ull);
+    }
+#endif
 }
 
 struct HeadArgs {
@@ -342,6 +410,7 @@ const char* wnv_forward_why_not(const WnvModelDev& m) {
     if (m.K % HC != 0) return "needs skip_out_channels to be a multiple of 128";
     if (m.O > 256) return "needs out_channels <= 256";
     if (m.Rp != m.R) return "padded residual width";
+    if (m.cin > 0 && (m.cin & 3) != 0) return "needs cin_channels to be a multiple of 4";
     return nullptr;
 }
 
@@ -380,6 +449,22 @@ hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_ho
         hipLaunchKernelGGL(wnv_fwd_layer_kernel, dim3((unsigned)(B * tiles)), dim3(FT), lds, s, la);
         std::swap(in, out);
     }
+#ifdef WNV_FWD_TRACE
+    {
+        unsigned long long ph[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(ph, HIP_SYMBOL(g_fwd_phase), sizeof ph);
+        const double n = (double)ph[15];
+        static const char* names[9] = {"prologue (first fetch)", "barrier after MFMAs", "vmcnt wait + LDS commit", "commit barrier", "issue next fetch",
+                                       "GEMM1 MFMA phase", "gate", "GEMM2", "epilogue"};
+        double tot = 0;
+        for (int k = 0; k < 9; ++k) tot += (double)ph[k];
+        fprintf(stderr, "[wnv_forward trace] %.0f workgroup-layers, cycles per workgroup (wave 0), total %.0f:\n", n, tot / n);
+        for (int k = 0; k < 9; ++k) fprintf(stderr, "   %-26s %10.0f  %5.1f %%\n", names[k], (double)ph[k] / n, 100.0 * (double)ph[k] / tot);
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_phase), z, sizeof z);
+    }
+#endif
     HeadArgs ha{};
     ha.Skip = Skip; ha.out = a.out; ha.w_h1 = d_W + m.w_h1; ha.b_h1 = d_W + m.b_h1; ha.w_h2 = d_W + m.w_h2; ha.b_h2 = d_W + m.b_h2;
     ha.T = T; ha.tiles_per_utt = tiles; ha.K = m.K; ha.kp = m.Kp; ha.O = m.O; ha.op = m.Op; ha.scale = m.skip_scale;
