@@ -32,3 +32,20 @@ print(f"T = {T} (10 s of audio x 8): {dt:.2f} s wall incl. input generation, std
 pre, _, _ = eng.generate(B=8, T=4096, c_up=cond(8, T, 3)[:, :4096].contiguous(), seed=3, kernel=2)
 assert torch.equal(pre, out[:, :, :4096]), "prefix property at length"
 print("prefix property holds")
+# the wide-skip instantiations (K = 256 one-hot with two head parts, K = 512 with four): repeated launches, determinism
+for name, Bs in (("cfg1_mulaw256", (1, 8)), ("cfg4_mol_multispeaker", (8, 16))):
+    from tests._configs import inputs
+    mm = build(name).to("cuda")
+    ee = mm._get_engine()
+    t0 = time.time()
+    for B in Bs:
+        T = 2048
+        c, gids = inputs(name, B, T)
+        c_up = ee.upsample(c.cuda(), T_expected=T)
+        gi = None if gids is None else gids[:, 0].cuda()
+        first = None
+        for i in range(20):
+            out, _, _ = ee.generate(B=B, T=T, c_up=c_up, g_ids=gi, seed=5, kernel=2)
+            if first is None: first = out.clone()
+            assert torch.equal(out, first) and torch.isfinite(out).all(), (name, B, i)
+    print(f"{name}: 20 launches each at B = {Bs}: identical ({time.time()-t0:.1f} s)")

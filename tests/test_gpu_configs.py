@@ -121,3 +121,34 @@ def test_philox_mode_runs_and_is_seeded():
     d, _, _ = eng.generate(B=2, T=512, c_up=c_up, seed=124, kernel=1)
     assert torch.equal(a, b) and not torch.equal(a, d)
     assert float(a.abs().max()) <= 1.0 and torch.isfinite(a).all()
+
+
+@pytest.mark.parametrize("net,cin_pad,scales,Tc", [("ConvInUpsampleNetwork", 2, [4, 4, 4, 4], 37), ("UpsampleNetwork", 2, [4, 4, 4, 4], 21),
+                                                   ("ConvInUpsampleNetwork", 0, [16, 16], 9), ("ConvInUpsampleNetwork", 1, [2, 8, 4], 13)])
+def test_upsampler_at_size_vs_oracle(net, cin_pad, scales, Tc):
+    """The prologue at realistic sizes (the LDS-tiled time-major last stage, both networks, the trimmed `indent` path of the plain
+    network, other scale sets) against the oracle's torch-CPU upsampler."""
+    import numpy as np
+    import wavenet_vocoder_amd as wnv
+    hop = int(np.prod(scales))
+    kw = dict(out_channels=30, layers=4, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
+              dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=80, cin_pad=cin_pad,
+              upsample_conditional_features=True, upsample_net=net,
+              upsample_params=dict(upsample_scales=scales, **({"cin_channels": 80, "cin_pad": cin_pad} if net == "ConvInUpsampleNetwork" else {"cin_pad": cin_pad})))
+    torch.manual_seed(4)
+    m = wnv.WaveNet(**kw).eval()
+    with torch.no_grad():                                       # the reference initialises the FIRs to constants: randomise them
+        for name, p in m.named_parameters():
+            if name.startswith("upsample_net"):
+                p.copy_(torch.randn_like(p) * 0.3)
+    o = Oracle(oracle_config(kw), m.state_dict())
+    B = 3
+    c = torch.randn(B, 80, Tc + 2 * cin_pad, generator=torch.Generator().manual_seed(5))
+    want = o.upsample(c)                                        # (B, 80, T)
+    T = Tc * hop
+    assert want.shape == (B, 80, T)
+    eng = m.to("cuda")._get_engine()
+    got = eng.upsample(c.cuda(), T_expected=T)                  # (B, T, 80) time-major
+    assert got.shape == (B, T, 80)
+    err = (got.cpu().transpose(1, 2) - want).abs().max().item()
+    assert err < 1e-5 * max(1.0, want.abs().max().item()), err          # values reach ~10 with the randomised filters

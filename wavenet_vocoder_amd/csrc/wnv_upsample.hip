@@ -6,9 +6,11 @@
 // mel bins -- and finally the (B, C, T) -> (B, T, C) transpose of wavenet.py:277-278.
 //
 // These are HBM-bound streaming kernels (the output, 4*cin bytes per audio sample per utterance, dominates).
-// The last stage writes the time-major layout directly so the sample loop reads one contiguous cin-float row per
-// step.  Round-1 form: one launch per stage, one output element per thread; the stages run once per batch and
-// are < 1 % of a synthesis call, so fusing them is scheduled behind the sample loop work.
+// The LAST stage -- 80 % of the bytes: it reads (B, cin, T/s) and writes the time-major (B, T, cin) the sample loop reads one
+// contiguous row of per step -- is LDS-tiled (wnv_stretch_fir_tm_kernel): a workgroup stages the [cin][64 + 2] input window of
+// 64 s output samples with row-contiguous reads, then streams the outputs in memory order (consecutive lanes = consecutive
+// channels of one sample, then the next sample): every global access is a full-line burst.  The earlier stages are 4x, 16x, ...
+// smaller and keep the one-element-per-thread form.
 #include "wnv_internal.h"
 
 namespace {
@@ -63,6 +65,45 @@ __global__ void wnv_stretch_fir_kernel(const float* __restrict__ in, const float
     }
 }
 
+// Last stage, time-major output.  out[b][j][ch] = sum_m w[m] rep[j + indent + m - s],  rep[q] = in[b][ch][q / s] (0 outside);
+// with J = (j0 + indent) / s (indent and the tile origin j0 are multiples of s) the window row of tap m of local sample tl is
+// simply (tl + m) / s.  The taps are accumulated in the order m = 0 .. 2s, like the per-element kernel (bit-identical results).
+constexpr int UT = 256;
+__global__ void __launch_bounds__(UT) wnv_stretch_fir_tm_kernel(const float* __restrict__ in, const float* __restrict__ w,
+                                                                float* __restrict__ out, int cin, long long Tin, int scale,
+                                                                long long indent, long long Tout, int ni, int tiles) {
+    extern __shared__ float win[];                         // [cin][ni + 2 (+1: odd stride)]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / tiles;
+    const long long j0 = (long long)(blockIdx.x % tiles) * ni * scale;
+    const long long ibase = (j0 + indent) / scale - 1;
+    const int np = ni + 2, ls = np | 1;
+    const float* src = in + (size_t)b * cin * Tin;
+    for (int i = tid; i < cin * np; i += UT) {
+        const int ch = i / np, p = i - ch * np;
+        const long long q = ibase + p;
+        win[ch * ls + p] = (q >= 0 && q < Tin) ? src[(size_t)ch * Tin + q] : 0.f;
+    }
+    float wr[33];
+#pragma unroll
+    for (int m = 0; m < 33; ++m) wr[m] = m <= 2 * scale ? w[m] : 0.f;
+    __syncthreads();
+    const long long nout = min((long long)ni * scale, Tout - j0);
+    float* dst = out + ((size_t)b * Tout + j0) * cin;
+    for (long long i = tid; i < nout * cin; i += UT) {
+        const int tl = (int)(i / cin), ch = (int)(i - (long long)tl * cin);
+        const float* row = win + ch * ls;
+        float acc = 0.f;
+        if (scale == 4) {
+#pragma unroll
+            for (int m = 0; m <= 8; ++m) acc = fmaf(wr[m], row[(tl + m) >> 2], acc);
+        } else {
+            for (int m = 0; m <= 2 * scale; ++m) acc = fmaf(w[m], row[(tl + m) / scale], acc);
+        }
+        dst[i] = acc;
+    }
+}
+
 __global__ void wnv_transpose_bct_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int cin,
                                          long long T) {
     const long long total = (long long)B * cin * T;
@@ -94,6 +135,19 @@ hipError_t wnv_launch_conv_in(const float* c, const float* w, float* out, int B,
 hipError_t wnv_launch_stretch_fir(const float* in, const float* w, float* out, int B, int cin, long long Tin,
                                   int scale, int transpose_out, long long indent, hipStream_t s) {
     const long long total = (long long)B * cin * (Tin * scale - 2 * indent);
+    if (transpose_out && scale <= 16 && indent % scale == 0 && cin <= 2048) {
+        // LDS-tiled last stage: ni input samples per tile such that the window fits 48 KiB
+        int ni = 64;
+        while (ni > 1 && (size_t)cin * ((ni + 2) | 1) * sizeof(float) > 48 * 1024) ni >>= 1;
+        const long long Tout = Tin * scale - 2 * indent;
+        const long long tiles = (Tout + (long long)ni * scale - 1) / ((long long)ni * scale);
+        if ((long long)B * tiles <= 0x7fffffffll && (size_t)cin * ((ni + 2) | 1) * sizeof(float) <= 64 * 1024) {
+            const size_t lds = (size_t)cin * ((ni + 2) | 1) * sizeof(float);
+            hipLaunchKernelGGL(wnv_stretch_fir_tm_kernel, dim3((unsigned)(B * tiles)), dim3(UT), lds, s, in, w, out, cin, Tin, scale,
+                               indent, Tout, ni, (int)tiles);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(wnv_stretch_fir_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w, out, B, cin, Tin,
                        scale, transpose_out, indent);
     return hipGetLastError();
