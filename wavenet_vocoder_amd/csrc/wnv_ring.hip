@@ -807,9 +807,10 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 }
                 if (!ok) s.flags[0] = 1;
             };
-            // the h recurrence is what the next-but-one stage waits for; only at the last stage the skip sum (the head's
-            // input) is the urgent one
-            if (last_stage) { skip_phase(); stamp(p, b, t, sidx, 3); h_phase(); stamp(p, b, t, sidx, 2); }
+            // the h recurrence is what the next-but-one stage waits for; at the last stage the skip sum (the head's input) is the
+            // urgent one -- and at the stage before it too: what it adds to the skip chain is what the last stage waits for,
+            // while its h output only feeds off-chain consumers (the last stage's history push)
+            if (last_stage || sidx == p.S - 2) { skip_phase(); stamp(p, b, t, sidx, 3); h_phase(); stamp(p, b, t, sidx, 2); }
             else { h_phase(); stamp(p, b, t, sidx, 2); skip_phase(); stamp(p, b, t, sidx, 3); }
             // ---- history push + next step's pre-activations (its barriers fence the LDS vectors for the next step) -------
             __syncthreads();                        // fences the LDS vectors against the next step; makes flags[0] uniform
