@@ -10,7 +10,6 @@ after ``make_generation_fast_``); ``load_state_dict`` also accepts the weight-no
 """
 from __future__ import annotations
 
-import torch
 from torch import nn
 
 from .engine import QueueConv, require_gpu_tensor

@@ -7,7 +7,7 @@ HIP stream to launch on, and moving weights to the host once.  All arithmetic ha
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Iterable, Optional, Sequence
+from typing import Dict, Optional, Sequence
 
 import torch
 

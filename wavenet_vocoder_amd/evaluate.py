@@ -19,7 +19,7 @@ import struct
 from dataclasses import dataclass
 from glob import glob
 from os.path import basename, exists, join, splitext
-from typing import Callable, List, Optional, Sequence
+from typing import Callable, List, Optional
 
 import numpy as np
 import torch

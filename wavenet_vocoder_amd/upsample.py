@@ -5,7 +5,6 @@ torch ops; inside ``WaveNet.incremental_forward`` the upsampling runs in the HIP
 from __future__ import annotations
 
 import numpy as np
-import torch
 from torch import nn
 from torch.nn import functional as F
 
