@@ -130,3 +130,21 @@ def test_mel_create_argument_errors():
         with pytest.raises(exc):
             _lib.check(lib.wnv_mel_create(C.byref(cfg), -1, C.byref(h)))
     assert lib.wnv_mel_frames(None, 10) == -1
+
+
+def test_host_mirror_argument_checks_need_no_gpu():
+    """audio.MelFrontEnd refuses a CPU device (no CPU path), other windows and pad modes, and fmax above Nyquist (audio.py:153-154);
+    get_hop_size / get_win_length follow audio.py:112-125."""
+    from wavenet_vocoder_amd import audio
+    hp = default_hparams()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        audio.MelFrontEnd(hp, device="cpu")
+    with pytest.raises(NotImplementedError):
+        audio.MelFrontEnd(default_hparams(window="hamming"), device="cpu")
+    with pytest.raises(NotImplementedError):
+        audio.MelFrontEnd(hp, device="cpu", pad_mode="edge")
+    with pytest.raises(AssertionError):
+        audio.MelFrontEnd(default_hparams(fmax=12000), device="cpu")
+    assert get_hop_size(default_hparams(hop_size=None, frame_shift_ms=12.5)) == int(12.5 / 1000 * 22050)
+    assert get_win_length(default_hparams(win_length=-1, win_length_ms=50.0)) == int(50.0 / 1000 * 22050)
+    assert get_hop_size(hp) == 256 and get_win_length(hp) == 1024
