@@ -85,6 +85,28 @@ __global__ void __launch_bounds__(64) rtt_kernel(P p) {
     if (threadIdx.x == 0) { p.stamps[0] = t0; p.stamps[1] = wall_clock64(); p.stamps[2] = acc; }
 }
 
+// lone round trips of WIDE polls: every lane its own granule(s): 64 x 8 B = 4 lines, 64 x 16 B = 8 lines (the ring kernel's poll)
+template <int W>
+__global__ void __launch_bounds__(64) rtt_wide_kernel(P p, u64* wide) {
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    const u64 t0 = wall_clock64();
+    unsigned acc = 0;
+    for (int r = 0; r < p.n; ++r) {
+        if (W == 8) {
+            u64 v;
+            asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(wide + lane + (acc & 1)) : "memory");
+            acc += (unsigned)v;
+        } else {
+            typedef unsigned v4 __attribute__((ext_vector_type(4)));
+            v4 v;
+            asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(wide + 2 * lane + 2 * (acc & 1)) : "memory");
+            acc += v.x + v.z;
+        }
+    }
+    if (lane == 0) { p.stamps[0] = t0; p.stamps[1] = wall_clock64(); p.stamps[2] = acc; }
+}
+
 typedef void (*kern_t)(P);
 static kern_t pick(int st, int ld) {
 #define C(S, L) if (st == S && ld == L) return hop1_kernel<S, L>;
@@ -130,6 +152,18 @@ int main() {
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(s, p.stamps, 64, hipMemcpyDeviceToHost));
         printf("  scalar glc   %7.1f ns\n", (double)(s[1] - s[0]) * 10.0 / p.n);
+    }
+    {
+        u64* wide; CK(hipMalloc(&wide, 4096)); CK(hipMemset(wide, 0, 4096));
+        u64 s[8];
+        hipLaunchKernelGGL(rtt_wide_kernel<8>, dim3(1), dim3(64), 0, 0, p, wide);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(s, p.stamps, 64, hipMemcpyDeviceToHost));
+        printf("  vector sc1, 64 lanes x 8 B (4 lines)   %7.1f ns\n", (double)(s[1] - s[0]) * 10.0 / p.n);
+        hipLaunchKernelGGL(rtt_wide_kernel<16>, dim3(1), dim3(64), 0, 0, p, wide);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(s, p.stamps, 64, hipMemcpyDeviceToHost));
+        printf("  vector sc1, 64 lanes x 16 B (8 lines)  %7.1f ns\n", (double)(s[1] - s[0]) * 10.0 / p.n);
     }
     return 0;
 }
