@@ -1,26 +1,31 @@
-"""Input-type predicates (same names and meaning as the reference's wavenet_vocoder/util.py:9-25)."""
+"""Input-type predicates of the reference (``wavenet_vocoder/util.py:9-25``): same function names, same answers, same
+AssertionError for an unknown ``input_type``.  The three types and what they mean for the engine:
 
-_VALID = ("mulaw-quantize", "mulaw", "raw")
+    "raw"             scalar waveform in [-1, 1]                  -> scalar_input, MoL / Gaussian head
+    "mulaw"           mu-law companded scalar in [-1, 1]          -> scalar_input, MoL / Gaussian head
+    "mulaw-quantize"  mu-law class index, fed back as a one-hot   -> categorical head
+"""
 
-
-def _check(s):
-    assert s in _VALID, f"input_type must be one of {_VALID}, got {s!r}"
-
-
-def is_mulaw_quantize(s):
-    _check(s)
-    return s == "mulaw-quantize"
+_SCALAR = {"raw": True, "mulaw": True, "mulaw-quantize": False}
 
 
-def is_mulaw(s):
-    _check(s)
-    return s == "mulaw"
+def _scalar(input_type):
+    assert input_type in _SCALAR, f"unknown input_type {input_type!r} (expected one of {sorted(_SCALAR)})"
+    return _SCALAR[input_type]
 
 
-def is_raw(s):
-    _check(s)
-    return s == "raw"
+def is_scalar_input(input_type):
+    """True for the two scalar-sample types ("raw", "mulaw")."""
+    return _scalar(input_type)
 
 
-def is_scalar_input(s):
-    return is_raw(s) or is_mulaw(s)
+def is_mulaw_quantize(input_type):
+    return not _scalar(input_type)
+
+
+def is_mulaw(input_type):
+    return _scalar(input_type) and input_type == "mulaw"
+
+
+def is_raw(input_type):
+    return _scalar(input_type) and input_type == "raw"
