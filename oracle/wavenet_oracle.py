@@ -2,7 +2,7 @@
 
 TEST INFRASTRUCTURE -- NOT PRODUCT CODE.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
 ``cpu_baseline`` leg of ``bench.py`` may import this module; nothing under ``wavenet_vocoder_amd/``
-does (``tests/test_no_oracle_in_product.py`` enforces it).  The product path is the HIP engine behind
+does (``tests/test_host_cpu.py::test_product_never_imports_the_oracle`` enforces it).  The product path is the HIP engine behind
 ``include/wnv.h``; it fails loudly when its shared library is missing and never falls back to this file.
 
 What it is: a plain ``torch``-on-CPU, float32 restatement of the reference algorithm
