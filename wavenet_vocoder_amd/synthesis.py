@@ -28,7 +28,8 @@ def default_hparams(**over) -> SimpleNamespace:
     """The fields batch_wavegen reads, with the values of the reference's egs/mol preset (hparams.py)."""
     h = SimpleNamespace(input_type="raw", quantize_channels=65536, upsample_conditional_features=True, cin_pad=2,
                         hop_size=256, log_scale_min=-32.23619130191664, postprocess="inv_preemphasis",
-                        global_gain_scale=0.55, preemphasis_coef=0.85)
+                        global_gain_scale=0.55, preemphasis_coef=0.85,
+                        cin_channels=80, sample_rate=22050, batch_size=8)        # read by evaluate.synthesize_dir
     h.__dict__.update(over)
     return h
 
