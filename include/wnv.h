@@ -96,7 +96,9 @@ typedef struct wnv_engine* wnv_handle;
 
 /* ---- life cycle ------------------------------------------------------------------------------ */
 
-/* Replaces WaveNet.__init__ (wavenet.py:98-156).  Synchronous. */
+/* Replaces WaveNet.__init__ (wavenet.py:98-156).  Synchronous.  device = -1 creates a HOST-ONLY handle: wnv_load_weights
+ * validates, folds and packs a checkpoint without touching a device (wnv_bytes_per_step / wnv_macs_per_sample work);
+ * wnv_upsample / wnv_generate / wnv_forward refuse it -- there is no CPU path. */
 wnv_status wnv_create(const wnv_config* cfg, int32_t device, wnv_handle* out);
 wnv_status wnv_destroy(wnv_handle h);
 

@@ -180,3 +180,99 @@ def test_ring_kernel_keeps_its_poll_registers_out_of_the_compilers_hands(tmp_pat
         meta = re.search(rf"\.name:\s+_ZN\S*wnv_ring_kernelILi{nk}E\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
         assert meta and int(meta.group(1)) == 0, "the capped kernel spills"
     assert checked == 2
+
+
+# ---- host-only handles (wnv_create with device = -1): the native checkpoint path without a GPU ------------------------------
+def _host_only_engine(kw):
+    import ctypes as C
+    from wavenet_vocoder_amd import _lib
+    from wavenet_vocoder_amd.engine import make_config
+    up = kw.get("upsample_params", {})
+    cond = kw.get("upsample_conditional_features", False) and kw.get("cin_channels", -1) > 0
+    cfg = make_config(out_channels=kw["out_channels"], layers=kw["layers"], stacks=kw["stacks"],
+                      residual_channels=kw["residual_channels"], gate_channels=kw["gate_channels"],
+                      skip_out_channels=kw["skip_out_channels"], kernel_size=kw["kernel_size"],
+                      cin_channels=kw.get("cin_channels", -1), gin_channels=kw.get("gin_channels", -1),
+                      n_speakers=kw.get("n_speakers") or 0, use_speaker_embedding=kw.get("use_speaker_embedding", False),
+                      scalar_input=kw.get("scalar_input", False), output_distribution=kw.get("output_distribution", "Logistic"),
+                      upsample_net=kw.get("upsample_net", "ConvInUpsampleNetwork") if cond else None,
+                      upsample_scales=up.get("upsample_scales", []) if cond else [],
+                      freq_axis_kernel_size=up.get("freq_axis_kernel_size", 1), cin_pad=kw.get("cin_pad", 0))
+    h = C.c_void_p()
+    _lib.check(_lib.lib().wnv_create(C.byref(cfg), -1, C.byref(h)))
+    return h
+
+
+def _load(h, state):
+    from wavenet_vocoder_amd import _lib
+    from wavenet_vocoder_amd.engine import _tensor_table
+    arr, keep = _tensor_table(state)
+    try:
+        _lib.check(_lib.lib().wnv_load_weights(h, arr, len(state)))
+    finally:
+        del keep
+
+
+def test_native_checkpoint_path_without_a_gpu():
+    """libwnv_hip.so validates, folds and packs a reference state_dict on the host (device = -1): both checkpoint layouts of
+    every golden case load; the algorithmic work it reports matches SURVEY.md 8d; device entry points refuse the handle."""
+    import ctypes as C
+    from tests._configs import CONFIGS, build
+    from wavenet_vocoder_amd import _lib
+    lib = _lib.lib()
+    for name in CASE_NAMES:
+        c = Case(name)
+        for state in (c.wn, c.fused):
+            h = _host_only_engine(c.kwargs)
+            try:
+                _load(h, state)
+                assert lib.wnv_macs_per_sample(h) > 0
+            finally:
+                lib.wnv_destroy(h)
+    # egs/mol (cfg2): 3 657 600 MAC per sample, 15 076 504 algorithmic bytes per step at B = 8 (SURVEY.md 8d)
+    m = build("cfg2_mol")
+    h = _host_only_engine(CONFIGS["cfg2_mol"])
+    try:
+        _load(h, {k: v for k, v in m.state_dict().items()})
+        assert lib.wnv_macs_per_sample(h) == 3657600
+        assert lib.wnv_bytes_per_step(h, 8) == 15076504
+        a = _lib.GenerateArgs()
+        a.B, a.T = 1, 4
+        with pytest.raises(ValueError, match="host-only"):
+            _lib.check(lib.wnv_generate(h, C.byref(a)))
+        with pytest.raises(ValueError, match="host-only"):
+            _lib.check(lib.wnv_upsample(h, 1, 1, 8, 1, -1, None))
+        assert lib.wnv_reset(h) == 0
+    finally:
+        lib.wnv_destroy(h)
+
+
+def test_native_checkpoint_errors_without_a_gpu():
+    """Unknown key -> WNV_ERR_INVALID_ARG, missing tensor -> WNV_ERR_NOT_LOADED, wrong shape -> WNV_ERR_INVALID_ARG (the messages
+    mirror torch's load_state_dict)."""
+    from wavenet_vocoder_amd import _lib
+    c = Case("mol_upsample_convin")
+    lib = _lib.lib()
+    h = _host_only_engine(c.kwargs)
+    try:
+        bad = dict(c.fused)
+        bad["conv_layers.0.bogus.weight"] = torch.zeros(3)
+        with pytest.raises(ValueError, match="unexpected key"):
+            _load(h, bad)
+    finally:
+        lib.wnv_destroy(h)
+    h = _host_only_engine(c.kwargs)                  # (a handle keeps what earlier calls loaded: start afresh)
+    try:
+        missing = {k: v for k, v in c.fused.items() if k != "first_conv.bias"}
+        with pytest.raises(RuntimeError, match="missing tensor 'first_conv.bias'"):
+            _load(h, missing)
+    finally:
+        lib.wnv_destroy(h)
+    h = _host_only_engine(c.kwargs)
+    try:
+        wrong = dict(c.fused)
+        wrong["first_conv.bias"] = torch.zeros(wrong["first_conv.bias"].numel() + 1)
+        with pytest.raises(ValueError, match="size mismatch for first_conv.bias"):
+            _load(h, wrong)
+    finally:
+        lib.wnv_destroy(h)

@@ -157,9 +157,11 @@ extern "C" wnv_status wnv_create(const wnv_config* cfg, int32_t device, wnv_hand
     *out = nullptr;
     wnv_status st = validate_config(cfg);
     if (st != WNV_OK) return st;
-    int ndev = 0;
-    HIP_TRY(hipGetDeviceCount(&ndev));
-    if (device < 0 || device >= ndev) return fail(WNV_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
+    if (device != -1) {                            // -1: host-only handle (checkpoint validation, packing, introspection; no launches)
+        int ndev = 0;
+        HIP_TRY(hipGetDeviceCount(&ndev));
+        if (device < 0 || device >= ndev) return fail(WNV_ERR_INVALID_ARG, "device %d out of range (%d visible)", device, ndev);
+    }
     wnv_engine* h = new wnv_engine();
     h->cfg = *cfg;
     h->device = device;
@@ -187,6 +189,7 @@ extern "C" wnv_status wnv_destroy(wnv_handle h) {
 
 extern "C" wnv_status wnv_reset(wnv_handle h) {
     if (!h) return fail(WNV_ERR_INVALID_ARG, "handle is NULL");
+    if (h->device < 0) return WNV_OK;
     DeviceGuard g(h->device);
     HIP_TRY(hipDeviceSynchronize());
     h->ring.release(); h->zbias.release(); h->upA.release(); h->upB.release(); h->fwd.release();
@@ -290,6 +293,7 @@ static wnv_status pack(wnv_engine* h) {
         return fail(WNV_ERR_UNSUPPORTED, "configuration needs %zu bytes of LDS (> 160 KiB)", wnv_generic_lds_bytes(m));
     // upload
     h->w_floats = b.v.size();
+    if (h->device < 0) { h->packed = true; return WNV_OK; }       // host-only handle: validated and packed, nothing to upload
     HIP_TRY(hipMalloc((void**)&h->d_W, std::max<size_t>(b.v.size(), 4) * sizeof(float)));
     HIP_TRY(hipMemcpy(h->d_W, b.v.data(), b.v.size() * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&h->d_layers, L * sizeof(WnvLayerDev)));
@@ -355,6 +359,7 @@ extern "C" int64_t wnv_macs_per_sample(wnv_handle h) { return (h && h->packed) ?
 extern "C" wnv_status wnv_upsample(wnv_handle h, const float* c_in, int32_t B, int64_t Tc_in, float* c_up,
                                    int64_t T_expected, void* stream) {
     if (!h || !c_in || !c_up || B <= 0 || Tc_in <= 0) return fail(WNV_ERR_INVALID_ARG, "bad arguments to wnv_upsample");
+    if (h->device < 0) return fail(WNV_ERR_INVALID_ARG, "host-only handle (created with device = -1): there is no CPU path");
     if (!h->packed) return fail(WNV_ERR_NOT_LOADED, "weights are not loaded");
     const wnv_config& c = h->cfg;
     if (c.cin_channels <= 0) return fail(WNV_ERR_INVALID_ARG, "model has no local conditioning");
@@ -407,6 +412,7 @@ extern "C" wnv_status wnv_upsample(wnv_handle h, const float* c_in, int32_t B, i
 // ------------------------------------------------------------------------------------------------
 extern "C" wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* a) {
     if (!h || !a) return fail(WNV_ERR_INVALID_ARG, "NULL handle or args");
+    if (h->device < 0) return fail(WNV_ERR_INVALID_ARG, "host-only handle (created with device = -1): there is no CPU path");
     if (!h->packed) return fail(WNV_ERR_NOT_LOADED, "weights are not loaded");
     const WnvModelDev& m = h->m;
     if (a->B <= 0 || a->T <= 0 || a->T > 0x7fffffffLL) return fail(WNV_ERR_INVALID_ARG, "B and T must be positive (T < 2^31)");
@@ -436,6 +442,7 @@ extern "C" wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* a) {
 // ------------------------------------------------------------------------------------------------
 extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     if (!h || !a) return fail(WNV_ERR_INVALID_ARG, "NULL handle or args");
+    if (h->device < 0) return fail(WNV_ERR_INVALID_ARG, "host-only handle (created with device = -1): there is no CPU path");
     if (!h->packed) return fail(WNV_ERR_NOT_LOADED, "weights are not loaded");
     const wnv_config& c = h->cfg;
     const WnvModelDev& m = h->m;

@@ -35,6 +35,7 @@ struct DeviceGuard {
     int prev = -1;
     bool ok = true;
     explicit DeviceGuard(int dev) {
+        if (dev < 0) return;                       // host-only handle (wnv_create with device = -1): nothing to guard
         if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
         if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
     }
