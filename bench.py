@@ -13,11 +13,20 @@ step     : ONE pass of the hot path over one batch: wnv_upsample (mel -> sample 
 scaling  : weak -- every rank synthesises its own 8 utterances; no collective on the data path (utterances
            are independent); only the barrier/max-reduce around the timed region uses RCCL.
 kernel   : auto = the pipelined ring kernel (csrc/wnv_ring.hip) for this configuration.
+launch   : `python bench.py --gpus N` starts its own N ranks (one process per GPU, LOCAL_RANK = GPU index, rendezvous on
+           127.0.0.1) when WORLD_SIZE is not set; under `python -m torch.distributed.run ... bench.py --gpus N` it uses the
+           ranks it is given.  `--dry-run` exercises the same launch / barrier / max-reduce / single-JSON-line plumbing on
+           CPU (gloo, no engine) -- tests/test_bench_launch_cpu.py.
 roofline : the dominant kernel is the sample-loop kernel.  achieved = algorithmic bytes per launch
            (wnv_bytes_per_step(B) x T, SURVEY.md 8d: every weight once per step per utterance group + ring taps
            + conditioning row + sample) / the kernel's duration measured with HIP events on its own stream.
-           `roofline` prices it against the 8 TB/s HBM peak (schema bound "hbm"), `roofline_lds` against the
-           LDS read peak BASELINE.json asks for (MI355X_MICROARCH.md: 256 CU x 256 B/clk x 2.4 GHz = 157 TB/s).
+           `roofline` prices it against the LDS read peak -- the roofline BASELINE.json and SURVEY.md 8d ask for: the
+           weights are on chip (VGPRs + LDS), nothing streams from HBM (MI355X_MICROARCH.md: 256 CU x 256 B/clk x
+           2.4 GHz = 157 TB/s); `roofline_hbm` prices the same bytes against 8 TB/s for reference; `roofline_latency` is
+           the bound this kernel actually has: the serial chain of L layers, floor = L x (one CU -> CU hop as measured
+           by scripts/ubench_hop2.hip + the on-chain 256x128 mat-vec at the CU's fp32 FMA peak) + the head.
+           `traffic` (HBM/fabric bytes per launch from rocprofv3 PMC passes) cannot be collected from inside this
+           process: it is quoted from profiles/traffic_latest.json together with its source file and commit.
 cpu_baseline : the CPU oracle (oracle/wavenet_oracle.py, a torch-CPU restatement of the reference's op
            sequence incl. its per-step queue shift) timed on rank 0's host cores on a bounded sample of the SAME
            workload (same weights, mel, batch 8; T_cpu steps), reference thread setting (4) and all cores.
@@ -93,6 +102,91 @@ def describe(kw):
     return s
 
 
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one process per GPU), wait for them,
+    return the worst exit code.  Rank 0's stdout is ours, so exactly one JSON line comes out."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies must not leave the others waiting in a rendezvous or a barrier for ever: stop them (by PID)
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for r, pr in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = pr.poll()
+        if any(c not in (None, 0) for c in codes):
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    pr.terminate()
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    try:
+                        codes[r] = pr.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        pr.kill()
+                        codes[r] = pr.wait()
+            break
+        time.sleep(0.05)
+    return max(abs(c) for c in codes)
+
+
+def dry_run(args, world, rank):
+    """The distributed skeleton of main() without the engine: rendezvous (gloo), warm-up, barrier, K timed no-op steps,
+    barrier, MAX-reduce of the elapsed time, ONE JSON line from rank 0 with the same keys."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    B, T = args.batch, args.T
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))                   # ranks finish at different times: the reduce must take the MAX
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        print(json.dumps({"metric": "audio kSamples/sec (24 kHz MoL egs/mol, batch=8 per GPU), whole job", "value": 0.0,
+                          "unit": "kSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)", "dry_run": True,
+                          "config": {"workload": f"{args.workload} dry run, B={B} x T={T}", "parallelism": f"utterance-sharded x{world}"}}),
+              flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+    return 0
+
+
+def latency_floor_us(kw, n_head_parts=1):
+    """Serial-chain floor of the one-layer-per-CU design, from the committed microbenchmarks: per layer one same-XCD CU -> CU
+    hop (profiles/ubench/hop2.txt: 0.444 us, plain store -> sc1 poll, whatever the store flavour) + the on-chain G x G/2 mat-vec at
+    the CU's fp32 FMA peak (128 FMA/clk at 2.4 GHz: 256 x 128 MACs = 0.107 us); head: the skip hop and the first_conv hop + the
+    K x K and O x K mat-vecs at the same FMA peak (+ one more hop when the head is split over several workgroups)."""
+    hop, fma_per_us = 0.444, 128 * 2400.0
+    G, K, O = kw["gate_channels"], kw["skip_out_channels"], kw["out_channels"]
+    layer = hop + (G * (G // 2)) / fma_per_us
+    head = 2 * hop + (K * K / max(n_head_parts, 1) + O * K) / fma_per_us + (hop if n_head_parts > 1 else 0.0)
+    return kw["layers"] * layer + head
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -103,13 +197,20 @@ def main():
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--cpu-steps", type=int, default=1024, help="T of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--workload", default=WORKLOAD)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch / rendezvous / reduce / print plumbing only, on CPU with gloo (no engine, no GPU)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (no throughput_mode, no cpu_baseline): what the rocprofv3 summaries are taken with")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))                  # one process per GPU; rank 0 prints the JSON line
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.dry_run:
+        return dry_run(args, world, rank)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback for the product path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -118,7 +219,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from tests._configs import CONFIGS, build, inputs
     name, B, T = args.workload, args.batch, args.T
@@ -169,13 +269,18 @@ def main():
         kdur = sum(kern_ms) / len(kern_ms) / 1e3                      # seconds per sample-loop launch
         alg_bytes = eng.bytes_per_step(B) * T                          # per launch
         ach = alg_bytes / kdur / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tfile))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = {k: tj.get(k) for k in ("source", "commit", "kernel_version", "collected_with") if tj.get(k) is not None}
+                traffic_src["note"] = "quoted from a separate rocprofv3 --pmc run (counters cannot be read from inside this process)"
             except Exception:
-                traffic = None
+                traffic, traffic_src = None, None
+        us_step = kdur / T * 1e6
+        floor = latency_floor_us(kw, max(kw["skip_out_channels"] // 128, 1))
         line = {
             "metric": "audio kSamples/sec (24 kHz MoL egs/mol, batch=8 per GPU), whole job",
             "value": round(value, 3), "unit": "kSamples/s", "n_gpus": world, "steps": args.steps,
@@ -183,16 +288,22 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded N(0,1) mel, random-init weights of the egs/mol architecture, in-kernel Philox noise)",
             "config": {"workload": f"{name}: {describe(kw)}, B={B} utterances/GPU x T={T} samples", "batch_per_gpu": B, "T": T,
-                       "kernel": "auto" if args.kernel == 0 else ("generic" if args.kernel == 1 else "ring"),
+                       "kernel": {0: "auto", 1: "generic", 2: "ring"}[args.kernel] + f" (ran: {({1: 'generic', 2: 'ring'}).get(eng.last_kernel(), '?')})",
                        "parallelism": f"utterance-sharded x{world}"},
             "kSamples_per_s_per_gpu": round(value / world, 3),
             "samples_per_s_per_utterance": round(per_utt, 1),
             "rtf_24k": round(per_utt / 24000.0, 4), "rtf_22k05": round(per_utt / 22050.0, 4),
-            "roofline": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": traffic,
+            "roofline": {"bound": "lds", "peak_name": "LDS read bandwidth, 256 CU x 256 B/clk x 2.4 GHz (BASELINE.json / SURVEY.md 8d: weights resident on chip)",
+                         "achieved": round(ach, 2), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(ach / LDS_PEAK_GBS, 6),
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": round(kdur * 1e3, 3), "algorithmic_bytes_per_launch": alg_bytes},
-            "roofline_lds": {"bound": "lds", "achieved": round(ach, 2), "peak": LDS_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(ach / LDS_PEAK_GBS, 6)},
+            "roofline_hbm": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(ach / HBM_PEAK_GBS, 5),
+                             "note": "for reference only: the sample loop does not stream from HBM (traffic << algorithmic bytes)"},
+            "roofline_latency": {"bound": "serial chain latency", "floor_us_per_step": round(floor, 3), "achieved_us_per_step": round(us_step, 3),
+                                 "frac": round(floor / us_step, 4),
+                                 "model": "L x (CU->CU hop 0.444 us [profiles/ubench/hop2.txt] + on-chain 256x128 mat-vec at the fp32 FMA peak "
+                                          "0.107 us) + head (2 hops + KxK and OxK mat-vecs)"},
         }
         if world == 1 and args.batch == B_PER_GPU and args.workload == WORKLOAD and not args.no_extras:
             # informative only (not `value`): the same kernel with 32 utterances per GPU -- the rings pipeline four
@@ -210,6 +321,22 @@ def main():
                                            "kSamples_per_s_per_gpu": round(B2 * T2 / (time.perf_counter() - t1) / 1e3, 1)}
             except Exception as e:  # the headline line must not depend on this extra
                 line["throughput_mode"] = {"error": str(e)[:120]}
+        if world == 1 and not args.no_extras:
+            # informative only: the same batch through the reference-compatible public entry point -- WaveNet.incremental_forward with
+            # its default rng = "replay" (the noise tape the reference's CPU generator would have produced for the current seed is
+            # built on the host first), upsampling included
+            try:
+                torch.manual_seed(0)
+                model.incremental_forward(c=c_dev, g=None if gids is None else gids.to(dev), T=T)      # warm: engine + scratch exist
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                model.incremental_forward(c=c_dev, g=None if gids is None else gids.to(dev), T=T)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                line["api_path"] = {"entry": "WaveNet.incremental_forward(c, T) [rng='replay']", "kSamples_per_s_per_gpu": round(B * T / dt / 1e3, 1),
+                                    "ms_per_call": round(dt * 1e3, 2)}
+            except Exception as e:
+                line["api_path"] = {"error": str(e)[:120]}
         if world == 1 and args.cpu_steps > 0 and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(model_cpu, kw, c, args.cpu_steps)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)

@@ -12,8 +12,9 @@
  *     the device the handle was created for; "host" pointers are ordinary process memory.
  *   - all tensors are contiguous float32 unless stated.  Shapes are written reference-style.
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = the null stream)
- *     except where it says "synchronous".  The caller owns all in/out buffers; the handle owns packed
- *     weights, history rings and scratch.
+ *     except where it says "synchronous" -- wnv_generate is the notable case: on the pipelined ring kernel
+ *     it returns after the launch has finished unless WNV_GEN_ASYNC is set (see wnv_generate_args.flags).
+ *     The caller owns all in/out buffers; the handle owns packed weights, history rings and scratch.
  *   - every function returns a wnv_status; wnv_last_error() gives the message for the calling thread.
  *     The Python host maps WNV_ERR_TRAINING_MODE -> RuntimeError('incremental_forward only supports eval
  *     mode') (reference conv.py:19-20), WNV_ERR_SHAPE -> AssertionError (wavenet.py:276), and so on.
@@ -29,7 +30,7 @@
 extern "C" {
 #endif
 
-#define WNV_ABI_VERSION 1
+#define WNV_ABI_VERSION 2
 #define WNV_MAX_UPSAMPLE_STAGES 8
 
 typedef enum wnv_status {
@@ -147,10 +148,28 @@ typedef struct wnv_generate_args {
     float* params_out;         /* optional device (B, out_channels, T): head output before sampling      */
     int32_t* index_out;        /* optional device (B, T): sampled class (categorical + quantize)         */
     int32_t kernel;            /* 0 = auto, 1 = generic single-workgroup kernel, 2 = pipelined ring      */
+    int32_t flags;             /* WNV_GEN_* bits                                                         */
     void* stream;
 } wnv_generate_args;
 
+/* The pipelined ring kernel is a persistent launch whose workgroups wait for each other; every wait is bounded and a
+ * wait that gives up makes the whole launch drain with a status code, which only the host can turn into WNV_ERR_TIMEOUT.
+ * Default: wnv_generate synchronises `stream` after that launch and reports the status itself (and, with kernel == 0,
+ * re-runs the call on the generic kernel -- see below).  With WNV_GEN_ASYNC the call returns right after the launch;
+ * the status is reported by wnv_wait(), or by the next wnv_generate / wnv_reset on the handle.  The generic kernel has no
+ * cross-workgroup waits and is asynchronous either way. */
+#define WNV_GEN_ASYNC 1
+
+/* kernel == 0 ("auto") picks the ring kernel when it covers the configuration (wnv_ring_why_not) AND the device can keep
+ * its grid resident (occupancy query x CU count, one ring per XCD as measured by a placement census at load time);
+ * otherwise, or when a ring launch ends in WNV_ERR_TIMEOUT (CUs masked or taken by another process: the workgroups
+ * were not co-resident), the call is served by the generic kernel, the reason goes to stderr once, and the handle stays
+ * on the generic kernel.  An explicit kernel == 2 reports the error instead. */
 wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* args);
+/* Waits for the handle's last WNV_GEN_ASYNC launch and returns its status (WNV_OK when nothing is pending).  Synchronous. */
+wnv_status wnv_wait(wnv_handle h);
+/* Which kernel served the last wnv_generate of this handle: 1 generic, 2 ring, 0 none yet. */
+int32_t wnv_last_kernel(wnv_handle h);
 
 /* WaveNet.clear_buffer (wavenet.py:345-353): the engine re-zeroes its history at the start of every
  * wnv_generate (as incremental_forward does at :241), so this only releases scratch. */

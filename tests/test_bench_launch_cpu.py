@@ -1,0 +1,50 @@
+"""CPU: the launch path of bench.py.  `python bench.py --gpus N` must start its own N ranks when no launcher set WORLD_SIZE
+(that is how the driver's N = 1 command looks with a larger N), must keep working under torch.distributed.run, and must print
+exactly ONE JSON line (from rank 0) carrying n_gpus = N.  `--dry-run` swaps the engine for a no-op and RCCL for gloo; the
+rendezvous, the barriers, the MAX-reduce of the elapsed time and the printing are the code the GPU run uses."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def run(cmd, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")):
+    env = {k: v for k, v in os.environ.items() if k not in drop}
+    env.update(env_extra or {})
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=240)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, lines
+
+
+@pytest.mark.parametrize("n", [1, 2, 3])
+def test_self_launch_prints_one_line_with_n_gpus(n):
+    r, lines = run([sys.executable, BENCH, "--gpus", str(n), "--steps", "3", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == n and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["dry_run"] is True
+    # ranks sleep 2 ms x (rank + 1) per step: the reported time is the slowest rank's (MAX over ranks), not rank 0's
+    assert j["ms_per_step"] >= 2.0 * n * 0.9
+
+
+def test_under_torch_distributed_run():
+    r, lines = run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29613", BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_world_size_mismatch_is_an_error():
+    r, lines = run([sys.executable, BENCH, "--gpus", "2", "--dry-run"], env_extra={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
+    assert r.returncode != 0 and not lines
+
+
+def test_a_dying_rank_takes_the_job_down():
+    """Rank 1 refuses to start (bad LOCAL_RANK handling is simulated by an impossible --steps): nobody is left waiting."""
+    r, lines = run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "not-a-number"])
+    assert r.returncode != 0 and not lines

@@ -13,8 +13,9 @@ from typing import Optional
 __all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "ForwardArgs", "MelConfig", "LogmelArgs", "LIB_PATH",
            "WNV_ABI_VERSION", "DIST", "UPSAMPLE"]
 
-WNV_ABI_VERSION = 1
+WNV_ABI_VERSION = 2
 WNV_MAX_UPSAMPLE_STAGES = 8
+WNV_GEN_ASYNC = 1
 # WNV_LIB selects another build of the same sources (debug/trace builds: python -m wavenet_vocoder_amd.build --out ... --flags ...)
 LIB_PATH = os.environ.get("WNV_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwnv_hip.so")
 
@@ -58,7 +59,8 @@ class GenerateArgs(C.Structure):
         ("B", C.c_int32), ("T", C.c_int64), ("c_up", C.c_void_p), ("g", C.c_void_p), ("g_ids", C.c_void_p),
         ("initial", C.c_void_p), ("teacher", C.c_void_p), ("Tt", C.c_int64), ("noise", C.c_void_p),
         ("seed", C.c_uint64), ("softmax", C.c_int32), ("quantize", C.c_int32), ("out", C.c_void_p),
-        ("params_out", C.c_void_p), ("index_out", C.c_void_p), ("kernel", C.c_int32), ("stream", C.c_void_p),
+        ("params_out", C.c_void_p), ("index_out", C.c_void_p), ("kernel", C.c_int32), ("flags", C.c_int32),
+        ("stream", C.c_void_p),
     ]
 
 
@@ -111,6 +113,8 @@ _PROTOS = {
     "wnv_upsample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]),
     "wnv_generate": (C.c_int, [C.c_void_p, C.POINTER(GenerateArgs)]),
     "wnv_reset": (C.c_int, [C.c_void_p]),
+    "wnv_wait": (C.c_int, [C.c_void_p]),
+    "wnv_last_kernel": (C.c_int32, [C.c_void_p]),
     "wnv_qconv_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "wnv_qconv_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "wnv_qconv_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -59,6 +59,9 @@ class Conv1d(WeightNormCompat, nn.Conv1d):
         y = self._engine().step(input[:, -1, :])
         return y.view(input.size(0), 1, -1)
 
+    def invalidate_engine(self):
+        self._qconv, self._qconv_key = None, None
+
     def clear_buffer(self):
         if getattr(self, "_qconv", None) is not None:
             self._qconv.reset()

@@ -34,6 +34,7 @@ struct WnvModelDev {
     // LDS carve (floats)
     int lds_xin, lds_u, lds_o, lds_vin, lds_taps, lds_nz, lds_part_stride;
     int taps_in_lds;
+    int n_embed;                             // rows of embed_speakers.weight (0 = none): speaker ids are clamped into it
 };
 
 struct WnvGenArgs {
@@ -48,6 +49,7 @@ struct WnvGenArgs {
     float* ring;             // (B, ring_floats) zeroed before launch
     unsigned long long seed;
     int softmax, quantize, nz;
+    int async;               // ring kernel: do not synchronise after the launch (WNV_GEN_ASYNC)
     float* out;              // (B, C, T)
     float* params_out;       // (B, O, T) or null
     int* index_out;          // (B, T) or null

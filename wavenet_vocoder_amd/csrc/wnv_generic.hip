@@ -232,7 +232,12 @@ __global__ void wnv_zbias_kernel(const WnvModelDev m, const WnvLayerDev* __restr
     const WnvLayerDev Ld = layers[l];
     const bool has_g = (g != nullptr || ids != nullptr) && Ld.w_g >= 0;
     const float* gv = nullptr;
-    if (has_g) gv = g ? g + (size_t)b * m.gin : embed + (size_t)ids[b] * m.gin;       // wavenet.py:264-268
+    if (has_g) {                                                                      // wavenet.py:264-268
+        // an id outside the table is the host's IndexError (nn.Embedding); here it is clamped so that no launch can read past it
+        long long id = ids ? ids[b] : 0;
+        id = id < 0 ? 0 : (id >= m.n_embed ? (long long)m.n_embed - 1 : id);
+        gv = g ? g + (size_t)b * m.gin : embed + (size_t)id * m.gin;
+    }
     for (int n = threadIdx.x; n < m.Gp; n += blockDim.x) {
         float acc = 0.f;
         if (has_g)

@@ -39,6 +39,8 @@ struct wnv_engine {
     int64_t core_macs = 0;
     Scratch ring, zbias, upA, upB, fwd;
     WnvRingState* ring_state = nullptr;   // pipelined kernel (wnv_ring.hip), built lazily
+    bool ring_disabled = false;           // auto mode: a ring launch timed out on this device (workgroups not co-resident)
+    int last_kernel = 0;                  // 1 generic, 2 ring: what served the last wnv_generate
 };
 
 static std::vector<int> dilations_of(const wnv_config& c) {
@@ -187,13 +189,25 @@ extern "C" wnv_status wnv_destroy(wnv_handle h) {
     return WNV_OK;
 }
 
+extern "C" wnv_status wnv_wait(wnv_handle h) {
+    if (!h) return fail(WNV_ERR_INVALID_ARG, "handle is NULL");
+    if (h->device < 0 || !h->ring_state) return WNV_OK;
+    DeviceGuard g(h->device);
+    std::string err;
+    const wnv_status st = wnv_ring_wait(h->ring_state, err);
+    return st == WNV_OK ? WNV_OK : fail(st, "%s", err.c_str());
+}
+
+extern "C" int32_t wnv_last_kernel(wnv_handle h) { return h ? h->last_kernel : 0; }
+
 extern "C" wnv_status wnv_reset(wnv_handle h) {
     if (!h) return fail(WNV_ERR_INVALID_ARG, "handle is NULL");
     if (h->device < 0) return WNV_OK;
     DeviceGuard g(h->device);
+    const wnv_status deferred = wnv_wait(h);                // a pending WNV_GEN_ASYNC launch reports here
     HIP_TRY(hipDeviceSynchronize());
     h->ring.release(); h->zbias.release(); h->upA.release(); h->upB.release(); h->fwd.release();
-    return WNV_OK;
+    return deferred;
 }
 
 static wnv_status pack(wnv_engine* h) {
@@ -270,6 +284,7 @@ static wnv_status pack(wnv_engine* h) {
     weights += (int64_t)K * K + K + (int64_t)O * K + O;
     macs += (int64_t)K * K + (int64_t)O * K;
     h->embed_off = -1;
+    m.n_embed = (gin > 0 && c.use_speaker_embedding) ? c.n_speakers : 0;
     if (gin > 0 && c.use_speaker_embedding) {
         const HostTensor& e = T("embed_speakers.weight");
         h->embed_off = b.alloc(e.data.size());
@@ -462,8 +477,10 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     HIP_TRY(h->zbias.ensure((size_t)Bz * m.L * m.Gp * sizeof(float)));
     HIP_TRY(wnv_launch_zbias(m, h->d_layers, h->d_W, has_g ? a->g : nullptr, (has_g && !a->g) ? (const long long*)a->g_ids : nullptr,
                              h->embed_off >= 0 ? h->d_W + h->embed_off : nullptr, Bz, (float*)h->zbias.p, s));
-    if (!c.scalar_input && a->quantize)
-        HIP_TRY(hipMemsetAsync(a->out, 0, (size_t)a->B * m.O * (size_t)a->T * sizeof(float), s));
+    auto zero_onehot_out = [&]() -> hipError_t {                     // the kernels write only the sampled class (wavenet.py:334)
+        if (!c.scalar_input && a->quantize) return hipMemsetAsync(a->out, 0, (size_t)a->B * m.O * (size_t)a->T * sizeof(float), s);
+        return hipSuccess;
+    };
 
     WnvGenArgs ga{};
     ga.B = a->B; ga.T = a->T; ga.Tt = a->teacher ? a->Tt : 0;
@@ -472,22 +489,43 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     ga.seed = a->seed; ga.softmax = a->softmax; ga.quantize = c.scalar_input ? 1 : a->quantize;
     ga.nz = wnv_noise_width(&c);
     ga.out = a->out; ga.params_out = a->params_out; ga.index_out = a->index_out;
+    // asynchronous ring launches only when the caller chose the ring explicitly: auto mode must see the status to fall back
+    ga.async = (a->flags & WNV_GEN_ASYNC) && a->kernel == 2;
 
+    if (h->ring_state) {                                             // a pending asynchronous launch reports first
+        std::string err;
+        const wnv_status pst = wnv_ring_wait(h->ring_state, err);
+        if (pst != WNV_OK) return fail(pst, "deferred from the previous asynchronous call: %s", err.c_str());
+    }
     int kernel = a->kernel;
-    if (kernel == 0) kernel = (wnv_ring_supported(c, a->B) && wnv_ring_default()) ? 2 : 1;
+    if (kernel == 0) kernel = (!h->ring_disabled && wnv_ring_supported(c, a->B) && wnv_ring_default()) ? 2 : 1;
     if (kernel == 2) {
         if (!wnv_ring_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the pipelined ring kernel does not cover this configuration: %s", wnv_ring_why_not(c, a->B));
+        HIP_TRY(zero_onehot_out());
         std::string err;
         wnv_status st = wnv_ring_generate(&h->ring_state, h->device, c, h->store, ga, s, err);
-        if (st == WNV_OK) return WNV_OK;
-        // auto mode on a device that cannot host the persistent pipeline (fewer CUs than one ring + its tap workgroups per
-        // XCD, e.g. a partitioned GPU): the generic kernel still covers the call; an explicit kernel = 2 reports the reason
-        if (!(a->kernel == 0 && st == WNV_ERR_UNSUPPORTED)) return fail(st, "%s", err.c_str());
+        if (st == WNV_OK) { h->last_kernel = 2; return WNV_OK; }
+        // auto mode: a device that cannot host the persistent pipeline (fewer CUs than one ring + its tap workgroups per XCD, a
+        // partitioned GPU: WNV_ERR_UNSUPPORTED from the occupancy / placement checks) or did not keep it co-resident (CUs masked
+        // or busy with another process: WNV_ERR_TIMEOUT after the bounded spins) is served by the generic kernel; the handle
+        // stays on it.  An explicit kernel = 2 reports the reason instead.
+        const bool recoverable = st == WNV_ERR_UNSUPPORTED || st == WNV_ERR_TIMEOUT;
+        if (!(a->kernel == 0 && recoverable)) return fail(st, "%s", err.c_str());
+        if (st == WNV_ERR_TIMEOUT) {
+            h->ring_disabled = true;
+            fprintf(stderr, "[wnv] device %d: the pipelined ring kernel timed out (%s); its workgroups were not co-resident -- "
+                            "this handle now uses the generic kernel\n", h->device, err.c_str());
+        } else if (!h->ring_disabled) {
+            h->ring_disabled = true;
+            fprintf(stderr, "[wnv] device %d: the pipelined ring kernel cannot run here (%s); using the generic kernel\n", h->device, err.c_str());
+        }
     }
+    HIP_TRY(zero_onehot_out());
     const size_t ring_bytes = std::max<size_t>((size_t)a->B * m.ring_floats * sizeof(float), 16);
     HIP_TRY(h->ring.ensure(ring_bytes));
     HIP_TRY(hipMemsetAsync(h->ring.p, 0, ring_bytes, s));                       // history before t = 0 is zero (conv.py:34-36)
     ga.ring = (float*)h->ring.p;
     HIP_TRY(wnv_launch_generate_generic(m, h->d_layers, h->d_W, ga, s));
+    h->last_kernel = 1;
     return WNV_OK;
 }

@@ -31,16 +31,7 @@ static inline wnv_status fail(wnv_status st, const char* fmt, ...) {
         if (e__ != hipSuccess) return fail(WNV_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
     } while (0)
 
-struct DeviceGuard {
-    int prev = -1;
-    bool ok = true;
-    explicit DeviceGuard(int dev) {
-        if (dev < 0) return;                       // host-only handle (wnv_create with device = -1): nothing to guard
-        if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
-        if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
-    }
-    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
-};
+#include "wnv_devguard.h"
 
 static inline int pad4(int n) { return (n + 3) & ~3; }
 

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "../../include/wnv.h"
+#include "wnv_devguard.h"
 
 namespace {
 
@@ -233,7 +234,8 @@ extern "C" wnv_status wnv_mel_create(const wnv_mel_config* c, int32_t device, wn
     *out = h;
     h->d.N = N; h->d.hop = c->hop_size; h->d.nbins = nb; h->d.n_mels = M; h->d.pad_mode = c->pad_mode;
     if (device < 0) return WNV_OK;                                // host-only handle: wnv_mel_basis / introspection, no launches
-    MEL_HIP(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok) { wnv_g_err = "wnv_mel_create: cannot select the device"; return WNV_ERR_HIP; }
     MEL_HIP(hipMalloc(&h->blob, total));
     MEL_HIP(hipMemcpy(h->blob, host.data(), total, hipMemcpyHostToDevice));
     MEL_HIP(hipMalloc((void**)&h->d_mean, (size_t)2 * M * sizeof(float)));
@@ -265,7 +267,8 @@ extern "C" wnv_status wnv_mel_set_scaler(wnv_mel_handle h, const float* mean, co
         v[i] = mean[i];
         v[M + i] = scale[i];
     }
-    MEL_HIP(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) { wnv_g_err = "wnv_mel: cannot select the device"; return WNV_ERR_HIP; }
     MEL_HIP(hipMemcpy(h->d_mean, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
     h->have_scaler = true;
     return WNV_OK;
@@ -293,7 +296,8 @@ extern "C" wnv_status wnv_logmel(wnv_mel_handle h, const wnv_logmel_args* a) {
     const long long pairs = (frames + 1) / 2;
     if ((long long)a->B * pairs > 0x7fffffffll) { wnv_g_err = "wnv_logmel: too many frames for one launch"; return WNV_ERR_UNSUPPORTED; }
     const size_t lds = (size_t)3 * N * sizeof(float2) + (size_t)2 * h->d.nbins * sizeof(float);
-    MEL_HIP(hipSetDevice(h->device));
+    DeviceGuard guard(h->device);
+    if (!guard.ok) { wnv_g_err = "wnv_mel: cannot select the device"; return WNV_ERR_HIP; }
     MEL_HIP(hipFuncSetAttribute((const void*)wnv_logmel_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(wnv_logmel_kernel, dim3((unsigned)(a->B * pairs)), dim3(MT), lds, (hipStream_t)a->stream, h->d, a->wav, (long long)a->n,
                        stride, frames, a->out, a->transpose, a->normalize);

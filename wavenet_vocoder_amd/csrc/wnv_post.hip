@@ -21,6 +21,7 @@
 #include <string>
 
 #include "../../include/wnv.h"
+#include "wnv_devguard.h"
 
 namespace {
 constexpr int PT = 256;
@@ -98,8 +99,10 @@ extern "C" wnv_status wnv_postprocess(int32_t device, const wnv_post_args* a) {
     if (!a || !a->y || !a->wav || a->B <= 0 || a->T <= 0 || a->C <= 0) { wnv_g_err = "wnv_postprocess: bad arguments"; return WNV_ERR_INVALID_ARG; }
     if (a->input_type < 0 || a->input_type > 2 || (a->input_type != 0 && a->mu <= 0)) { wnv_g_err = "wnv_postprocess: bad input_type / mu"; return WNV_ERR_INVALID_ARG; }
     if (a->input_type != 2 && a->C != 1) { wnv_g_err = "wnv_postprocess: scalar input types take C == 1"; return WNV_ERR_INVALID_ARG; }
-    hipError_t e = hipSetDevice(device);
-    if (e != hipSuccess) { wnv_g_err = std::string("hipSetDevice failed: ") + hipGetErrorString(e); return WNV_ERR_HIP; }
+    if (device < 0) { wnv_g_err = "wnv_postprocess: device must be >= 0"; return WNV_ERR_INVALID_ARG; }
+    DeviceGuard guard(device);                         // the caller's current device is restored on return
+    if (!guard.ok) { wnv_g_err = "wnv_postprocess: cannot select the device"; return WNV_ERR_HIP; }
+    hipError_t e;
     hipLaunchKernelGGL(wnv_post_kernel, dim3(a->B), dim3(PT), 0, (hipStream_t)a->stream, a->y, a->C, (long long)a->T, a->input_type,
                        (float)a->mu, a->preemphasis, a->gain_scale, a->clip, a->wav, (short*)a->pcm);
     e = hipGetLastError();

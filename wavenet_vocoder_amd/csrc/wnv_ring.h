@@ -18,4 +18,6 @@ bool wnv_ring_default();
 // Builds (once) the ring-specific weight images from the fused host tensors and runs the whole loop.
 wnv_status wnv_ring_generate(WnvRingState** st, int device, const wnv_config& c, const TensorStore& store,
                              const WnvGenArgs& ga, hipStream_t s, std::string& err);
+// Waits for a pending asynchronous launch (WnvGenArgs::async) and returns its status; WNV_OK when nothing is pending.
+wnv_status wnv_ring_wait(WnvRingState* st, std::string& err);
 void wnv_ring_destroy(WnvRingState* st);

@@ -1177,6 +1177,17 @@ __global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_
 // K = 512: needs the whole register file; polls one load at a time in compiler-allocated registers
 __global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4>(p); }
 
+// Placement census (once per handle): every workgroup of a one-block-per-CU grid reports the XCC it runs on.  The host derives
+// the number of XCDs and checks the block -> XCD mapping the ring layout relies on (block b on XCD b % n_xcd, observed; HIP
+// promises nothing) instead of assuming it.
+__global__ void __launch_bounds__(64) wnv_ring_census_kernel(unsigned int* xcc) {
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        xcc[blockIdx.x] = (x & 0xfu) + 1u;
+    }
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1195,6 +1206,13 @@ struct WnvRingState {
     size_t state_cap = 0;
     unsigned tag_next = 0;         // tags handed out so far (mailboxes are only re-zeroed when this would wrap)
     size_t mail_bytes = 0;         // size of the mailbox region the tags in flight refer to
+    // placement census of this device (see wnv_ring_census_kernel)
+    int ncu = 0, n_xcd = 0;
+    bool map_ok = false;           // block b ran on the same XCD as block b % n_xcd for every b of the census grid
+    // asynchronous launches (WnvGenArgs::async): the status word lands in pinned host memory behind the kernel
+    unsigned int* h_status = nullptr;
+    bool pending = false;
+    hipStream_t pending_stream = nullptr;
 };
 
 static const char* why_not(const wnv_config& c, int B) {
@@ -1224,6 +1242,8 @@ void wnv_ring_destroy(WnvRingState* st) {
     if (st->d_dil) (void)hipFree(st->d_dil);
     if (st->d_histoff) (void)hipFree(st->d_histoff);
     if (st->d_state) (void)hipFree(st->d_state);
+    if (st->pending) (void)hipStreamSynchronize(st->pending_stream);
+    if (st->h_status) (void)hipHostFree(st->h_status);
     delete st;
 }
 
@@ -1378,6 +1398,42 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     RING_HIP(hipMemcpy(st->d_dil, dil.data(), L * sizeof(int), hipMemcpyHostToDevice));
     RING_HIP(hipMalloc((void**)&st->d_histoff, L * sizeof(int)));
     RING_HIP(hipMemcpy(st->d_histoff, hoff.data(), L * sizeof(int), hipMemcpyHostToDevice));
+    RING_HIP(hipHostMalloc((void**)&st->h_status, 64, hipHostMallocDefault));
+    *st->h_status = 0;
+    // placement census: how many XCDs, and does block b land on XCD b % n_xcd?
+    RING_HIP(hipDeviceGetAttribute(&st->ncu, hipDeviceAttributeMultiprocessorCount, device));
+    {
+        const int n = std::max(st->ncu, 1);
+        unsigned int* d_x = nullptr;
+        RING_HIP(hipMalloc((void**)&d_x, n * sizeof(unsigned int)));
+        RING_HIP(hipMemset(d_x, 0, n * sizeof(unsigned int)));
+        hipLaunchKernelGGL(wnv_ring_census_kernel, dim3(n), dim3(64), 0, 0, d_x);
+        RING_HIP(hipGetLastError());
+        std::vector<unsigned int> x(n);
+        RING_HIP(hipMemcpy(x.data(), d_x, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
+        (void)hipFree(d_x);
+        unsigned seen = 0;
+        for (int b = 0; b < n; ++b) seen |= 1u << (x[b] & 31u);
+        st->n_xcd = __builtin_popcount(seen & ~1u);
+        st->map_ok = st->n_xcd >= 1;
+        for (int b = 0; b < n && st->map_ok; ++b) st->map_ok = x[b] != 0u && x[b] == x[b % st->n_xcd];
+        if (const char* e = getenv("WNV_RING_CENSUS"); e && e[0] == '1')
+            fprintf(stderr, "[wnv] device %d: %d CUs, %d XCDs, block -> XCD (b %% %d) mapping %s\n", device, st->ncu, st->n_xcd, st->n_xcd,
+                    st->map_ok ? "verified" : "NOT as assumed");
+    }
+    return WNV_OK;
+}
+
+wnv_status wnv_ring_wait(WnvRingState* st, std::string& err) {
+    if (!st || !st->pending) return WNV_OK;
+    st->pending = false;
+    RING_HIP(hipStreamSynchronize(st->pending_stream));
+    if (*st->h_status != 0) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "ring kernel gave up waiting (code 0x%x: 0x1ss = activation into stage ss, 0x2ss = skip into stage ss, 0x300 = head)", *st->h_status);
+        err = buf;
+        return WNV_ERR_TIMEOUT;
+    }
     return WNV_OK;
 }
 
@@ -1389,8 +1445,17 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     }
     WnvRingState* st = *pst;
     const int B = ga.B;
-    int ncu = 0;
-    RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, st->device));
+    { std::string perr; wnv_status pst = wnv_ring_wait(st, perr); if (pst != WNV_OK) { err = perr; return pst; } }
+    const int ncu = st->ncu, NX = st->n_xcd;
+    // The layout below (ring r = blocks r, r + NX, ... = one XCD; a per-XCD CU budget) needs the observed block -> XCD mapping and
+    // the usual 8 XCDs; anything else (a partitioned GPU, a different dispatcher) is not a place for the persistent pipeline.
+    if (!st->map_ok || NX != 8) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "ring kernel: placement census found %d XCDs over %d CUs with the block -> XCD mapping %s (needs 8 XCDs, b %% 8)",
+                 NX, ncu, st->map_ok ? "as assumed" : "NOT as assumed");
+        err = buf;
+        return WNV_ERR_UNSUPPORTED;
+    }
     // one workgroup per CU, one ring per utterance slot; at most 8 rings (one per XCD) and never more than fit
     // Workgroups that must be co-resident: n_rings x (S + 1) ring workgroups + tap_parts x L tap workgroups, one per CU.
     // Block b runs on XCD b % 8 (observed; 32 CUs each), ring r occupies blocks r, r + 8, ... = XCD r, so the budget is per
@@ -1492,6 +1557,21 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.tap_parts = tap_parts;
     const int grid = p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);
     if (p.ring_blocks > ncu) { err = "ring kernel: too many layers for one ring per XCD"; return WNV_ERR_UNSUPPORTED; }
+    // every LIVE workgroup must be resident at once (they wait for each other): ask the runtime how many fit a CU with this
+    // register / LDS footprint instead of assuming one, and compare with what stays alive (the workgroups of unused ring slots
+    // exit at once)
+    {
+        int per_cu = 0;
+        RING_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, RT, lds));
+        const int live = n_rings * P + tap_parts * st->L;
+        if (per_cu < 1 || live > ncu * per_cu) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "ring kernel: %d workgroups must be co-resident but the device holds %d (%d CUs x %d per CU)", live,
+                     ncu * std::max(per_cu, 0), ncu, per_cu);
+            err = buf;
+            return WNV_ERR_UNSUPPORTED;
+        }
+    }
     // optional timeline (WNV_RING_TRACE=<file>): wall-clock stamps of utterance 0 for 8 steps in mid-run
     const char* trace_path = getenv("WNV_RING_TRACE");
     unsigned long long* d_trace = nullptr;
@@ -1507,10 +1587,16 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     else if (NK == 2) hipLaunchKernelGGL(wnv_ring_kernel<2>, dim3(grid), dim3(RT), lds, stream, p);
     else hipLaunchKernelGGL(wnv_ring_kernel_k512, dim3(grid), dim3(RT), lds, stream, p);
     RING_HIP(hipGetLastError());
-    // the ring path is synchronous: a bounded spin that gave up must be reported to the caller
-    unsigned int status = 0;
-    RING_HIP(hipMemcpyAsync(&status, p.status, sizeof status, hipMemcpyDeviceToHost, stream));
+    // a bounded spin that gave up must reach the caller: the status word follows the kernel into pinned host memory; the call
+    // waits for it here unless the caller asked for an asynchronous launch (then wnv_ring_wait reports it)
+    RING_HIP(hipMemcpyAsync(st->h_status, p.status, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    if (ga.async && !d_trace) {
+        st->pending = true;
+        st->pending_stream = stream;
+        return WNV_OK;
+    }
     RING_HIP(hipStreamSynchronize(stream));
+    const unsigned int status = *st->h_status;
     if (d_trace) {
         std::vector<unsigned long long> tr(trace_words);
         RING_HIP(hipMemcpy(tr.data(), d_trace, trace_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));

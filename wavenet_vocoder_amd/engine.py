@@ -154,8 +154,10 @@ class Engine:
 
     def generate(self, *, B: int, T: int, c_up=None, g=None, g_ids=None, initial=None, teacher=None,
                  noise=None, seed: int = 0, softmax: bool = True, quantize: bool = True,
-                 want_params: bool = False, want_index: bool = False, kernel: int = 0):
-        """Runs the whole autoregressive loop.  Returns (out (B,C,T), params (B,O,T)|None, index (B,T)|None)."""
+                 want_params: bool = False, want_index: bool = False, kernel: int = 0, asynchronous: bool = False):
+        """Runs the whole autoregressive loop.  Returns (out (B,C,T), params (B,O,T)|None, index (B,T)|None).
+        ``asynchronous`` (ring kernel chosen explicitly, kernel=2): return right after the launch; ``wait()`` or the next
+        call reports a bounded-spin timeout (WNV_GEN_ASYNC in include/wnv.h)."""
         dev = self.device
         cfg = self.cfg
         C_out = 1 if cfg.scalar_input else cfg.out_channels
@@ -172,9 +174,18 @@ class Engine:
         a.softmax, a.quantize = int(bool(softmax)), int(bool(quantize))
         a.out, a.params_out, a.index_out = out.data_ptr(), _ptr(params), _ptr(index)
         a.kernel = int(kernel)
+        a.flags = _lib.WNV_GEN_ASYNC if asynchronous else 0
         a.stream = _stream(dev)
         check(_lib.lib().wnv_generate(self._h, C.byref(a)))
         return out, params, index
+
+    def wait(self) -> None:
+        """Status of the last asynchronous launch (raises TimeoutError if a bounded in-kernel wait gave up)."""
+        check(_lib.lib().wnv_wait(self._h))
+
+    def last_kernel(self) -> int:
+        """1 = generic kernel, 2 = pipelined ring kernel served the last ``generate`` (0: none yet)."""
+        return int(_lib.lib().wnv_last_kernel(self._h))
 
 
 class QueueConv:

@@ -109,6 +109,10 @@ class ResidualConv1dGLU(nn.Module):
                                      None if g is None else g[:, -1, :])
         return xo.view(B, 1, -1), so.view(B, 1, -1)
 
+    def invalidate_engine(self):
+        """Drop the packed weights of the layer-level engine (see WaveNet.invalidate_engine)."""
+        self._glu, self._glu_key = None, None
+
     def clear_buffer(self):
         if self._glu is not None:
             self._glu.reset()

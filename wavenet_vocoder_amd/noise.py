@@ -40,25 +40,38 @@ def noise_width(scalar_input: bool, output_distribution: str, out_channels: int)
 
 
 def make_noise_tape(T: int, B: int, *, scalar_input: bool, output_distribution: str,
-                    out_channels: int, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+                    out_channels: int, generator: Optional[torch.Generator] = None,
+                    per_step: bool = False) -> torch.Tensor:
     """Replay the reference's per-step CPU draws; returns a CPU float32 tensor (T, B, NZ).
 
-    Per-step calls (not one bulk call) because torch's CPU ``normal_`` switches algorithm with the
-    tensor size, so only same-sized calls reproduce the same stream."""
+    torch's CPU ``uniform_`` and ``exponential_`` consume the Mersenne-Twister stream element by element, so ONE bulk
+    draw of the whole tape yields exactly the numbers the reference's per-step calls see (T = 65 536, B = 8, MoL:
+    0.1 s instead of 1.3 s; tests/test_host_cpu.py pins bulk == per-step for every distribution and batch size).
+    ``normal_`` does not: it switches to a 16-wide vectorised Box-Muller for tensors of >= 16 elements, so only calls
+    of the same size reproduce the same stream -- Gaussian tapes are drawn in bulk when B is a multiple of 16 (every
+    per-step call is vectorised then, and so is the bulk one) and step by step otherwise.  ``per_step=True`` forces the
+    literal replay (what the tests compare the bulk path with)."""
     nz = noise_width(scalar_input, output_distribution, out_channels)
-    tape = torch.empty(T, B, nz, dtype=torch.float32)
     kw = {} if generator is None else {"generator": generator}
-    if scalar_input:
-        mix = nz - 1
-        normal = output_distribution == "Normal"
-        for t in range(T):
-            if mix > 0:
-                tape[t, :, :mix] = torch.empty(B, 1, mix).uniform_(_EPS, 1.0 - _EPS, **kw)[:, 0, :]
-            if normal:
-                tape[t, :, mix] = torch.empty(B, 1).normal_(0.0, 1.0, **kw)[:, 0]
-            else:
-                tape[t, :, mix] = torch.empty(B, 1).uniform_(_EPS, 1.0 - _EPS, **kw)[:, 0]
-    else:
-        for t in range(T):
-            tape[t] = torch.empty(B, out_channels).exponential_(1.0, **kw)
+    if not scalar_input:
+        if per_step:
+            return torch.stack([torch.empty(B, out_channels).exponential_(1.0, **kw) for _ in range(T)]) if T else torch.empty(0, B, nz)
+        return torch.empty(T, B, out_channels).exponential_(1.0, **kw)
+    mix = nz - 1
+    normal = output_distribution == "Normal"
+    tape = torch.empty(T, B, nz, dtype=torch.float32)
+    if not per_step and not normal:
+        raw = torch.empty(T, B * mix + B).uniform_(_EPS, 1.0 - _EPS, **kw)       # per step: u1 (B, 1, mix) then u2 (B, 1)
+        tape[:, :, :mix] = raw[:, :B * mix].view(T, B, mix)
+        tape[:, :, mix] = raw[:, B * mix:]
+        return tape
+    if not per_step and mix == 0 and B % 16 == 0:
+        return torch.empty(T, B, 1).normal_(0.0, 1.0, **kw)
+    for t in range(T):
+        if mix > 0:
+            tape[t, :, :mix] = torch.empty(B, 1, mix).uniform_(_EPS, 1.0 - _EPS, **kw)[:, 0, :]
+        if normal:
+            tape[t, :, mix] = torch.empty(B, 1).normal_(0.0, 1.0, **kw)[:, 0]
+        else:
+            tape[t, :, mix] = torch.empty(B, 1).uniform_(_EPS, 1.0 - _EPS, **kw)[:, 0]
     return tape

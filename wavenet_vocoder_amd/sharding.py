@@ -50,16 +50,22 @@ def pad_group(mels: Sequence[torch.Tensor], cin_pad: int) -> torch.Tensor:
 
 def broadcast_weights(model: torch.nn.Module, src: int = 0, group=None) -> None:
     """One-time replication of the weights from ``src`` (one flat buffer, one collective: the whole egs/mol
-    model is 14.8 MB, far below anything worth bucketing)."""
+    model is 14.8 MB, far below anything worth bucketing).  The copy goes through ``Parameter.copy_`` under
+    ``no_grad`` so that the tensors' version counters move (the packed-weight caches of the engine key on them), and
+    any engine built before the broadcast is dropped explicitly as well."""
     import torch.distributed as dist
-    params = [p.data for p in model.parameters()]
-    flat = torch.cat([p.reshape(-1) for p in params])
-    dist.broadcast(flat, src=src, group=group)
-    off = 0
-    for p in params:
-        n = p.numel()
-        p.copy_(flat[off:off + n].view_as(p))
-        off += n
+    params = list(model.parameters())
+    with torch.no_grad():
+        flat = torch.cat([p.reshape(-1) for p in params])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for p in params:
+            n = p.numel()
+            p.copy_(flat[off:off + n].view_as(p))
+            off += n
+    for m in model.modules():
+        if hasattr(m, "invalidate_engine"):
+            m.invalidate_engine()
 
 
 def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torch.Tensor, List[int]], torch.Tensor],

@@ -138,20 +138,11 @@ class WaveNet(nn.Module):
         (CPU modules -- the online == offline parity oracle of the tests --, training, odd channel counts) evaluates the
         same graph with torch ops."""
         B, _, T = x.size()
-        if (x.is_cuda and not self.training and not torch.is_grad_enabled()
-                and self.residual_channels == 128 and self.gate_channels == 256
-                and self.skip_out_channels % 128 == 0 and self.out_channels <= 256):
-            eng = self._get_engine()
-            c_up = None
-            if c is not None:
-                c_up = eng.upsample(c, T_expected=T) if self.upsample_net is not None else c.transpose(1, 2).contiguous()
-            g_ids = g_feat = None
-            if g is not None:
-                if self.embed_speakers is not None:
-                    g_ids = g.view(B).long().contiguous()
-                else:
-                    g_feat = g.reshape(B, -1).float().contiguous()
-            return eng.forward(x, c_up=c_up, g=g_feat, g_ids=g_ids, softmax=softmax)
+        if self._mfma_forward_covers(x, c, g):
+            try:
+                return self._forward_engine(x, c, g, softmax)
+            except NotImplementedError:      # WNV_ERR_UNSUPPORTED: a shape wnv_forward_why_not refuses -> torch ops below
+                pass
         if g is not None and self.embed_speakers is not None:
             g = self.embed_speakers(g.view(B, -1)).transpose(1, 2)
             assert g.dim() == 3
@@ -168,6 +159,60 @@ class WaveNet(nn.Module):
         for f in self.last_conv_layers:
             x = f(x)
         return F.softmax(x, dim=1) if softmax else x
+
+    def _mfma_forward_covers(self, x, c, g) -> bool:
+        """Host-side mirror of wnv_forward_why_not (csrc/wnv_forward.hip) plus the argument combinations the engine entry
+        point refuses (a conditioned model called without c / g evaluates like the reference does: on the torch path)."""
+        if not x.is_cuda or self.training or torch.is_grad_enabled():
+            return False
+        if self.residual_channels != 128 or self.gate_channels != 256 or self.skip_out_channels % 128 != 0:
+            return False
+        if self.out_channels > 256:
+            return False
+        cin = max(self.cin_channels, 0)
+        if cin % 4 != 0 or (cin > 0) != (c is not None) or (self.gin_channels > 0) != (g is not None):
+            return False
+        return x.size(1) == (1 if self.scalar_input else self.out_channels)
+
+    def _forward_engine(self, x, c, g, softmax):
+        B, _, T = x.size()
+        eng = self._get_engine()
+        c_up = None
+        if c is not None:
+            c = c.detach().to(device=x.device, dtype=torch.float32)
+            if self.upsample_net is not None:
+                c_up = eng.upsample(c.contiguous(), T_expected=T)                 # asserts length == T (wavenet.py:184)
+            else:
+                assert c.size(-1) == T, (c.size(-1), T)
+                c_up = c.transpose(1, 2).contiguous()
+            assert c_up.shape == (B, T, self.cin_channels), (tuple(c_up.shape), (B, T, self.cin_channels))
+        g_ids = g_feat = None
+        if g is not None:
+            g = g.detach().to(device=x.device)
+            if self.embed_speakers is not None:
+                g_ids = g.reshape(B, -1)[:, 0].to(torch.int64).contiguous()
+                self._check_speaker_ids(g_ids)
+            else:
+                g_feat = g.float().reshape(B, -1).contiguous()
+                assert g_feat.size(1) == self.gin_channels
+        return eng.forward(x, c_up=c_up, g=g_feat, g_ids=g_ids, softmax=softmax)
+
+    def _check_speaker_ids(self, g_ids):
+        """nn.Embedding raises IndexError for an id outside [0, n_speakers) (modules.py:21-24 via wavenet.py:264-268); the
+        device kernel would read past the table instead, so the check happens here (one tiny reduction, once per call)."""
+        n = self.embed_speakers.num_embeddings
+        if g_ids.numel() and (int(g_ids.min()) < 0 or int(g_ids.max()) >= n):
+            raise IndexError(f"speaker id out of range [0, {n})")
+
+    def invalidate_engine(self):
+        """Drop the packed weights (call after changing parameters through ``.data`` or any other route that does not bump
+        the tensors' version counters; ordinary in-place updates are detected by ``_get_engine``)."""
+        if self._engine is not None:
+            self._engine.close()
+        self._engine, self._engine_key = None, None
+        for f in self.conv_layers:
+            if hasattr(f, "invalidate_engine"):
+                f.invalidate_engine()
 
     # ---- engine plumbing ---------------------------------------------------------------------------
     def _get_engine(self) -> Engine:
@@ -221,6 +266,7 @@ class WaveNet(nn.Module):
         if g is not None:
             if self.embed_speakers is not None:
                 g_ids = g.reshape(B, -1)[:, 0].to(torch.int64).contiguous()
+                self._check_speaker_ids(g_ids)
             else:
                 g_feat = g.float().reshape(B, -1).contiguous()
                 assert g_feat.size(1) == self.gin_channels
