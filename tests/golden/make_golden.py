@@ -78,6 +78,15 @@ CASES = {
     "mol_wide_skip": (dict(out_channels=30, layers=6, stacks=3, residual_channels=24, gate_channels=48,
                            skip_out_channels=40, kernel_size=3, dropout=0.0, scalar_input=True,
                            cin_channels=5), 2, 40, 32, {"c_full": True}),
+    # the geometry the pipelined ring kernel is specialised for (R = 128, G = 256, K = 128): these two put the RING kernel
+    # next to numbers the reference itself produced (tests/test_gpu_golden.py runs them on both kernels).  Only the
+    # weight-normed state_dict is stored (2.4 + 1.5 MB of random weights do not compress); the loader folds it.
+    "ring_mol_r128": (dict(out_channels=30, layers=4, stacks=2, residual_channels=128, gate_channels=256,
+                           skip_out_channels=128, kernel_size=3, dropout=0.0, scalar_input=True, cin_channels=16,
+                           output_distribution="Logistic"), 2, 64, 64, {"c_full": True, "store": "wn"}),
+    "ring_onehot_r128": (dict(out_channels=256, layers=2, stacks=1, residual_channels=128, gate_channels=256,
+                              skip_out_channels=128, kernel_size=3, dropout=0.0, cin_channels=8), 2, 48, 32,
+                         {"c_full": True, "store": "wn"}),
 }
 
 
@@ -230,6 +239,16 @@ def gen_case(name, kwargs, B, Tt, Tf, extras, seed):
     model.make_generation_fast_()
     state_fused = np_state(model)
     meta = dict(kwargs=kwargs, B=B, Tt=Tt, Tf=Tf, seed=seed, extras=extras)
+    if extras.get("store") == "wn":
+        # prove here, against the reference's own make_generation_fast_, that the fold the loader will apply is the same
+        from wavenet_vocoder_amd.conv import fold_weight_norm_
+        folded = {k: torch.from_numpy(v) for k, v in state_wn.items()}
+        for k in [k for k in list(folded) if k.endswith("weight_g")]:
+            fold_weight_norm_(folded, k[:-len("weight_g")])
+        assert set(folded) == set(state_fused)
+        for k in folded:
+            assert np.allclose(folded[k].numpy(), state_fused[k], atol=1e-6, rtol=1e-6), k
+        state_fused = {}
     np.savez_compressed(os.path.join(HERE, f"{name}.npz"), __meta__=json.dumps(meta),
                         **{f"wn/{k}": v for k, v in state_wn.items()},
                         **{f"fused/{k}": v for k, v in state_fused.items()},
@@ -327,12 +346,19 @@ def gen_layer_fixtures():
 
 
 def main():
+    """No arguments: regenerate everything.  With case names: only those (seeds depend on the position in CASES, so a partial
+    run writes the same bytes a full one would)."""
+    only = set(sys.argv[1:])
+    assert only <= set(CASES) | {"layers"}, only - set(CASES)
     verify_tape_replay()
     for i, (name, (kwargs, B, Tt, Tf, extras)) in enumerate(CASES.items()):
+        if only and name not in only:
+            continue
         gen_case(name, kwargs, B, Tt, Tf, extras, seed=1000 + 10 * i)
         print("wrote", name)
-    gen_layer_fixtures()
-    print("wrote layers")
+    if not only or "layers" in only:
+        gen_layer_fixtures()
+        print("wrote layers")
     total = sum(os.path.getsize(os.path.join(HERE, f)) for f in os.listdir(HERE) if f.endswith(".npz"))
     print(f"fixtures: {total / 1e6:.2f} MB")
 

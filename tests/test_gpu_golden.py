@@ -12,10 +12,13 @@ import wavenet_vocoder_amd as wnv
 from wavenet_vocoder_amd.conv import Conv1d
 from wavenet_vocoder_amd.modules import ResidualConv1dGLU
 from tests._golden import CASE_NAMES, Case, load_layers
+from tests._margins import assert_match_or_near_tie
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
-KERNELS = [1]          # 1 = generic single-workgroup kernel; the ring kernel has its own file
+# (case, kernel) pairs: 1 = the generic single-workgroup kernel covers every case; 2 = the pipelined ring kernel takes the cases
+# of its geometry (residual 128 / gate 256 / skip 128: the reference-made ring_* fixtures)
+CASE_KERNELS = [(n, 1) for n in CASE_NAMES] + [(n, 2) for n in CASE_NAMES if n.startswith("ring_")]
 
 
 def model_on_gpu(c, layout="wn"):
@@ -28,8 +31,7 @@ def cuda(t):
     return None if t is None else t.to("cuda")
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("name", CASE_NAMES)
+@pytest.mark.parametrize("name,kernel", CASE_KERNELS)
 def test_teacher_forced_matches_reference(name, kernel):
     c = Case(name)
     m = model_on_gpu(c)
@@ -41,13 +43,13 @@ def test_teacher_forced_matches_reference(name, kernel):
                               T=x.size(-1), softmax=True, quantize=False)
     y = y.cpu()
     assert y.shape == c.get("tf_out").shape
+    assert m._get_engine().last_kernel() == kernel
     if scalar:
         p = m.last_params.cpu()
         err = (p - c.get("tf_params")).abs().max().item()
         assert err < TOL, f"distribution parameters differ by {err}"
-        # samples: same noise, so they agree unless a Gumbel argmax flipped on a near tie
-        d = (y - c.get("tf_out")).abs()
-        assert (d < TOL).float().mean().item() > 0.98, d.max()
+        # samples: same noise, so they agree -- except where the Gumbel-max pick is a near tie in the reference's own numbers
+        assert_match_or_near_tie(y, c.get("tf_out"), c.get("tf_params"), c.get("tf_tape"), c.kwargs, tol=TOL)
         # batch forward of the reference == our incremental parameters (online == offline)
         assert (p - c.get("fwd")).abs().max().item() < TOL
     else:
@@ -56,8 +58,7 @@ def test_teacher_forced_matches_reference(name, kernel):
         assert (y - c.get("fwd")).abs().max().item() < TOL
 
 
-@pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("name", CASE_NAMES)
+@pytest.mark.parametrize("name,kernel", CASE_KERNELS)
 def test_free_running_with_shared_tape(name, kernel):
     c = Case(name)
     m = model_on_gpu(c, "fused")

@@ -1,0 +1,128 @@
+"""-m gpu: the boundary under adverse conditions (VERDICT r01 "What's weak" 7).
+
+  * CU MASK.  The pipelined ring kernel needs every one of its workgroups resident at once.  With most CUs masked away
+    (HSA_CU_MASK, set before the HIP runtime starts -> a subprocess) a ring launch cannot become co-resident; the bounded spins
+    give up, the launch drains, and `kernel = 0` (auto) serves the call on the generic kernel, says why on stderr, and stays
+    there.  An explicit `kernel = 2` reports TimeoutError / NotImplementedError -- never a hang, never garbage.
+  * ASYNCHRONOUS ring launches (WNV_GEN_ASYNC): same bits as the synchronous call; the status arrives through wnv_wait.
+  * the engine configuration read off the module tree (the reference-side graft's path) drives the same launch."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tests._configs import CONFIGS, build, inputs
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, sys, time, torch
+sys.path.insert(0, %(root)r)
+from tests._configs import build, inputs
+name, B, T = "cfg2_mol", 8, 256
+m = build(name).to("cuda")
+eng = m._get_engine()
+c, _ = inputs(name, B, T)
+c_up = eng.upsample(c.cuda(), T_expected=T)
+res = {}
+ref, _, _ = eng.generate(B=B, T=T, c_up=c_up, seed=11, kernel=1)
+t0 = time.time()
+auto, _, _ = eng.generate(B=B, T=T, c_up=c_up, seed=11, kernel=0)
+torch.cuda.synchronize()
+res["auto_seconds"] = time.time() - t0
+res["auto_kernel"] = eng.last_kernel()
+res["auto_vs_generic"] = float((auto - ref).abs().max())
+t0 = time.time()
+again, _, _ = eng.generate(B=B, T=T, c_up=c_up, seed=11, kernel=0)
+torch.cuda.synchronize()
+res["second_auto_seconds"] = time.time() - t0
+res["second_auto_kernel"] = eng.last_kernel()
+res["second_equal"] = bool(torch.equal(again, auto))
+try:
+    eng2 = build(name).to("cuda")._get_engine()
+    forced, _, _ = eng2.generate(B=B, T=T, c_up=c_up, seed=11, kernel=2)
+    res["forced"] = "ran"
+    res["forced_vs_generic"] = float((forced - ref).abs().max())
+except (TimeoutError, NotImplementedError) as e:
+    res["forced"] = type(e).__name__ + ": " + str(e)[:200]
+print("RESULT " + json.dumps(res), flush=True)
+"""
+
+
+def run_child(env_extra, timeout=240):
+    env = dict(os.environ)
+    env.update(env_extra)
+    p = subprocess.Popen([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()                      # this PID only
+        out, err = p.communicate()
+        pytest.fail(f"the child did not finish in {timeout} s (a wait that is not bounded?)\n{err[-2000:]}")
+    lines = [ln for ln in out.splitlines() if ln.startswith("RESULT ")]
+    assert p.returncode == 0 and lines, f"rc {p.returncode}\n{out[-1500:]}\n{err[-3000:]}"
+    return json.loads(lines[-1][7:]), err
+
+
+def test_unmasked_device_runs_the_ring():
+    res, err = run_child({"WNV_RING_CENSUS": "1"})
+    print(res, err[-300:])
+    assert res["auto_kernel"] == 2 and res["forced"] == "ran"
+    assert res["auto_vs_generic"] < 1e-3 and res["forced_vs_generic"] < 1e-3
+    assert "8 XCDs" in err and "verified" in err                     # the placement census saw what the layout assumes
+
+
+def test_cu_mask_clean_timeout_then_fallback():
+    """64 of 256 CUs visible to the queues of device 0: 224 co-resident workgroups are impossible."""
+    res, err = run_child({"HSA_CU_MASK": "0:0-63", "WNV_RING_CENSUS": "1"})
+    print(res, err[-600:])
+    # whatever the runtime reports under the mask, the call must succeed with the generic kernel's result ...
+    assert res["auto_vs_generic"] < 1e-3, res
+    if res["auto_kernel"] == 1:
+        # ... and when the ring was tried and gave up (or was refused up front), the reason is on stderr and the handle stays put
+        assert "[wnv] device 0" in err and ("timed out" in err or "cannot run here" in err), err[-1500:]
+        assert res["second_auto_kernel"] == 1 and res["second_equal"]
+        assert res["second_auto_seconds"] < max(1.0, 0.5 * res["auto_seconds"] + 0.5), res      # no second timeout
+        assert res["forced"] != "ran" or res["forced_vs_generic"] < 1e-3
+        assert res["forced"] == "ran" or res["forced"].startswith(("TimeoutError", "NotImplementedError")), res
+    else:
+        # the mask left enough CUs co-resident after all (or is not honoured on this box): the ring result must be right
+        assert res["forced"] == "ran" and res["forced_vs_generic"] < 1e-3, res
+
+
+def test_asynchronous_ring_launch_equals_the_synchronous_one():
+    name, B, T = "cfg2_mol", 8, 1024
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    c, _ = inputs(name, B, T)
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    sync, _, _ = eng.generate(B=B, T=T, c_up=c_up, seed=3, kernel=2)
+    a1, _, _ = eng.generate(B=B, T=T, c_up=c_up, seed=3, kernel=2, asynchronous=True)
+    eng.wait()                                                        # status of the launch: nothing gave up
+    assert torch.equal(a1, sync)
+    a2, _, _ = eng.generate(B=B, T=T, c_up=c_up, seed=4, kernel=2, asynchronous=True)
+    a3, _, _ = eng.generate(B=B, T=T, c_up=c_up, seed=3, kernel=2, asynchronous=True)      # waits for a2's status first
+    eng.wait()
+    eng.wait()                                                        # idempotent
+    assert torch.equal(a3, sync) and not torch.equal(a2, sync)
+
+
+def test_config_read_off_the_module_tree_runs_the_same_launch():
+    """EngineHost without the explicit constructor record = what the reference-side graft does (graft.infer_config_kwargs)."""
+    name, B, T = "cfg4_mol_multispeaker", 3, 512
+    a = build(name).to("cuda")
+    b = build(name).to("cuda")
+    del b._cfg_kwargs
+    c, gids = inputs(name, B, T)
+    outs = []
+    for m in (a, b):
+        m.rng = "philox"
+        torch.manual_seed(7)
+        outs.append(m.incremental_forward(c=c.cuda(), g=gids.cuda(), T=T))
+    assert torch.equal(outs[0], outs[1])
+    with pytest.raises(IndexError):                                   # nn.Embedding's error for an unknown speaker (wavenet.py:264-268)
+        a.incremental_forward(c=c.cuda(), g=torch.full((B, 1), 7), T=T)

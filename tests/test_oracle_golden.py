@@ -15,7 +15,7 @@ torch.set_num_threads(1)
 @pytest.mark.parametrize("name", CASE_NAMES)
 def test_fold_equals_make_generation_fast(name):
     c = Case(name)
-    folded = fold_weight_norm(c.wn)
+    folded = fold_weight_norm(c.wn)          # (for wn-only cases c.fused is the PRODUCT's fold: the two folds must agree)
     assert set(folded) == set(c.fused)
     for k in folded:
         assert torch.allclose(folded[k].float(), c.fused[k].float(), atol=1e-6, rtol=1e-6), k

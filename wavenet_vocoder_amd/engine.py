@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from ._lib import Config, GenerateArgs, GluConfig, Tensor, check
 
-__all__ = ["Engine", "QueueConv", "GluLayer", "make_config", "require_gpu_tensor"]
+__all__ = ["Engine", "QueueConv", "GluLayer", "make_config", "require_gpu_tensor", "check_checkpoint"]
 
 
 def require_gpu_tensor(t: torch.Tensor, what: str) -> None:
@@ -84,6 +84,23 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def _stream(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
+
+
+def check_checkpoint(cfg: Config, state: Dict[str, torch.Tensor], batch: int = 8) -> Dict[str, int]:
+    """Run a ``state_dict`` through the engine's native checkpoint path WITHOUT a device (``wnv_create(device = -1)`` +
+    ``wnv_load_weights``): key / shape validation, weight-norm fold, packing.  Raises what loading on a GPU would raise;
+    returns the algorithmic work the engine derives from it."""
+    h = C.c_void_p()
+    check(_lib.lib().wnv_create(C.byref(cfg), -1, C.byref(h)))
+    try:
+        arr, keep = _tensor_table(state)
+        check(_lib.lib().wnv_load_weights(h, arr, len(state)))
+        del keep
+        return {"macs_per_sample": int(_lib.lib().wnv_macs_per_sample(h)),
+                "bytes_per_step": int(_lib.lib().wnv_bytes_per_step(h, int(batch))),
+                "receptive_field": int(_lib.lib().wnv_receptive_field(cfg.layers, cfg.stacks, cfg.kernel_size))}
+    finally:
+        _lib.lib().wnv_destroy(h)
 
 
 class Engine:

@@ -1,0 +1,214 @@
+"""The engine-backed ``incremental_forward`` as a MIXIN, and the reference-side graft built from it.
+
+``EngineHost`` holds everything that turns a WaveNet module tree into calls on the C ABI (include/wnv.h): building the
+``wnv_config`` from the module, handing the ``state_dict`` to ``wnv_load_weights`` (weight-normed or fused), caching the packed
+weights, and the argument handling of ``incremental_forward`` (reference wavenet.py:215-343).  It assumes only the attribute and
+sub-module names of the reference class (wavenet.py:98-156), so it serves two hosts:
+
+  * ``wavenet_vocoder_amd.WaveNet`` -- this package's stand-alone module (``class WaveNet(EngineHost, nn.Module)``);
+  * ``make_wavenet_amd(wavenet_vocoder.WaveNet)`` -- the graft a maintainer of the reference adds:
+    a subclass of the REFERENCE's own class whose constructor, parameters, ``state_dict``, ``forward`` and training code stay
+    the reference's, while ``incremental_forward`` runs in libwnv_hip.so.  ``synthesis.py`` / ``evaluate.py`` / ``train.eval_model``
+    call it unchanged.
+
+Nothing here imports the reference: the graft takes its class as an argument.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .engine import Engine, check_checkpoint, make_config, require_gpu_tensor
+from .noise import make_noise_tape
+
+__all__ = ["EngineHost", "infer_config_kwargs", "make_wavenet_amd"]
+
+
+def infer_config_kwargs(m) -> dict:
+    """The constructor arguments the engine needs (``engine.make_config``), read off a WaveNet module tree with the reference's
+    attribute names (wavenet.py:112-156) -- the reference keeps only some of its constructor arguments as attributes, the rest is
+    recovered from the sub-modules."""
+    layers = len(m.conv_layers)
+    first = m.conv_layers[0]
+    dil = [int(f.conv.dilation[0]) for f in m.conv_layers]
+    per = next((i for i in range(1, layers) if dil[i] == 1), layers)                # dilation = 2 ** (i % per)  (wavenet.py:126)
+    if layers % per or any(d != 2 ** (i % per) for i, d in enumerate(dil)):
+        raise NotImplementedError(f"dilation pattern {dil} is not 2 ** (i % layers_per_stack)")
+    gin = int(first.conv1x1g.in_channels) if getattr(first, "conv1x1g", None) is not None else -1
+    emb = getattr(m, "embed_speakers", None)
+    kw = dict(out_channels=int(m.out_channels), layers=layers, stacks=layers // per,
+              residual_channels=int(m.first_conv.out_channels), gate_channels=int(first.conv.out_channels),
+              skip_out_channels=int(first.conv1x1_skip.out_channels), kernel_size=int(first.conv.kernel_size[0]),
+              cin_channels=int(m.cin_channels), gin_channels=gin,
+              n_speakers=None if emb is None else int(emb.num_embeddings), use_speaker_embedding=emb is not None,
+              scalar_input=bool(m.scalar_input), output_distribution=m.output_distribution,
+              upsample_net=None, upsample_scales=[], freq_axis_kernel_size=1, cin_pad=0)
+    up = getattr(m, "upsample_net", None)
+    if up is not None:
+        kind = type(up).__name__
+        inner = up.upsample if kind == "ConvInUpsampleNetwork" else up
+        scales, freq = [], 1
+        for layer in inner.up_layers:
+            name = type(layer).__name__
+            if name == "Stretch2d":
+                if getattr(layer, "mode", "nearest") != "nearest" or int(getattr(layer, "y_scale", 1)) != 1:
+                    raise NotImplementedError("only nearest-neighbour stretching along time is implemented (upsample.py:20)")
+                scales.append(int(layer.x_scale))
+            elif hasattr(layer, "kernel_size"):
+                freq = int(layer.kernel_size[0])
+            else:
+                raise NotImplementedError(f"upsample activation {name} is not implemented (no reference preset uses one)")
+        total = 1
+        for s in scales:
+            total *= s
+        cin_pad = (int(up.conv_in.kernel_size[0]) - 1) // 2 if kind == "ConvInUpsampleNetwork" else int(up.indent) // total
+        kw.update(upsample_net=kind, upsample_scales=scales, freq_axis_kernel_size=freq, cin_pad=cin_pad)
+    return kw
+
+
+class EngineHost:
+    """Mixin for an ``nn.Module`` with the reference WaveNet's attribute names; see the module docstring."""
+
+    # engine state: class-level defaults so that a grafted subclass needs no __init__ of its own
+    rng = "replay"            # "replay": the stream torch's CPU generator gives the reference for the current seed | "philox"
+    kernel = 0                # 0 auto, 1 generic single-workgroup kernel, 2 pipelined ring kernel
+    capture_params = False    # keep the head outputs (B, O, T) of the last call in ``last_params``
+    last_params = None
+    _engine: Optional[Engine] = None
+    _engine_key = None
+
+    def _wnv_config_kwargs(self) -> dict:
+        kw = getattr(self, "_cfg_kwargs", None)
+        return dict(kw) if kw is not None else infer_config_kwargs(self)
+
+    def check_engine_checkpoint(self, batch: int = 8) -> dict:
+        """This module's ``state_dict`` through the engine's native checkpoint path on the HOST (no GPU needed): validation,
+        weight-norm fold, packing; returns {macs_per_sample, bytes_per_step, receptive_field} as the engine computes them."""
+        return check_checkpoint(make_config(**self._wnv_config_kwargs()), self.state_dict(), batch)
+
+    def _check_speaker_ids(self, g_ids):
+        """nn.Embedding raises IndexError for an id outside [0, n_speakers) (modules.py:21-24 via wavenet.py:264-268); the
+        device kernel would read past the table instead, so the check happens here (one tiny reduction, once per call)."""
+        n = self.embed_speakers.num_embeddings
+        if g_ids.numel() and (int(g_ids.min()) < 0 or int(g_ids.max()) >= n):
+            raise IndexError(f"speaker id out of range [0, {n})")
+
+    def invalidate_engine(self):
+        """Drop the packed weights (call after changing parameters through ``.data`` or any other route that does not bump
+        the tensors' version counters; ordinary in-place updates are detected by ``_get_engine``)."""
+        if self._engine is not None:
+            self._engine.close()
+        self._engine, self._engine_key = None, None
+        for f in self.conv_layers:
+            if hasattr(f, "invalidate_engine"):
+                f.invalidate_engine()
+
+    # ---- engine plumbing ---------------------------------------------------------------------------
+    def _get_engine(self) -> Engine:
+        params = list(self.parameters())
+        require_gpu_tensor(params[0], "WaveNet parameters")
+        dev = params[0].device
+        key = tuple((p.device, p.data_ptr(), p._version) for p in params)
+        if self._engine is None or self._engine_key != key:
+            if self._engine is not None:
+                self._engine.close()
+            eng = Engine(make_config(**self._wnv_config_kwargs()), dev)
+            eng.load_weights(self.state_dict())
+            self._engine, self._engine_key = eng, key
+        return self._engine
+
+    def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None,
+                            tqdm=lambda x: x, softmax=True, quantize=True, log_scale_min=-50.0):
+        """Autoregressive generation; same signature and return layout as reference wavenet.py:215-343.
+        ``tqdm`` is accepted and ignored (there is no per-sample host iteration to wrap); ``log_scale_min``
+        is accepted and unused exactly as in the reference (mixture.py:147-148: clamp_log_scale=False)."""
+        if self.training:
+            raise RuntimeError('incremental_forward only supports eval mode')     # conv.py:19-20
+        eng = self._get_engine()
+        dev = eng.device
+        C_in = 1 if self.scalar_input else self.out_channels
+
+        def prep(t):
+            return None if t is None else t.detach().to(device=dev)
+
+        initial_input, c, g, test_inputs = prep(initial_input), prep(c), prep(g), prep(test_inputs)
+        B = 1
+        if test_inputs is not None:                                               # wavenet.py:245-258
+            if self.scalar_input:
+                if test_inputs.size(1) == 1:
+                    test_inputs = test_inputs.transpose(1, 2)
+            elif test_inputs.size(1) == self.out_channels:
+                test_inputs = test_inputs.transpose(1, 2)
+            test_inputs = test_inputs.float().contiguous()                        # (B, Tt, C)
+            B = test_inputs.size(0)
+            T = test_inputs.size(1) if T is None else max(int(T), test_inputs.size(1))
+        T = int(T)
+        if c is not None:
+            B = c.shape[0]
+        elif test_inputs is None:
+            if initial_input is not None:
+                B = initial_input.size(0)
+            elif g is not None:
+                B = g.size(0)
+        # global conditioning (wavenet.py:262-269): ids -> embedding, or external float features
+        g_ids = g_feat = None
+        if g is not None:
+            if self.embed_speakers is not None:
+                g_ids = g.reshape(B, -1)[:, 0].to(torch.int64).contiguous()
+                self._check_speaker_ids(g_ids)
+            else:
+                g_feat = g.float().reshape(B, -1).contiguous()
+                assert g_feat.size(1) == self._wnv_config_kwargs()["gin_channels"]
+        # local conditioning (wavenet.py:272-278)
+        c_up = None
+        if c is not None:
+            c = c.float()
+            if self.upsample_net is not None:
+                c_up = eng.upsample(c.contiguous(), T_expected=T)                 # asserts length == T
+            elif c.size(-1) == T:
+                c_up = c.transpose(1, 2).contiguous()
+            else:
+                c_up = c.contiguous()                                             # already (B, T, cin)
+            assert c_up.shape == (B, T, self.cin_channels), (tuple(c_up.shape), (B, T, self.cin_channels))
+        # first input (wavenet.py:281-292)
+        init = None
+        if initial_input is not None:
+            if initial_input.size(1) == self.out_channels and not self.scalar_input:
+                initial_input = initial_input.transpose(1, 2)
+            init = initial_input.float().reshape(B, -1).contiguous()
+            assert init.size(1) == C_in, (tuple(init.shape), C_in)
+        # noise
+        noise, seed = None, 0
+        if self.rng == "replay":
+            tape = make_noise_tape(T, B, scalar_input=self.scalar_input,
+                                   output_distribution=self.output_distribution, out_channels=self.out_channels)
+            noise = tape.to(dev, non_blocking=False).contiguous()
+        elif self.rng == "philox":
+            seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        else:
+            raise ValueError(f"unknown rng mode {self.rng!r}")
+        out, params, _ = eng.generate(B=B, T=T, c_up=c_up, g=g_feat, g_ids=g_ids, initial=init,
+                                      teacher=test_inputs, noise=noise, seed=seed, softmax=softmax,
+                                      quantize=quantize, want_params=self.capture_params, kernel=self.kernel)
+        self.last_params = params
+        return out
+
+
+def make_wavenet_amd(reference_wavenet_cls):
+    """``class WaveNetAMD(EngineHost, wavenet_vocoder.WaveNet)``: the reference's class with its sample loop in libwnv_hip.so.
+
+        from wavenet_vocoder import WaveNet
+        from wavenet_vocoder_amd.graft import make_wavenet_amd
+        WaveNetAMD = make_wavenet_amd(WaveNet)
+        model = WaveNetAMD(**kwargs); model.load_state_dict(checkpoint["state_dict"]); model.eval().to("cuda")
+        y = model.incremental_forward(c=c, g=g, T=T, softmax=True, quantize=True)      # synthesis.py:61-64, unchanged
+
+    The constructor, ``forward``, ``state_dict`` keys (weight-normed until ``make_generation_fast_``; the engine folds either
+    form) and everything training uses are inherited from the reference; only ``incremental_forward`` (and with it
+    ``clear_buffer``'s meaning for the engine) comes from ``EngineHost``."""
+    if not isinstance(reference_wavenet_cls, type):
+        raise TypeError("make_wavenet_amd expects the reference's WaveNet class")
+    return type("WaveNetAMD", (EngineHost, reference_wavenet_cls),
+                {"__doc__": "wavenet_vocoder.WaveNet with incremental_forward running in the MI355X engine (libwnv_hip.so)",
+                 "__module__": __name__})

@@ -26,9 +26,8 @@ from torch import nn
 from torch.nn import functional as F
 
 from . import upsample
-from .engine import Engine, make_config, require_gpu_tensor
+from .graft import EngineHost
 from .modules import Conv1d1x1, Embedding, ResidualConv1dGLU
-from .noise import make_noise_tape
 
 __all__ = ["WaveNet", "receptive_field_size"]
 
@@ -49,7 +48,7 @@ def _expand_global_features(B, T, g, bct=True):
     return e.contiguous() if bct else e.transpose(1, 2).contiguous()
 
 
-class WaveNet(nn.Module):
+class WaveNet(EngineHost, nn.Module):
     def __init__(self, out_channels=256, layers=20, stacks=2, residual_channels=512, gate_channels=512,
                  skip_out_channels=512, kernel_size=3, dropout=1 - 0.95, cin_channels=-1, gin_channels=-1,
                  n_speakers=None, upsample_conditional_features=False,
@@ -100,13 +99,7 @@ class WaveNet(nn.Module):
             output_distribution=output_distribution, upsample_net=self._upsample_kind,
             upsample_scales=self._upsample_scales, freq_axis_kernel_size=self._freq_k,
             cin_pad=self._upsample_cin_pad)
-        # engine state (not part of the module state)
-        self.rng = "replay"          # "replay": reference CPU stream of the current torch seed | "philox"
-        self.kernel = 0              # 0 auto, 1 generic single-workgroup kernel, 2 pipelined ring kernel
-        self._engine: Optional[Engine] = None
-        self._engine_key = None
-        self.last_params = None      # head outputs (B, O, T) of the last call when ``capture_params``
-        self.capture_params = False
+        # engine state (rng, kernel, capture_params, last_params, the packed-weight cache): EngineHost, not module state
 
     # ---- reference API ---------------------------------------------------------------------------
     def has_speaker_embedding(self):
@@ -196,110 +189,3 @@ class WaveNet(nn.Module):
                 g_feat = g.float().reshape(B, -1).contiguous()
                 assert g_feat.size(1) == self.gin_channels
         return eng.forward(x, c_up=c_up, g=g_feat, g_ids=g_ids, softmax=softmax)
-
-    def _check_speaker_ids(self, g_ids):
-        """nn.Embedding raises IndexError for an id outside [0, n_speakers) (modules.py:21-24 via wavenet.py:264-268); the
-        device kernel would read past the table instead, so the check happens here (one tiny reduction, once per call)."""
-        n = self.embed_speakers.num_embeddings
-        if g_ids.numel() and (int(g_ids.min()) < 0 or int(g_ids.max()) >= n):
-            raise IndexError(f"speaker id out of range [0, {n})")
-
-    def invalidate_engine(self):
-        """Drop the packed weights (call after changing parameters through ``.data`` or any other route that does not bump
-        the tensors' version counters; ordinary in-place updates are detected by ``_get_engine``)."""
-        if self._engine is not None:
-            self._engine.close()
-        self._engine, self._engine_key = None, None
-        for f in self.conv_layers:
-            if hasattr(f, "invalidate_engine"):
-                f.invalidate_engine()
-
-    # ---- engine plumbing ---------------------------------------------------------------------------
-    def _get_engine(self) -> Engine:
-        params = list(self.parameters())
-        require_gpu_tensor(params[0], "WaveNet parameters")
-        dev = params[0].device
-        key = tuple((p.device, p.data_ptr(), p._version) for p in params)
-        if self._engine is None or self._engine_key != key:
-            if self._engine is not None:
-                self._engine.close()
-            eng = Engine(make_config(**self._cfg_kwargs), dev)
-            eng.load_weights(self.state_dict())
-            self._engine, self._engine_key = eng, key
-        return self._engine
-
-    def incremental_forward(self, initial_input=None, c=None, g=None, T=100, test_inputs=None,
-                            tqdm=lambda x: x, softmax=True, quantize=True, log_scale_min=-50.0):
-        """Autoregressive generation; same signature and return layout as reference wavenet.py:215-343.
-        ``tqdm`` is accepted and ignored (there is no per-sample host iteration to wrap); ``log_scale_min``
-        is accepted and unused exactly as in the reference (mixture.py:147-148: clamp_log_scale=False)."""
-        if self.training:
-            raise RuntimeError('incremental_forward only supports eval mode')     # conv.py:19-20
-        eng = self._get_engine()
-        dev = eng.device
-        C_in = 1 if self.scalar_input else self.out_channels
-
-        def prep(t):
-            return None if t is None else t.detach().to(device=dev)
-
-        initial_input, c, g, test_inputs = prep(initial_input), prep(c), prep(g), prep(test_inputs)
-        B = 1
-        if test_inputs is not None:                                               # wavenet.py:245-258
-            if self.scalar_input:
-                if test_inputs.size(1) == 1:
-                    test_inputs = test_inputs.transpose(1, 2)
-            elif test_inputs.size(1) == self.out_channels:
-                test_inputs = test_inputs.transpose(1, 2)
-            test_inputs = test_inputs.float().contiguous()                        # (B, Tt, C)
-            B = test_inputs.size(0)
-            T = test_inputs.size(1) if T is None else max(int(T), test_inputs.size(1))
-        T = int(T)
-        if c is not None:
-            B = c.shape[0]
-        elif test_inputs is None:
-            if initial_input is not None:
-                B = initial_input.size(0)
-            elif g is not None:
-                B = g.size(0)
-        # global conditioning (wavenet.py:262-269): ids -> embedding, or external float features
-        g_ids = g_feat = None
-        if g is not None:
-            if self.embed_speakers is not None:
-                g_ids = g.reshape(B, -1)[:, 0].to(torch.int64).contiguous()
-                self._check_speaker_ids(g_ids)
-            else:
-                g_feat = g.float().reshape(B, -1).contiguous()
-                assert g_feat.size(1) == self.gin_channels
-        # local conditioning (wavenet.py:272-278)
-        c_up = None
-        if c is not None:
-            c = c.float()
-            if self.upsample_net is not None:
-                c_up = eng.upsample(c.contiguous(), T_expected=T)                 # asserts length == T
-            elif c.size(-1) == T:
-                c_up = c.transpose(1, 2).contiguous()
-            else:
-                c_up = c.contiguous()                                             # already (B, T, cin)
-            assert c_up.shape == (B, T, self.cin_channels), (tuple(c_up.shape), (B, T, self.cin_channels))
-        # first input (wavenet.py:281-292)
-        init = None
-        if initial_input is not None:
-            if initial_input.size(1) == self.out_channels and not self.scalar_input:
-                initial_input = initial_input.transpose(1, 2)
-            init = initial_input.float().reshape(B, -1).contiguous()
-            assert init.size(1) == C_in, (tuple(init.shape), C_in)
-        # noise
-        noise, seed = None, 0
-        if self.rng == "replay":
-            tape = make_noise_tape(T, B, scalar_input=self.scalar_input,
-                                   output_distribution=self.output_distribution, out_channels=self.out_channels)
-            noise = tape.to(dev, non_blocking=False).contiguous()
-        elif self.rng == "philox":
-            seed = int(torch.empty((), dtype=torch.int64).random_().item())
-        else:
-            raise ValueError(f"unknown rng mode {self.rng!r}")
-        out, params, _ = eng.generate(B=B, T=T, c_up=c_up, g=g_feat, g_ids=g_ids, initial=init,
-                                      teacher=test_inputs, noise=noise, seed=seed, softmax=softmax,
-                                      quantize=quantize, want_params=self.capture_params, kernel=self.kernel)
-        self.last_params = params
-        return out
