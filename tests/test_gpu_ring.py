@@ -156,10 +156,63 @@ def test_ring_properties_at_length():
 
 
 def test_unsupported_configs_say_so():
-    m = build("cfg0_mulaw256_small").to("cuda")
-    eng = m._get_engine()
+    kw = dict(CONFIGS["cfg2_mol"], residual_channels=256, gate_channels=512, skip_out_channels=256)      # wider than one CU's layer
+    torch.manual_seed(0)
+    eng = wnv.WaveNet(**kw).eval().to("cuda")._get_engine()
     with pytest.raises(NotImplementedError, match="ring kernel"):
-        eng.generate(B=1, T=16, kernel=2)
+        eng.generate(B=1, T=16, c_up=torch.zeros(1, 16, 80, device="cuda"), kernel=2)
+    out, _, _ = eng.generate(B=1, T=16, c_up=torch.zeros(1, 16, 80, device="cuda"), kernel=0)             # auto: the generic kernel
+    assert eng.last_kernel() == 1 and torch.isfinite(out).all()
+
+
+# ---- models narrower than the kernel's 128 / 256 / 128 n geometry run zero-padded (exact: padded channels stay 0) ------------
+NARROW = {
+    "cfg0_mulaw256_small": CONFIGS["cfg0_mulaw256_small"],       # BASELINE cfg0: one-hot, R64 / G128 / K64, no conditioning
+    "mol_r96_g160_k200": dict(out_channels=30, layers=6, stacks=3, residual_channels=96, gate_channels=160, skip_out_channels=200,
+                              kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=24,
+                              gin_channels=8, n_speakers=3, use_speaker_embedding=True),
+    "gauss_r32_g64_k32_kw2": dict(out_channels=2, layers=4, stacks=2, residual_channels=32, gate_channels=64, skip_out_channels=32,
+                                  kernel_size=2, dropout=0.0, scalar_input=True, output_distribution="Normal"),
+}
+
+
+@pytest.mark.parametrize("name", list(NARROW))
+def test_ring_narrow_models_zero_padded_vs_oracle_and_generic(name):
+    kw = NARROW[name]
+    torch.manual_seed(17)
+    m = tame_head_(wnv.WaveNet(**kw).eval())
+    o = Oracle(oracle_config(kw), m.state_dict())
+    scalar = kw.get("scalar_input", False)
+    B, Tt, T = 3, 96, 192
+    g = torch.Generator().manual_seed(2)
+    cin, gin = kw.get("cin_channels", -1), kw.get("gin_channels", -1)
+    c = torch.randn(B, cin, T, generator=g) if cin > 0 else None
+    gids = torch.randint(0, kw["n_speakers"], (B, 1), generator=g) if gin > 0 else None
+    from tests.test_gpu_configs import teacher
+    x = teacher(kw, B, Tt)
+    tape = make_noise_tape(T, B, scalar_input=scalar, output_distribution=kw.get("output_distribution", "Logistic"),
+                           out_channels=kw["out_channels"], generator=torch.Generator().manual_seed(6))
+    torch.set_num_threads(8)
+    want, wparams = o.incremental_forward(test_inputs=x, c=c, g=gids, T=T, noise=tape, return_params=True)
+    eng = m.to("cuda")._get_engine()
+    res = {}
+    for k in (1, 2):
+        res[k] = eng.generate(B=B, T=T, c_up=None if c is None else c.transpose(1, 2).contiguous().cuda(),
+                              g_ids=None if gids is None else gids[:, 0].cuda(), teacher=x.transpose(1, 2).contiguous().cuda(),
+                              noise=tape.cuda(), want_params=True, want_index=not scalar, kernel=k)
+        assert eng.last_kernel() == k
+    out, params, idx = res[2]
+    assert (params.cpu()[:, :, :Tt] - wparams[:, :, :Tt]).abs().max().item() < TOL            # ring vs oracle, forced part
+    assert (params[:, :, :Tt] - res[1][1][:, :, :Tt]).abs().max().item() < 2e-5               # ring vs generic kernel
+    if scalar:
+        assert_match_or_near_tie(out.cpu()[:, :, :Tt - 1], want[:, :, :Tt - 1], wparams[:, :, :Tt - 1], tape[:Tt - 1], kw, tol=TOL)
+        assert_free_run_agrees_until_near_tie(out.cpu(), want, params.cpu(), wparams, tape, kw, t0=Tt - 1, what=name)
+    else:
+        assert_match_or_near_tie(idx.cpu()[:, :Tt - 1], want.argmax(1)[:, :Tt - 1], wparams[:, :, :Tt - 1], tape[:Tt - 1], kw)
+        assert_free_run_agrees_until_near_tie(idx.cpu(), want.argmax(1), params.cpu(), wparams, tape, kw, t0=Tt - 1, what=name)
+    auto, _, _ = eng.generate(B=B, T=T, c_up=None if c is None else c.transpose(1, 2).contiguous().cuda(),
+                              g_ids=None if gids is None else gids[:, 0].cuda(), noise=tape.cuda(), kernel=0)
+    assert eng.last_kernel() == 2, "auto must pick the ring kernel for a model that fits its geometry after padding"
 
 
 def test_ring_slow_path_is_bit_identical(monkeypatch):

@@ -70,8 +70,9 @@ struct RingParams {
     const float *wh1img, *bh1, *wh2img, *bh2, *wfirst, *bfirst;   // one-hot models: wh2img holds two row images (rows i, 128 + i), wfirst is K-major [cin1][128]
     int cin1, softmax, quantize;       // first_conv input channels (1 = scalar input); categorical head switches (wavenet.py:332-335)
     int* index_out;
-    const float* zbias;
+    const float* zbias;                // effective conv bias of the generic pack: [B or 1][L][zb_ld], rows = the model's own G gate rows
     long long zbias_bstride;
+    int zb_ld, gh;                     // its row stride (G padded to 4) and the model's G / 2: padded output n -> row (n >> 7) * gh + (n & 127)
     const int *lay_dil, *lay_histoff;
     unsigned long long *xmail, *hmail, *smail;   // chain inputs X[b][S+1][128]; layer inputs H[b][2 (t parity)][S+1][128]; skip sums
     unsigned long long *omail;                   // head parts j > 0 -> part 0: partial head outputs O[b][NH][Op]
@@ -319,9 +320,10 @@ __device__ __forceinline__ bool same_xcd_as(const RingParams& p, int reader_a, i
 }
 
 // debug timeline: stamp slot k of (step t, position pos) with the device-wide 100 MHz wall clock
+constexpr int TRW = 16;            // stamp slots per (step, position)
 __device__ __forceinline__ void stamp(const RingParams& p, int b, int t, int pos, int k, int who = 0) {
     if (p.trace && b == 0 && (int)threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
-        p.trace[((size_t)(t - p.trace_t0) * (p.S + 1) + pos) * 8 + k] = wall_clock64();
+        p.trace[((size_t)(t - p.trace_t0) * (p.S + 1) + pos) * TRW + k] = wall_clock64();
 }
 
 // sum over the four adjacent lanes of a quad (the four K-quarters of one output channel): two DPP quad_perm adds
@@ -580,7 +582,12 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                     const int b = b0 + u0 + u;
                     float* rec = p.pmail + ((size_t)b * p.L + l) * (4 + GC);
                     if (live) {
-                        const float4 zb = *reinterpret_cast<const float4*>(p.zbias + (size_t)b * p.zbias_bstride + (size_t)l * GC + 4 * n4);
+                        // the bias rows are the MODEL's gate rows (tanh rows [0, G/2), sigmoid rows [G/2, G)); this kernel's 256 outputs
+                        // are tanh channels 0..127 then sigmoid channels 0..127, zero beyond G/2 (models narrower than 128 / 256 are padded)
+                        const int zhalf = (4 * n4) >> 7, zch = (4 * n4) & 127;
+                        const float* zrow = p.zbias + (size_t)b * p.zbias_bstride + (size_t)l * p.zb_ld + (size_t)zhalf * p.gh + zch;
+                        const float4 zb = make_float4(zch < p.gh ? zrow[0] : 0.f, zch + 1 < p.gh ? zrow[1] : 0.f, zch + 2 < p.gh ? zrow[2] : 0.f,
+                                                      zch + 3 < p.gh ? zrow[3] : 0.f);
                         const float4 cv = *reinterpret_cast<const float4*>(p.cvec + (size_t)l * GC + 4 * n4);
                         float4 v = make_float4(zb.x + cv.x, zb.y + cv.y, zb.z + cv.z, zb.w + cv.w);
 #pragma unroll
@@ -724,6 +731,9 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 else
                     got = wave_recv2(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane, false, u4v{0, 0, 0, 0});
                 if (!got) s.flags[0] = 1;
+#ifdef WNV_FINE_TRACE
+                stamp(p, b, t, sidx, 8);            // the poll that carried every tag has returned
+#endif
                 *reinterpret_cast<float2*>(s.hx + eidx(2 * lane)) = make_float2(v0, v1);
             }
             __syncthreads();
@@ -742,10 +752,16 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 const float a = quad_allreduce((hi ? a1 : a0) + dpp_mov<0x141>(hi ? a0 : a1)) + zin_a;
                 const float g = quad_allreduce((hi ? g1 : g0) + dpp_mov<0x141>(hi ? g0 : g1)) + zin_g;
                 const float u = fast_gate(a, g);                                // modules.py:154
+#ifdef WNV_FINE_TRACE
+                stamp(p, b, t, sidx, 5);            // gate value ready (wave 0)
+#endif
                 if (writer) {
                     if (!last_stage) st_granule(x_out, tag, u, fast);           // send on: nothing else is on the chain
                     s.us[eidx(ch)] = u;
                 }
+#ifdef WNV_FINE_TRACE
+                if (wave > 0) stamp(p, b, t, sidx, 8 + wave, 64 * wave);        // when each of the other waves issued its share of u
+#endif
             }
             stamp(p, b, t, sidx, 1);
             // ---- behind the send -----------------------------------------------------------------------------------
@@ -1217,14 +1233,14 @@ struct WnvRingState {
 
 static const char* why_not(const wnv_config& c, int B) {
     if (!c.scalar_input && c.out_channels > 256) return "one-hot models need out_channels <= 256";
-    if (c.residual_channels != RC || c.gate_channels != GC) return "needs residual_channels == 128 and gate_channels == 256";
-    if (c.skip_out_channels != 128 && c.skip_out_channels != 256 && c.skip_out_channels != 512)
-        return "needs skip_out_channels in {128, 256, 512} (one head workgroup per 128 hidden units)";
+    // narrower models run zero-padded to the kernel's 128 / 256 / 128 n geometry (exact: padded channels stay 0 through every layer)
+    if (c.residual_channels > RC || c.gate_channels > GC) return "needs residual_channels <= 128 and gate_channels <= 256";
+    if (c.skip_out_channels > 512) return "needs skip_out_channels <= 512 (one head workgroup per 128 hidden units, at most four)";
     if (!c.scalar_input && c.skip_out_channels > 256) return "one-hot models need skip_out_channels <= 256";
     if (c.scalar_input && c.out_channels > 128) return "needs out_channels <= 128";
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 512 - (c.kernel_size - 1) * RC) return "too many local-conditioning channels";
-    if (c.layers + c.skip_out_channels / 128 > 32) return "too many layers for one ring per XCD";
+    if (c.layers + (c.skip_out_channels + 127) / 128 > 32) return "too many layers for one ring per XCD";
     if (B > 64) return "more than 64 utterances per call";
     return nullptr;
 }
@@ -1286,19 +1302,31 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     WnvRingState* st = new WnvRingState();
     st->device = device;
     const int L = c.layers, kw = c.kernel_size, cin = c.cin_channels > 0 ? c.cin_channels : 0;
-    const int K = c.skip_out_channels, Kp = (K + 3) & ~3, O = c.out_channels;
+    // The kernel's geometry is fixed: 128 residual channels, 128 gate channels (256 gate rows), 128 n skip channels.  A narrower
+    // model is embedded by ZERO PADDING: padded residual / gate / skip channels carry exact zeros through every layer
+    // (z = 0 -> tanh(0) sigmoid(0) = 0; zero rows and biases), so the live channels see the same sums plus exact-zero terms.
+    const int Ra = c.residual_channels, Ga = c.gate_channels, Gha = Ga / 2, Ka = c.skip_out_channels, O = c.out_channels;
+    const int NK = (Ka + RC - 1) / RC;                              // skip passes per stage = head parts per ring
+    const int K = NK * RC, Kp = K;                                  // padded skip width
     st->L = L; st->S = L; st->K = K; st->Kp = Kp; st->O = O; st->cin = cin; st->kw = kw;
     st->kpre = (kw - 1) * RC + cin;
     std::vector<float> blob;
     auto alloc = [&](size_t n) { size_t o = (blob.size() + 3) & ~(size_t)3; blob.resize(o + n, 0.f); return o; };
     auto T = [&](const std::string& n) -> const HostTensor& { return *store.get(n); };
+    // padded gate row o (tanh channels 0..127, then sigmoid channels 0..127) -> the model's gate row, or -1
+    auto gate_row = [&](int o) { const int ch = o & (RC - 1); return ch < Gha ? (o >> 7) * Gha + ch : -1; };
+    // a (rows x cols) row-major matrix zero-padded to (prow x pcol)
+    auto padded = [](const float* M, int rows, int cols, int prow, int pcol) {
+        std::vector<float> P((size_t)prow * pcol, 0.f);
+        for (int r = 0; r < rows; ++r) std::copy(M + (size_t)r * cols, M + (size_t)(r + 1) * cols, P.begin() + (size_t)r * pcol);
+        return P;
+    };
     st->o_w2 = alloc((size_t)L * 16 * RT * 4);
     st->o_wn = alloc((size_t)L * 16 * RT * 4);
     st->o_cvec = alloc((size_t)L * GC);
     st->o_wo = alloc((size_t)L * 8 * RT * 4);
     st->o_bo = alloc((size_t)L * RC);
     st->o_wpre = alloc((size_t)L * st->kpre * GC);
-    const int NK = K / RC;                                          // skip passes per stage = head parts per ring
     st->o_ws = alloc((size_t)L * NK * 8 * RT * 4);
     st->o_bskip = alloc((size_t)L * Kp);
     std::vector<int> dil(L), hoff(L);
@@ -1309,25 +1337,29 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     for (int l = 0; l < L; ++l) {
         const std::string pfx = "conv_layers." + std::to_string(l) + ".";
         const HostTensor& wc = T(pfx + "conv.weight");                 // (G, R, kw)
-        // newest tap (k = kw-1) as a (256 x 128) matrix
-        for (int o = 0; o < GC; ++o)
-            for (int ii = 0; ii < RC; ++ii) cur[(size_t)o * RC + ii] = wc.data[((size_t)o * RC + ii) * kw + (kw - 1)];
+        // newest tap (k = kw-1) as a padded (256 x 128) matrix
+        std::fill(cur.begin(), cur.end(), 0.f);
+        for (int o = 0; o < GC; ++o) {
+            const int go = gate_row(o);
+            if (go < 0) continue;
+            for (int ii = 0; ii < Ra; ++ii) cur[(size_t)o * RC + ii] = wc.data[((size_t)go * Ra + ii) * kw + (kw - 1)];
+        }
         // gate-to-gate chain (see run_stage): M_l = sqrt(.5) W_cur,l W_o,l-1, N_l = sqrt(.5) W_cur,l, c_l = N_l b_o,l-1, folded in
         // double and rounded once; layer 0 reads h_0 itself: M_0 = W_cur,0, no N term
         if (l == 0) {
             mmat = cur;
         } else {
-            const HostTensor& wop = T("conv_layers." + std::to_string(l - 1) + ".conv1x1_out.weight");   // (R, G/2, 1)
-            const HostTensor& bop = T("conv_layers." + std::to_string(l - 1) + ".conv1x1_out.bias");
+            const std::vector<float> wop = padded(T("conv_layers." + std::to_string(l - 1) + ".conv1x1_out.weight").data.data(), Ra, Gha, RC, RC);   // (R, G/2, 1)
+            const std::vector<float> bop = padded(T("conv_layers." + std::to_string(l - 1) + ".conv1x1_out.bias").data.data(), 1, Ra, 1, RC);
             for (int o = 0; o < GC; ++o) {
                 for (int kk = 0; kk < RC; ++kk) {
                     double acc = 0.0;
-                    for (int m = 0; m < RC; ++m) acc += (double)cur[(size_t)o * RC + m] * (double)wop.data[(size_t)m * RC + kk];
+                    for (int m = 0; m < RC; ++m) acc += (double)cur[(size_t)o * RC + m] * (double)wop[(size_t)m * RC + kk];
                     mmat[(size_t)o * RC + kk] = (float)(rs * acc);
                     nmat[(size_t)o * RC + kk] = (float)(rs * (double)cur[(size_t)o * RC + kk]);
                 }
                 double cb = 0.0;
-                for (int m = 0; m < RC; ++m) cb += (double)cur[(size_t)o * RC + m] * (double)bop.data[m];
+                for (int m = 0; m < RC; ++m) cb += (double)cur[(size_t)o * RC + m] * (double)bop[m];
                 blob[st->o_cvec + (size_t)l * GC + o] = (float)(rs * cb);
             }
         }
@@ -1336,25 +1368,27 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
             put_row8(blob, st->o_w2 + ((size_t)l * 4 + row) * rowsz, mmat.data(), (row & 1) ? RC : 0, row >> 1);
             if (l > 0) put_row8(blob, st->o_wn + ((size_t)l * 4 + row) * rowsz, nmat.data(), (row & 1) ? RC : 0, row >> 1);
         }
-        const HostTensor& wo = T(pfx + "conv1x1_out.weight");          // (R, G/2, 1)
-        put_row8(blob, st->o_wo + ((size_t)l * 2 + 0) * rowsz, wo.data.data(), 0, 0);
-        put_row8(blob, st->o_wo + ((size_t)l * 2 + 1) * rowsz, wo.data.data(), 0, 1);
+        const std::vector<float> wo = padded(T(pfx + "conv1x1_out.weight").data.data(), Ra, Gha, RC, RC);          // (R, G/2, 1)
+        put_row8(blob, st->o_wo + ((size_t)l * 2 + 0) * rowsz, wo.data(), 0, 0);
+        put_row8(blob, st->o_wo + ((size_t)l * 2 + 1) * rowsz, wo.data(), 0, 1);
         const HostTensor& bo = T(pfx + "conv1x1_out.bias");
         std::copy(bo.data.begin(), bo.data.end(), blob.begin() + st->o_bo + (size_t)l * RC);
         // deferred: older taps (oldest first) then local conditioning, K-major [kpre][256]
         float* wp = blob.data() + st->o_wpre + (size_t)l * st->kpre * GC;
-        for (int k = 0; k < kw - 1; ++k)
-            for (int ii = 0; ii < RC; ++ii)
-                for (int o = 0; o < GC; ++o) wp[(size_t)(k * RC + ii) * GC + o] = wc.data[((size_t)o * RC + ii) * kw + k];
-        if (cin > 0) {
-            const HostTensor& wcc = T(pfx + "conv1x1c.weight");        // (G, cin, 1)
-            for (int jx = 0; jx < cin; ++jx)
-                for (int o = 0; o < GC; ++o) wp[(size_t)((kw - 1) * RC + jx) * GC + o] = wcc.data[(size_t)o * cin + jx];
+        for (int o = 0; o < GC; ++o) {
+            const int go = gate_row(o);
+            if (go < 0) continue;
+            for (int k = 0; k < kw - 1; ++k)
+                for (int ii = 0; ii < Ra; ++ii) wp[(size_t)(k * RC + ii) * GC + o] = wc.data[((size_t)go * Ra + ii) * kw + k];
+            if (cin > 0) {
+                const HostTensor& wcc = T(pfx + "conv1x1c.weight");        // (G, cin, 1)
+                for (int jx = 0; jx < cin; ++jx) wp[(size_t)((kw - 1) * RC + jx) * GC + o] = wcc.data[(size_t)go * cin + jx];
+            }
         }
-        const HostTensor& ws = T(pfx + "conv1x1_skip.weight");         // (K, G/2, 1): pass pp = skip channels [128 pp, 128 pp + 128)
+        const std::vector<float> ws = padded(T(pfx + "conv1x1_skip.weight").data.data(), Ka, Gha, K, RC);   // (K, G/2, 1): pass pp = skip channels [128 pp, 128 pp + 128)
         for (int pp = 0; pp < NK; ++pp) {
-            put_row8(blob, st->o_ws + (((size_t)l * NK + pp) * 2 + 0) * rowsz, ws.data.data(), RC * pp, 0);
-            put_row8(blob, st->o_ws + (((size_t)l * NK + pp) * 2 + 1) * rowsz, ws.data.data(), RC * pp, 1);
+            put_row8(blob, st->o_ws + (((size_t)l * NK + pp) * 2 + 0) * rowsz, ws.data(), RC * pp, 0);
+            put_row8(blob, st->o_ws + (((size_t)l * NK + pp) * 2 + 1) * rowsz, ws.data(), RC * pp, 1);
         }
         const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
         std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bskip + (size_t)l * Kp);
@@ -1367,26 +1401,28 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     // [128 j, 128 j + 128) of the K x K matrix as NK column-block images and columns [128 j, 128 j + 128) of the O x K matrix
     // as two row images (rows i, and rows 128 + i for one-hot models), zero-padded
     const size_t imgsz = (size_t)8 * RT * 4;
+    const std::vector<float> w1p = padded(T("last_conv_layers.1.weight").data.data(), Ka, Ka, K, K);
+    const std::vector<float> w2p = padded(T("last_conv_layers.3.weight").data.data(), O, Ka, O, K);
     st->o_wh1 = alloc((size_t)NK * NK * imgsz);
     for (int part = 0; part < NK; ++part)
         for (int blk = 0; blk < NK; ++blk)
-            put_image(blob, st->o_wh1 + ((size_t)part * NK + blk) * imgsz, T("last_conv_layers.1.weight").data.data(), K, RC * part, K, RC * blk);
+            put_image(blob, st->o_wh1 + ((size_t)part * NK + blk) * imgsz, w1p.data(), K, RC * part, K, RC * blk);
     st->o_bh1 = alloc(K);
     std::copy(T("last_conv_layers.1.bias").data.begin(), T("last_conv_layers.1.bias").data.end(), blob.begin() + st->o_bh1);
     st->o_wh2 = alloc((size_t)NK * 2 * imgsz);
     for (int part = 0; part < NK; ++part) {
-        put_image(blob, st->o_wh2 + ((size_t)part * 2 + 0) * imgsz, T("last_conv_layers.3.weight").data.data(), K, 0, O, RC * part);
-        put_image(blob, st->o_wh2 + ((size_t)part * 2 + 1) * imgsz, T("last_conv_layers.3.weight").data.data(), K, RC, O, RC * part);
+        put_image(blob, st->o_wh2 + ((size_t)part * 2 + 0) * imgsz, w2p.data(), K, 0, O, RC * part);
+        put_image(blob, st->o_wh2 + ((size_t)part * 2 + 1) * imgsz, w2p.data(), K, RC, O, RC * part);
     }
     st->o_bh2 = alloc(2 * RC);
     std::copy(T("last_conv_layers.3.bias").data.begin(), T("last_conv_layers.3.bias").data.end(), blob.begin() + st->o_bh2);
-    // first_conv: (R, 1, 1) for scalar input; one-hot models: (R, cin1, 1) stored K-major [cin1][R] (row k = column k)
+    // first_conv: (R, 1, 1) for scalar input; one-hot models: (R, cin1, 1) stored K-major [cin1][128] (row k = column k)
     const int cin1 = c.scalar_input ? 1 : O;
     st->cin1 = cin1;
     st->o_wf = alloc((size_t)cin1 * RC);
     {
         const HostTensor& wf = T("first_conv.weight");
-        for (int r = 0; r < RC; ++r)
+        for (int r = 0; r < Ra; ++r)
             for (int k = 0; k < cin1; ++k) blob[st->o_wf + (size_t)k * RC + r] = wf.data[(size_t)r * cin1 + k];
     }
     st->o_bf = alloc(RC);
@@ -1500,6 +1536,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.wsimg = w + st->o_ws; p.bskip = w + st->o_bskip; p.wh1img = w + st->o_wh1; p.bh1 = w + st->o_bh1;
     p.wh2img = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf;
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride;
+    p.zb_ld = (c.gate_channels + 3) & ~3; p.gh = c.gate_channels / 2;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
     // state: [status 64 B][placement table 4 KiB][xmail B*(S+1)*128 u64][hmail B*2*(S+1)*128 u64][smail B*(S+1)*Kp u64][omail B*NK*256 u64]
     //        [hist B*hist_floats f32]
@@ -1578,7 +1615,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const int trace_n = 8;
     size_t trace_words = 0;
     if (trace_path && *trace_path && p.T > 64) {
-        trace_words = (size_t)trace_n * (st->S + 1) * 8;
+        trace_words = (size_t)trace_n * (st->S + 1) * TRW;
         RING_HIP(hipMalloc((void**)&d_trace, trace_words * sizeof(unsigned long long)));
         RING_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
@@ -1603,12 +1640,12 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         (void)hipFree(d_trace);
         if (FILE* f = fopen(trace_path, "w")) {
             fprintf(f, "# step pos(S=head) stamps[0..4] in ns relative to the head's send of the first traced step (100 MHz wall clock)\n");
-            const unsigned long long t00 = tr[((size_t)0 * (st->S + 1) + st->S) * 8 + 0];
+            const unsigned long long t00 = tr[((size_t)0 * (st->S + 1) + st->S) * TRW + 0];
             for (int tt = 0; tt < trace_n; ++tt)
                 for (int pos = 0; pos <= st->S; ++pos) {
                     fprintf(f, "%d %d", p.trace_t0 + tt, pos);
-                    for (int k = 0; k < 8; ++k) {
-                        const unsigned long long v = tr[((size_t)tt * (st->S + 1) + pos) * 8 + k];
+                    for (int k = 0; k < TRW; ++k) {
+                        const unsigned long long v = tr[((size_t)tt * (st->S + 1) + pos) * TRW + k];
                         fprintf(f, " %lld", v ? (long long)(v - t00) * 10 : -1LL);
                     }
                     fprintf(f, "\n");
