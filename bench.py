@@ -78,10 +78,22 @@ def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0):
         steps[threads] = o.last_steps
     o.cfg.upsample_conditional_features = saved
     best = max(results, key=results.get)
+    # the oracle is a little FASTER than the reference it restates (no module dispatch, no tqdm); the ratio was measured where both
+    # run (scripts/cpu_ref_vs_oracle.py in the authoring container -> profiles/cpu_ref_ratio.json)
+    ratio, est = None, None
+    try:
+        rj = json.load(open(os.path.join(ROOT, "profiles", "cpu_ref_ratio.json")))["by_threads"]
+        ratio = {k: round(v["oracle_over_reference"], 3) for k, v in rj.items()}
+        r_best = ratio.get(str(best), max(ratio.values()))
+        est = round(results[best] / r_best, 4)
+    except Exception:
+        pass
     return {"value": round(results[best], 4), "unit": "kSamples/s", "cores": best, "kind": "port",
             "sample": f"oracle/wavenet_oracle.py (torch-CPU restatement of the reference op sequence incl. its per-step "
                       f"queue shift), same weights/mel, B={B}, up to T={T_cpu} steps or {budget_s:.0f} s per thread setting "
-                      f"(steps done: {steps}); host has {ncores} cores",
+                      f"(steps done: {steps}); host has {ncores} cores; the oracle runs {ratio} x the real reference's speed by thread "
+                      f"count (profiles/r02_cpu_reference_vs_oracle.txt), so the reference itself would measure ~{est} kSamples/s here",
+            "oracle_over_reference_speed": ratio, "reference_estimate_kSamples_s": est,
             "all_threads_kSamples_s": {str(k): round(v, 4) for k, v in results.items()}}
 
 
