@@ -243,52 +243,66 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
         for (int half = 0; half < 2; ++half) {                          // two tiles at a time: 32 loads in flight, 32 registers
             float prev[2][16];
             if (interior) {
+                // Addresses as  WAVE-UNIFORM row pointer (scalar registers) + ONE 32-bit per-lane offset: row v of the accumulator is
+                // time step t0 + m0 + 8 (v / 4) + v % 4 (+ 4 for the upper half-wave), column gc; a 32-column tile lies entirely in
+                // the residual block or entirely in the skip block.  (Per-element 64-bit addresses cost 64 VGPRs here and pushed the
+                // kernel into 87 spilled registers.)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int gc = c0 + 128 * cb + 32 * (2 * half + j) + (lane & 31);
-                    const float* src = gc < HC ? Hin + gc : a.Skip + (size_t)b * a.T * a.K + (gc - HC);
-                    const long long ld = gc < HC ? HC : a.K;
+                    const int col0 = __builtin_amdgcn_readfirstlane(c0 + 128 * cb + 32 * (2 * half + j));      // first column of the tile
+                    const bool res = col0 < HC;
+                    const int ld = res ? HC : a.K;
+                    const float* base = (res ? Hin + col0 : a.Skip + (size_t)b * a.T * a.K + (col0 - HC)) + (size_t)(t0 + m0) * ld;
+                    const int loff = 4 * (lane >> 5) * ld + (lane & 31);
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) prev[j][v] = src[(size_t)(t0 + m0 + acc_row(v, lane)) * ld];
+                    for (int v = 0; v < 16; ++v) prev[j][v] = (base + (size_t)(8 * (v >> 2) + (v & 3)) * ld)[loff];
                 }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int i = 2 * half + j;
-                    const int gc = c0 + 128 * cb + 32 * i + (lane & 31);
-                    const float bias = a.b_os[gc];
-                    float* dst = gc < HC ? a.Hout + (size_t)b * a.T * HC + gc : a.Skip + (size_t)b * a.T * a.K + (gc - HC);
-                    const long long ld = gc < HC ? HC : a.K;
-                    const float scale = gc < HC ? 0.70710678118654752440f : 1.0f;     // (out + residual) * sqrt(0.5) | skips += s
+                    const int col0 = __builtin_amdgcn_readfirstlane(c0 + 128 * cb + 32 * i);
+                    const bool res = col0 < HC;
+                    const int ld = res ? HC : a.K;
+                    const float bias = a.b_os[col0 + (lane & 31)];
+                    float* base = (res ? a.Hout + (size_t)b * a.T * HC + col0 : a.Skip + (size_t)b * a.T * a.K + (col0 - HC)) + (size_t)(t0 + m0) * ld;
+                    const int loff = 4 * (lane >> 5) * ld + (lane & 31);
+                    const float scale = res ? 0.70710678118654752440f : 1.0f;        // (out + residual) * sqrt(0.5) | skips += s
 #pragma unroll
-                    for (int v = 0; v < 16; ++v) dst[(size_t)(t0 + m0 + acc_row(v, lane)) * ld] = (prev[j][v] + (acc[i][v] + bias)) * scale;
+                    for (int v = 0; v < 16; ++v) (base + (size_t)(8 * (v >> 2) + (v & 3)) * ld)[loff] = (prev[j][v] + (acc[i][v] + bias)) * scale;
                 }
                 continue;
             }
+            // edge tiles (the last time tile of an utterance, a partial column block): the same addressing with per-element
+            // predicates; rows are 32-bit offsets from wave-uniform bases, so nothing 64-bit is kept per element
+            const int rows_left = (int)min((long long)TM, a.T - t0) - m0;         // valid rows of this wave's 32-row block (may be <= 0)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int gc = c0 + 128 * cb + 32 * (2 * half + j) + (lane & 31);
+                const int col0 = __builtin_amdgcn_readfirstlane(c0 + 128 * cb + 32 * (2 * half + j));
+                const bool res = col0 < HC;
+                const int ld = res ? HC : a.K;
+                const float* base = (res ? Hin : a.Skip + (size_t)b * a.T * a.K - HC) + (size_t)(t0 + m0) * ld;
+                const int gc = col0 + (lane & 31);
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const long long t = t0 + m0 + acc_row(v, lane);
-                    prev[j][v] = 0.f;
-                    if (gc < ntot && t < a.T)
-                        prev[j][v] = gc < HC ? Hin[(size_t)t * HC + gc] : a.Skip[((size_t)b * a.T + t) * a.K + (gc - HC)];
+                    const int row = acc_row(v, lane);
+                    prev[j][v] = (gc < ntot && row < rows_left) ? base[row * ld + gc] : 0.f;
                 }
             }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int i = 2 * half + j;
-                const int gc = c0 + 128 * cb + 32 * i + (lane & 31);
+                const int col0 = __builtin_amdgcn_readfirstlane(c0 + 128 * cb + 32 * i);
+                const bool res = col0 < HC;
+                const int ld = res ? HC : a.K;
+                const int gc = col0 + (lane & 31);
                 if (gc >= ntot) continue;
                 const float bias = a.b_os[gc];
+                float* base = (res ? a.Hout + (size_t)b * a.T * HC : a.Skip + (size_t)b * a.T * a.K - HC) + (size_t)(t0 + m0) * ld;
+                const float scale = res ? 0.70710678118654752440f : 1.0f;            // modules.py:157-162 | wavenet.py:196-198
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
-                    const long long t = t0 + m0 + acc_row(v, lane);
-                    if (t >= a.T) continue;
-                    if (gc < HC)                                         // (out + residual) * sqrt(0.5), modules.py:157-162
-                        a.Hout[((size_t)b * a.T + t) * HC + gc] = (prev[j][v] + (acc[i][v] + bias)) * 0.70710678118654752440f;
-                    else                                                 // skips += s, wavenet.py:196-198
-                        a.Skip[((size_t)b * a.T + t) * a.K + (gc - HC)] = prev[j][v] + (acc[i][v] + bias);
+                    const int row = acc_row(v, lane);
+                    if (row < rows_left) base[row * ld + gc] = (prev[j][v] + (acc[i][v] + bias)) * scale;
                 }
             }
         }
