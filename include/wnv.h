@@ -147,7 +147,8 @@ typedef struct wnv_generate_args {
     float* out;                /* device (B, C, T): C = 1 scalar samples | out_channels one-hot/probs    */
     float* params_out;         /* optional device (B, out_channels, T): head output before sampling      */
     int32_t* index_out;        /* optional device (B, T): sampled class (categorical + quantize)         */
-    int32_t kernel;            /* 0 = auto, 1 = generic single-workgroup kernel, 2 = pipelined ring      */
+    int32_t kernel;            /* 0 = auto, 1 = generic single-workgroup kernel, 2 = pipelined ring,     */
+                               /* 3 = group ring for wide models (8 workgroups per layer)                */
     int32_t flags;             /* WNV_GEN_* bits                                                         */
     void* stream;
 } wnv_generate_args;
@@ -168,7 +169,7 @@ typedef struct wnv_generate_args {
 wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* args);
 /* Waits for the handle's last WNV_GEN_ASYNC launch and returns its status (WNV_OK when nothing is pending).  Synchronous. */
 wnv_status wnv_wait(wnv_handle h);
-/* Which kernel served the last wnv_generate of this handle: 1 generic, 2 ring, 0 none yet. */
+/* Which kernel served the last wnv_generate of this handle: 1 generic, 2 ring, 3 group ring (wide models), 0 none yet. */
 int32_t wnv_last_kernel(wnv_handle h);
 
 /* WaveNet.clear_buffer (wavenet.py:345-353): the engine re-zeroes its history at the start of every

@@ -29,6 +29,11 @@ CONFIGS = {
                                   skip_out_channels=512, kernel_size=3, dropout=0.0, scalar_input=True,
                                   output_distribution="Logistic", gin_channels=16, n_speakers=7,
                                   use_speaker_embedding=True, **MEL),
+    # the geometry of the reference's published CMU-ARCTIC models (docs/content/index.md:390-402: 24 layers, 512 / 512 / 256) with the
+    # scalar MoL output of egs/mol -- what the group-ring kernel for wide models (csrc/wnv_wide.hip) is for
+    "wide_mol_512": dict(out_channels=30, layers=24, stacks=4, residual_channels=512, gate_channels=512,
+                         skip_out_channels=256, kernel_size=3, dropout=0.0, scalar_input=True,
+                         output_distribution="Logistic", **MEL),
 }
 
 

@@ -1,0 +1,102 @@
+"""-m gpu: the group-ring kernel for WIDE models (csrc/wnv_wide.hip, kernel = 3): eight workgroups per layer, weights resident,
+two all-gather hops per layer -- against the CPU oracle, against the generic kernel on the same inputs, and through
+size-independent properties at the published 24-layer 512 / 512 / 256 geometry."""
+import time
+
+import pytest
+import torch
+
+import wavenet_vocoder_amd as wnv
+from oracle.wavenet_oracle import Oracle
+from tests._configs import CONFIGS, build, inputs, tame_head_
+from tests._golden import oracle_config
+from tests._margins import assert_free_run_agrees_until_near_tie, assert_match_or_near_tie
+from wavenet_vocoder_amd.noise import make_noise_tape
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CASES = {
+    # name: (kwargs, B, Tt, T)
+    "mol_512_512_256_mel": (dict(out_channels=30, layers=6, stacks=2, residual_channels=512, gate_channels=512, skip_out_channels=256,
+                                 kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=80), 2, 96, 160),
+    "gauss_256_384_192_k2_global": (dict(out_channels=2, layers=4, stacks=2, residual_channels=256, gate_channels=384, skip_out_channels=192,
+                                         kernel_size=2, dropout=0.0, scalar_input=True, output_distribution="Normal", gin_channels=8,
+                                         n_speakers=3, use_speaker_embedding=True), 3, 64, 128),
+    "mol_320_512_256_nine_layers": (dict(out_channels=30, layers=9, stacks=3, residual_channels=320, gate_channels=512, skip_out_channels=256,
+                                         kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=20), 8, 48, 96),
+}
+
+
+def tape_for(kw, T, B, seed):
+    return make_noise_tape(T, B, scalar_input=True, output_distribution=kw.get("output_distribution", "Logistic"),
+                           out_channels=kw["out_channels"], generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_wide_vs_oracle_and_generic(name):
+    kw, B, Tt, T = CASES[name]
+    torch.manual_seed(23)
+    m = tame_head_(wnv.WaveNet(**kw).eval())
+    o = Oracle(oracle_config(kw), m.state_dict())
+    g = torch.Generator().manual_seed(2)
+    cin, gin = kw.get("cin_channels", -1), kw.get("gin_channels", -1)
+    c = torch.randn(B, cin, T, generator=g) if cin > 0 else None
+    gids = torch.randint(0, kw["n_speakers"], (B, 1), generator=g) if gin > 0 else None
+    x = torch.tanh(torch.randn(B, 1, Tt, generator=g) * 0.5)
+    tape = tape_for(kw, T, B, 6)
+    torch.set_num_threads(8)
+    want, wparams = o.incremental_forward(test_inputs=x, c=c, g=gids, T=T, noise=tape, return_params=True)
+    eng = m.to("cuda")._get_engine()
+    args = dict(B=B, T=T, c_up=None if c is None else c.transpose(1, 2).contiguous().cuda(), g_ids=None if gids is None else gids[:, 0].cuda(),
+                teacher=x.transpose(1, 2).contiguous().cuda(), noise=tape.cuda(), want_params=True)
+    out, params, _ = eng.generate(kernel=3, **args)
+    assert eng.last_kernel() == 3
+    gen_out, gen_params, _ = eng.generate(kernel=1, **args)
+    out, params = out.cpu(), params.cpu()
+    err = float((params[:, :, :Tt] - wparams[:, :, :Tt]).abs().max())
+    print(f"{name}: forced head outputs vs oracle {err:.2e}, vs generic kernel {float((params[:, :, :Tt] - gen_params.cpu()[:, :, :Tt]).abs().max()):.2e}")
+    assert err < TOL
+    assert float((params[:, :, :Tt] - gen_params.cpu()[:, :, :Tt]).abs().max()) < 5e-5
+    assert_match_or_near_tie(out[:, :, :Tt - 1], want[:, :, :Tt - 1], wparams[:, :, :Tt - 1], tape[:Tt - 1], kw, tol=TOL)
+    assert_free_run_agrees_until_near_tie(out, want, params, wparams, tape, kw, t0=Tt - 1, what=name)
+    again, _, _ = eng.generate(kernel=3, **args)
+    assert torch.equal(again.cpu(), out), "determinism"
+    auto, _, _ = eng.generate(kernel=0, **args)
+    assert eng.last_kernel() == 3 and torch.equal(auto.cpu(), out), "auto picks the group ring for a wide model"
+
+
+def test_wide_published_geometry_properties_and_speed():
+    """24 layers, 512 / 512 / 256, 80-mel conditioned MoL (the published CMU-ARCTIC geometry): properties at a length the oracle cannot
+    reach, and the reason this kernel exists -- one utterance faster than real time."""
+    name = "wide_mol_512"
+    kw = CONFIGS[name]
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    B, T = 2, 2048
+    c, _ = inputs(name, B, T)
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    tape = tape_for(kw, T, B, 9).cuda()
+    full, _, _ = eng.generate(B=B, T=T, c_up=c_up, noise=tape, kernel=3)
+    T2 = 512
+    pre, _, _ = eng.generate(B=B, T=T2, c_up=c_up[:, :T2].contiguous(), noise=tape[:T2].contiguous(), kernel=3)
+    assert torch.equal(pre, full[:, :, :T2]), "prefix property"
+    solo, _, _ = eng.generate(B=1, T=T2, c_up=c_up[1:2, :T2].contiguous(), noise=tape[:T2, 1:2].contiguous(), kernel=3)
+    assert torch.equal(solo[0], full[1, :, :T2]), "batch members must be independent"
+    assert torch.isfinite(full).all() and float(full.abs().max()) <= 1.0 and float(full.std()) > 1e-3
+    gen, _, _ = eng.generate(B=B, T=128, c_up=c_up[:, :128].contiguous(), noise=tape[:128].contiguous(), kernel=1)
+    assert float((gen - full[:, :, :128]).abs().max()) < 1e-3                       # the generic kernel's trajectory over a short horizon
+    for Bs in (1, 8):
+        cs, _ = inputs(name, Bs, 4096)
+        cu = eng.upsample(cs.cuda(), T_expected=4096)
+        eng.generate(B=Bs, T=4096, c_up=cu, seed=1, kernel=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.generate(B=Bs, T=4096, c_up=cu, seed=2, kernel=3)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        per_utt = 4096 / dt
+        print(f"wide_mol_512, B = {Bs}: {Bs * per_utt / 1e3:.1f} kSamples/s, {per_utt / 1e3:.1f} kSamples/s per utterance = "
+              f"{per_utt / 16000:.2f}x real time at 16 kHz, {per_utt / 22050:.2f}x at 22.05 kHz, {per_utt / 24000:.2f}x at 24 kHz")
+        if Bs == 1:
+            assert per_utt > 16000, "a single utterance of the published (16 kHz) geometry must run faster than real time"

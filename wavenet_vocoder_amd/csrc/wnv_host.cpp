@@ -16,6 +16,7 @@
 #include "wnv_internal.h"
 #include "wnv_store.h"
 #include "wnv_ring.h"
+#include "wnv_wide.h"
 #include "wnv_forward.h"
 
 #include "wnv_hostutil.h"
@@ -39,6 +40,8 @@ struct wnv_engine {
     int64_t core_macs = 0;
     Scratch ring, zbias, upA, upB, fwd;
     WnvRingState* ring_state = nullptr;   // pipelined kernel (wnv_ring.hip), built lazily
+    WnvWideState* wide_state = nullptr;   // group-ring kernel for wide models (wnv_wide.hip), built lazily
+    bool wide_disabled = false;
     bool ring_disabled = false;           // auto mode: a ring launch timed out on this device (workgroups not co-resident)
     int last_kernel = 0;                  // 1 generic, 2 ring: what served the last wnv_generate
 };
@@ -177,6 +180,7 @@ static void free_dev(wnv_engine* h) {
     if (h->d_up) (void)hipFree(h->d_up);
     h->d_W = nullptr; h->d_layers = nullptr; h->d_up = nullptr;
     if (h->ring_state) { wnv_ring_destroy(h->ring_state); h->ring_state = nullptr; }
+    if (h->wide_state) { wnv_wide_destroy(h->wide_state); h->wide_state = nullptr; }
     h->packed = false;
 }
 
@@ -469,7 +473,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     if (m.gin == 0 && (a->g || a->g_ids)) return fail(WNV_ERR_INVALID_ARG, "g given but the model has no global conditioning");
     if (a->g_ids && !a->g && h->embed_off < 0) return fail(WNV_ERR_INVALID_ARG, "g_ids given but the model has no speaker embedding");
     if (a->Tt < 0 || a->Tt > a->T || (a->Tt > 0 && !a->teacher)) return fail(WNV_ERR_INVALID_ARG, "bad teacher-forcing arguments");
-    if (a->kernel < 0 || a->kernel > 2) return fail(WNV_ERR_INVALID_ARG, "unknown kernel selector %d", a->kernel);
+    if (a->kernel < 0 || a->kernel > 3) return fail(WNV_ERR_INVALID_ARG, "unknown kernel selector %d", a->kernel);
     DeviceGuard g(h->device);
     hipStream_t s = (hipStream_t)a->stream;
     const bool has_g = m.gin > 0;
@@ -498,7 +502,22 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         if (pst != WNV_OK) return fail(pst, "deferred from the previous asynchronous call: %s", err.c_str());
     }
     int kernel = a->kernel;
-    if (kernel == 0) kernel = (!h->ring_disabled && wnv_ring_supported(c, a->B) && wnv_ring_default()) ? 2 : 1;
+    if (kernel == 0) {
+        if (!h->ring_disabled && wnv_ring_supported(c, a->B) && wnv_ring_default()) kernel = 2;
+        else if (!h->wide_disabled && !wnv_ring_supported(c, a->B) && wnv_wide_supported(c, a->B) && wnv_ring_default()) kernel = 3;
+        else kernel = 1;
+    }
+    if (kernel == 3) {                     // wide models: one GROUP of 8 workgroups per layer (wnv_wide.hip); same fallback rules as the ring
+        if (!wnv_wide_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the group-ring kernel does not cover this configuration: %s", wnv_wide_why_not(c, a->B));
+        std::string err;
+        wnv_status st = wnv_wide_generate(&h->wide_state, h->device, c, h->store, ga, s, err);
+        if (st == WNV_OK) { h->last_kernel = 3; return WNV_OK; }
+        const bool recoverable = st == WNV_ERR_UNSUPPORTED || st == WNV_ERR_TIMEOUT;
+        if (!(a->kernel == 0 && recoverable)) return fail(st, "%s", err.c_str());
+        h->wide_disabled = true;
+        fprintf(stderr, "[wnv] device %d: the group-ring kernel %s (%s); this handle now uses the generic kernel\n", h->device,
+                st == WNV_ERR_TIMEOUT ? "timed out" : "cannot run here", err.c_str());
+    }
     if (kernel == 2) {
         if (!wnv_ring_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the pipelined ring kernel does not cover this configuration: %s", wnv_ring_why_not(c, a->B));
         HIP_TRY(zero_onehot_out());

@@ -10,6 +10,10 @@
 
 struct WnvRingState;
 
+// Placement census of a device (one tiny launch): CU count, number of XCDs, and whether block b of a one-block-per-CU grid ran on
+// the same XCD as block b % n_xcd for every b (the mapping the persistent kernels lay their workgroups out by).
+wnv_status wnv_placement_census(int device, int* ncu, int* n_xcd, bool* map_ok, std::string& err);
+
 // Can the ring kernel run this configuration with B utterances in flight?
 bool wnv_ring_supported(const wnv_config& c, int B);
 const char* wnv_ring_why_not(const wnv_config& c, int B);

@@ -1297,6 +1297,30 @@ static void put_row8(std::vector<float>& blob, size_t off, const float* M, int r
     }
 }
 
+wnv_status wnv_placement_census(int device, int* ncu_out, int* n_xcd_out, bool* map_ok_out, std::string& err) {
+    int ncu = 0;
+    RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
+    const int n = std::max(ncu, 1);
+    unsigned int* d_x = nullptr;
+    RING_HIP(hipMalloc((void**)&d_x, n * sizeof(unsigned int)));
+    RING_HIP(hipMemset(d_x, 0, n * sizeof(unsigned int)));
+    hipLaunchKernelGGL(wnv_ring_census_kernel, dim3(n), dim3(64), 0, 0, d_x);
+    RING_HIP(hipGetLastError());
+    std::vector<unsigned int> x(n);
+    RING_HIP(hipMemcpy(x.data(), d_x, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    (void)hipFree(d_x);
+    unsigned seen = 0;
+    for (int b = 0; b < n; ++b) seen |= 1u << (x[b] & 31u);
+    const int n_xcd = __builtin_popcount(seen & ~1u);
+    bool map_ok = n_xcd >= 1;
+    for (int b = 0; b < n && map_ok; ++b) map_ok = x[b] != 0u && x[b] == x[b % n_xcd];
+    if (const char* e = getenv("WNV_RING_CENSUS"); e && e[0] == '1')
+        fprintf(stderr, "[wnv] device %d: %d CUs, %d XCDs, block -> XCD (b %% %d) mapping %s\n", device, ncu, n_xcd, n_xcd,
+                map_ok ? "verified" : "NOT as assumed");
+    *ncu_out = ncu; *n_xcd_out = n_xcd; *map_ok_out = map_ok;
+    return WNV_OK;
+}
+
 static wnv_status build_state(WnvRingState** out, int device, const wnv_config& c, const TensorStore& store,
                               std::string& err) {
     WnvRingState* st = new WnvRingState();
@@ -1436,27 +1460,7 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     RING_HIP(hipMemcpy(st->d_histoff, hoff.data(), L * sizeof(int), hipMemcpyHostToDevice));
     RING_HIP(hipHostMalloc((void**)&st->h_status, 64, hipHostMallocDefault));
     *st->h_status = 0;
-    // placement census: how many XCDs, and does block b land on XCD b % n_xcd?
-    RING_HIP(hipDeviceGetAttribute(&st->ncu, hipDeviceAttributeMultiprocessorCount, device));
-    {
-        const int n = std::max(st->ncu, 1);
-        unsigned int* d_x = nullptr;
-        RING_HIP(hipMalloc((void**)&d_x, n * sizeof(unsigned int)));
-        RING_HIP(hipMemset(d_x, 0, n * sizeof(unsigned int)));
-        hipLaunchKernelGGL(wnv_ring_census_kernel, dim3(n), dim3(64), 0, 0, d_x);
-        RING_HIP(hipGetLastError());
-        std::vector<unsigned int> x(n);
-        RING_HIP(hipMemcpy(x.data(), d_x, n * sizeof(unsigned int), hipMemcpyDeviceToHost));
-        (void)hipFree(d_x);
-        unsigned seen = 0;
-        for (int b = 0; b < n; ++b) seen |= 1u << (x[b] & 31u);
-        st->n_xcd = __builtin_popcount(seen & ~1u);
-        st->map_ok = st->n_xcd >= 1;
-        for (int b = 0; b < n && st->map_ok; ++b) st->map_ok = x[b] != 0u && x[b] == x[b % st->n_xcd];
-        if (const char* e = getenv("WNV_RING_CENSUS"); e && e[0] == '1')
-            fprintf(stderr, "[wnv] device %d: %d CUs, %d XCDs, block -> XCD (b %% %d) mapping %s\n", device, st->ncu, st->n_xcd, st->n_xcd,
-                    st->map_ok ? "verified" : "NOT as assumed");
-    }
+    { const wnv_status cs = wnv_placement_census(device, &st->ncu, &st->n_xcd, &st->map_ok, err); if (cs != WNV_OK) return cs; }
     return WNV_OK;
 }
 

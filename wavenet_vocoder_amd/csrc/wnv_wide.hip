@@ -1,0 +1,652 @@
+// wnv_wide.hip -- the sample loop for WIDE models (residual_channels <= 512, gate_channels <= 512, skip_out_channels <= 256):
+// the reference's own default constructor geometry (wavenet.py:98-101) and its published 512 / 512 / 256 models, for which one
+// layer (4.1 MB of weights) is eight times what one CU can hold, so the one-layer-per-CU ring kernel (wnv_ring.hip) does not
+// apply and the generic kernel has to stream 99 MB of weights per sample.
+//
+// GROUP RING.  Every layer gets a GROUP of 8 workgroups on one XCD, one per CU, each owning a slice of the layer's OUTPUT
+// channels with its slice of the weights resident in registers:
+//
+//     head -> group 0 -> group 1 -> ... -> group L-1 -> head        (3-4 groups per XCD, consecutive layers share an XCD)
+//
+//   CU j of group l per step (modules.py:127-163, evaluated exactly in the reference's order -- no folding):
+//     gather h_l[t]             512 values published by the 8 CUs of group l-1 (by the head for l = 0)
+//     z   = W_cur[rows_j] h_l + pre_j      64 gate rows (32 tanh + the 32 sigmoid rows of the same channels), K = 512
+//     u_j = tanh . sigmoid                 -> publish 32 values of u_l
+//     gather u_l                256 values published by the 8 CUs of this very group
+//     h_{l+1}[64 j ..] = sqrt(.5) (W_out[rows_j] u_l + b + h_l[64 j ..])          -> publish (the chain goes on)
+//     skip_j += W_skip[rows_j] u_l + b     32 skip channels, handed from CU j of group l to CU j of group l+1; the head gathers
+//     history: every CU keeps its OWN copy of the layer's input history (no cross-CU ordering needed); the older taps and the
+//     local-conditioning 1x1 of the NEXT step -- pre_j[t+1], 282 KB of weights per CU -- stream from L2 / Infinity Cache behind
+//     the chain, once per step for all utterances
+//   two hops (all-gathers of 8 producers) and two mat-vec phases per layer.  Hand-off = the ring kernel's data-tagged 8-byte
+//   granules; plain stores inside an XCD (the host's placement census verified that blocks b and b % 8 share an XCD), write-through
+//   stores across XCDs.  Mat-vec mapping: lane = output row, the 8 waves split K, partial sums meet in LDS.
+//
+// Models narrower than 512 / 512 / 256 are zero-padded (exact).  Scalar-input models (MoL / Gaussian, out_channels <= 64);
+// utterances beyond the first share the groups like a systolic array (B <= 8).  Every wait is bounded (WNV_ERR_TIMEOUT).
+#include "wnv_wide.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "wnv_sample.h"
+
+namespace {
+
+constexpr int WT = 512;            // threads per workgroup
+constexpr int RWD = 512;           // padded residual channels
+constexpr int GHD = 256;           // padded gate channels (gate rows = 2 GHD)
+constexpr int KWD = 256;           // padded skip channels
+constexpr int PG = 8;              // workgroups per layer group
+constexpr int GS = GHD / PG;       // 32 gate channels per workgroup (64 gate rows = one per lane)
+constexpr int RS = RWD / PG;       // 64 residual rows per workgroup
+constexpr int KS = KWD / PG;       // 32 skip rows per workgroup
+constexpr int BMAX = 8;
+constexpr unsigned SPIN_LIMIT = 1u << 22;
+
+using u64 = unsigned long long;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+
+struct WideParams {
+    int L, nL, B, T, Tt, O, cin, cinp, kw, nz, dist, kpre, nkb;
+    int head_x, head_li, fast;
+    unsigned tag_base;
+    float skip_scale;
+    const float *wz, *wo, *ws, *bo, *bs, *wpre;           // per (layer, slice) register / stream images
+    const float *wh1, *bh1, *wh2, *bh2, *wfirst, *bfirst;
+    const float* zbias;                                   // generic pack: [B or 1][L][zb_ld], rows = the model's gate rows
+    long long zbias_bstride;
+    int zb_ld, gh_model;
+    const int *lay_dil, *lay_histoff;                     // dilation; float offset of the layer's history inside one copy set
+    long long hist_b_floats;                              // floats of history per utterance (all layers, all 8 copies)
+    u64 *hmail, *umail, *smail;                           // H[b][L+1][512], U[b][L][256], SK[b][L+1][256]
+    float* hist;
+    const float *c_up, *initial, *teacher, *noise;
+    u64 seed;
+    float *out, *params_out;
+    unsigned int* status;
+};
+
+__device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v, bool fast) {
+    const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
+    if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(x) : "memory");
+    else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+}
+// one wave receives 128 consecutive granules (two per lane, one 16-byte L1-bypassing load) into dst[0 .. 128)
+__device__ __forceinline__ bool recv128(const u64* g, unsigned tag, float* dst, unsigned int* status, unsigned code, int lane) {
+    const u64* g2 = g + 2 * lane;
+    for (unsigned spins = 0;;) {
+        u4v x;
+        asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(g2) : "memory");
+        if (__all(x.y == tag && x.w == tag)) {
+            *reinterpret_cast<float2*>(dst + 2 * lane) = make_float2(__uint_as_float(x.x), __uint_as_float(x.z));
+            return true;
+        }
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+    }
+}
+// the first `n` lanes of a wave each wait for one granule
+__device__ __forceinline__ bool recv_lanes(const u64* g, int n, unsigned tag, float& v, unsigned int* status, unsigned code, int lane) {
+    for (unsigned spins = 0;;) {
+        bool ok = true;
+        if (lane < n) {
+            const u64 x = __hip_atomic_load(g + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = __uint_as_float((unsigned)x);
+            ok = (unsigned)(x >> 32) == tag;
+        }
+        if (__all(ok)) return true;
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+    }
+}
+__device__ __forceinline__ float wide_gate(float a, float g) {                 // tanh(a) sigmoid(g), hardware exp2 / rcp (as wnv_ring.hip)
+    const float e = __builtin_amdgcn_exp2f(fabsf(a) * -2.8853900817779268f);
+    const float f = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
+    const float r = __builtin_amdgcn_rcpf((1.0f + e) * (1.0f + f));
+    return copysignf((1.0f - e) * r, a);
+}
+// dot product of NF4 float4s of weights (registers) with the same span of an LDS vector that every lane reads alike (broadcast)
+template <int NF4>
+__device__ __forceinline__ float dot_bcast(const float4 (&w)[NF4], const float* x) {
+    f2 a0 = f2{0.f, 0.f}, a1 = f2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NF4; ++c) {
+        const float4 v = reinterpret_cast<const float4*>(x)[c];
+        a0 = __builtin_elementwise_fma(f2{w[c].x, w[c].y}, f2{v.x, v.y}, a0);
+        a1 = __builtin_elementwise_fma(f2{w[c].z, w[c].w}, f2{v.z, v.w}, a1);
+    }
+    a0 += a1;
+    return a0.x + a0.y;
+}
+template <int NF4>
+__device__ __forceinline__ void load_img(float4 (&w)[NF4], const float* img, int wave, int lane) {     // [wave][c][lane][4]
+    const float4* src = reinterpret_cast<const float4*>(img) + (size_t)wave * NF4 * 64 + lane;
+#pragma unroll
+    for (int c = 0; c < NF4; ++c) w[c] = src[(size_t)c * 64];
+}
+
+struct StageLds {
+    float *hx, *ux, *pz, *po, *ps, *pre, *xin, *pt;
+    int* flags;
+};
+__device__ __forceinline__ StageLds carve_stage(float* smem, int kpre) {
+    StageLds s;
+    s.hx = smem;                           // [512] layer input h_l[t]
+    s.ux = s.hx + RWD;                     // [256] gate outputs u_l[t]
+    s.pz = s.ux + GHD;                     // [8][64] partial z
+    s.po = s.pz + 8 * 64;                  // [8][64] partial conv1x1_out
+    s.ps = s.po + 8 * 64;                  // [16][32] partial conv1x1_skip
+    s.pre = s.ps + 16 * 32;                // [BMAX][64] pre_j of the step being computed
+    s.pt = s.pre + BMAX * 64;              // [8][BMAX][64] partial taps
+    s.flags = reinterpret_cast<int*>(s.pt + 8 * BMAX * 64);
+    s.xin = reinterpret_cast<float*>(s.flags + 16);      // [BMAX][kpre] tap inputs of the next step
+    (void)kpre;
+    return s;
+}
+__host__ __device__ inline size_t stage_lds_floats(int kpre) { return (size_t)RWD + GHD + 3 * 512 + BMAX * 64 + 8 * BMAX * 64 + 16 + (size_t)BMAX * kpre; }
+
+// pre_j[tp] for every utterance: older taps of step tp out of this workgroup's own history copy (zeros before t = 0), the
+// conditioning row c[tp], then the streamed [kpre][64] matrix (one pass over the weights for all utterances)
+__device__ void compute_pre(const WideParams& p, const StageLds& s, int l, int j, int tp, int tid, int lane, int wave) {
+    const int d = p.lay_dil[l], rows = (p.kw - 1) * d, hoff = (p.kw - 1) * RWD;
+    for (int b = 0; b < p.B; ++b) {
+        const float* hist = p.hist + (size_t)b * p.hist_b_floats + (size_t)PG * p.lay_histoff[l] + (size_t)j * rows * RWD;
+        float* xb = s.xin + (size_t)b * p.kpre;
+        for (int e = tid; e < p.kpre; e += WT) {
+            float v = 0.f;
+            if (e < hoff) {
+                const int k = e >> 9, r = e & (RWD - 1);
+                const int tt = tp - (p.kw - 1 - k) * d;                     // conv.py:43-44: tap k (oldest first) looks d (kw-1-k) back
+                if (tt >= 0) v = hist[(size_t)(tt % rows) * RWD + r];       // rows this very workgroup stored (row tp - 1 a barrier ago)
+            } else if (e - hoff < p.cin) {
+                v = p.c_up[((size_t)b * p.T + tp) * p.cin + (e - hoff)];
+            }
+            xb[e] = v;
+        }
+    }
+    __syncthreads();
+    // stream: wave w takes the float4 K-blocks [kb0, kb1); lane = gate row; one accumulator per utterance
+    const int per = (p.nkb + 7) >> 3, kb0 = wave * per, kb1 = min(p.nkb, kb0 + per);
+    const float4* W = reinterpret_cast<const float4*>(p.wpre) + ((size_t)(l * PG + j) * p.nkb) * 64 + lane;
+    float acc[BMAX];
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b) acc[b] = 0.f;
+    for (int kb = kb0; kb < kb1; kb += 8) {
+        float4 w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) w[q] = kb + q < kb1 ? W[(size_t)(kb + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            if (kb + q >= kb1) break;
+#pragma unroll
+            for (int b = 0; b < BMAX; ++b) {
+                if (b >= p.B) break;
+                const float4 x = *reinterpret_cast<const float4*>(s.xin + (size_t)b * p.kpre + 4 * (kb + q));
+                acc[b] = fmaf(w[q].x, x.x, acc[b]); acc[b] = fmaf(w[q].y, x.y, acc[b]);
+                acc[b] = fmaf(w[q].z, x.z, acc[b]); acc[b] = fmaf(w[q].w, x.w, acc[b]);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < BMAX; ++b)
+        if (b < p.B) s.pt[((size_t)wave * BMAX + b) * 64 + lane] = acc[b];
+    __syncthreads();
+    for (int e = tid; e < p.B * 64; e += WT) {
+        const int b = e >> 6, r = e & 63;
+        // bias (+ W_g g, hoisted by the host): the model's gate row of padded row r of this slice
+        const int half = r >> 5, ch = GS * j + (r & 31);
+        float v = ch < p.gh_model ? p.zbias[(size_t)b * p.zbias_bstride + (size_t)l * p.zb_ld + (size_t)half * p.gh_model + ch] : 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) v += s.pt[((size_t)w * BMAX + b) * 64 + r];
+        s.pre[b * 64 + r] = v;
+    }
+    __syncthreads();
+}
+
+__device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next, float* smem) {
+    const StageLds s = carve_stage(smem, p.kpre);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4 wz[16], wo[8], ws[4];
+    load_img<16>(wz, p.wz + (size_t)(l * PG + j) * 8 * 16 * 64 * 4, wave, lane);
+    load_img<8>(wo, p.wo + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);
+    load_img<4>(ws, p.ws + (size_t)(l * PG + j) * 8 * 4 * 64 * 4, wave, lane);
+    const float bo_r = p.bo[(size_t)l * RWD + RS * j + lane];
+    const float bs_r = p.bs[(size_t)l * KWD + KS * j + (lane & 31)];
+    const int d = p.lay_dil[l], rows = (p.kw - 1) * d;
+    const bool fast = p.fast != 0;
+    if (tid == 0) s.flags[0] = 0;
+    __syncthreads();
+    compute_pre(p, s, l, j, 0, tid, lane, wave);                  // pre_j[0]: history is zero, conditioning row c[0]
+
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        for (int b = 0; b < p.B; ++b) {
+            // ---- gather h_l[t] (chain) ------------------------------------------------------------------------------------
+            if (wave < 4) {
+                if (!recv128(p.hmail + ((size_t)b * (p.L + 1) + l) * RWD + 128 * wave, tag, s.hx + 128 * wave, p.status, 0x100u + (unsigned)l, lane))
+                    s.flags[0] = 1;
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+            // ---- z = W_cur h + pre ; gate ; publish u_j --------------------------------------------------------------------
+            s.pz[wave * 64 + lane] = dot_bcast<16>(wz, s.hx + 64 * wave);
+            __syncthreads();
+            if (wave == 0 && lane < GS) {
+                float a = s.pre[b * 64 + lane], g = s.pre[b * 64 + 32 + lane];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) { a += s.pz[w * 64 + lane]; g += s.pz[w * 64 + 32 + lane]; }
+                st_granule(p.umail + ((size_t)b * p.L + l) * GHD + GS * j + lane, tag, wide_gate(a, g), fast);      // modules.py:152-154
+            }
+            // ---- gather u_l from the whole group ----------------------------------------------------------------------------
+            if (wave < 2) {
+                if (!recv128(p.umail + ((size_t)b * p.L + l) * GHD + 128 * wave, tag, s.ux + 128 * wave, p.status, 0x200u + (unsigned)l, lane))
+                    s.flags[0] = 1;
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+            // ---- conv1x1_out (chain) and conv1x1_skip -----------------------------------------------------------------------
+            s.po[wave * 64 + lane] = dot_bcast<8>(wo, s.ux + 32 * wave);
+            s.ps[(2 * wave + (lane >> 5)) * 32 + (lane & 31)] = dot_bcast<4>(ws, s.ux + 16 * (2 * wave + (lane >> 5)));
+            __syncthreads();
+            if (wave == 0) {
+                float o = bo_r;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) o += s.po[w * 64 + lane];
+                if (l + 1 < p.L)                                                 // the last layer's residual output is never used
+                    st_granule(p.hmail + ((size_t)b * (p.L + 1) + l + 1) * RWD + RS * j + lane, tag,
+                               (o + s.hx[RS * j + lane]) * 0.70710678118654752440f, fast_next);                       // modules.py:157-162
+            } else if (wave == 1) {
+                float sk = bs_r, acc = 0.f;
+                bool ok = true;
+                if (lane < KS) {
+#pragma unroll
+                    for (int h = 0; h < 16; ++h) sk += s.ps[h * 32 + lane];
+                }
+                if (l > 0) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 1) + l) * KWD + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)l, lane);
+                if (!ok) s.flags[0] = 1;
+                else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 1) + l + 1) * KWD + KS * j + lane, tag, acc + sk, fast_next);   // wavenet.py:312
+            }
+            // ---- history: this workgroup's own copy of row t ----------------------------------------------------------------
+            if (rows > 0) {
+                float* hist = p.hist + (size_t)b * p.hist_b_floats + (size_t)PG * p.lay_histoff[l] + (size_t)j * rows * RWD;
+                hist[(size_t)(t % rows) * RWD + tid] = s.hx[tid];
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+        }
+        // ---- behind the chain: pre_j[t + 1] for every utterance (the rows written above are this CU's own stores) ----------------
+        if (t + 1 < p.T) {
+            compute_pre(p, s, l, j, t + 1, tid, lane, wave);
+        }
+    }
+}
+
+struct HeadLds {
+    float *vs, *hid, *ph, *pout, *obuf, *nz;
+    int* flags;
+};
+__device__ __forceinline__ HeadLds carve_head(float* smem) {
+    HeadLds s;
+    s.vs = smem; s.hid = s.vs + KWD; s.ph = s.hid + KWD; s.pout = s.ph + 2 * KWD; s.obuf = s.pout + 8 * 64; s.nz = s.obuf + 64;
+    s.flags = reinterpret_cast<int*>(s.nz + 64);
+    return s;
+}
+constexpr size_t HEAD_LDS_FLOATS = 4 * KWD + 8 * 64 + 64 + 64 + 16;
+
+__device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem) {
+    const HeadLds s = carve_head(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4 w1[32], w2[8];
+    load_img<32>(w1, p.wh1, wave, lane);                 // rows (wave & 3) 64 + lane, K half (wave >> 2)
+    load_img<8>(w2, p.wh2, wave, lane);                  // row lane (< O), K chunk 32 wave
+    const float wf = p.wfirst[tid], bf = p.bfirst[tid];
+    const float b1 = tid < KWD ? p.bh1[tid] : 0.f;
+    const float b2 = lane < p.O ? p.bh2[lane] : 0.f;
+    if (tid == 0) s.flags[0] = 0;
+    __syncthreads();
+    // the input of step 0 (wavenet.py:283-289, :297-308)
+    for (int b = 0; b < p.B; ++b) {
+        const float xs = p.Tt > 0 ? p.teacher[(size_t)b * p.Tt] : (p.initial ? p.initial[b] : 0.f);
+        st_granule(p.hmail + ((size_t)b * (p.L + 1)) * RWD + tid, p.tag_base + 1u, fmaf(wf, xs, bf), fast_first);
+    }
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        for (int b = 0; b < p.B; ++b) {
+            if (tid < p.nz) {
+                const int kind = (p.dist == 2 && tid == p.nz - 1) ? 1 : 0;
+                s.nz[tid] = p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, b, tid, kind);
+            }
+            if (wave < 2) {
+                if (!recv128(p.smail + ((size_t)b * (p.L + 1) + p.L) * KWD + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+            if (tid < KWD) s.vs[tid] = fmaxf(s.vs[tid] * p.skip_scale, 0.f);                        // wavenet.py:313-316
+            __syncthreads();
+            s.ph[(wave >> 2) * KWD + (wave & 3) * 64 + lane] = dot_bcast<32>(w1, s.vs + 128 * (wave >> 2));
+            __syncthreads();
+            if (tid < KWD) s.hid[tid] = fmaxf(s.ph[tid] + s.ph[KWD + tid] + b1, 0.f);               // wavenet.py:317-318
+            __syncthreads();
+            s.pout[wave * 64 + lane] = dot_bcast<8>(w2, s.hid + 32 * wave);
+            __syncthreads();
+            if (wave == 0) {
+                float o = b2;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) o += s.pout[w * 64 + lane];
+                if (lane < p.O) {
+                    s.obuf[lane] = o;                                                                // wavenet.py:319
+                    if (p.params_out) p.params_out[((size_t)b * p.O + lane) * p.T + t] = o;
+                }
+                const float x = sample_scalar(p.dist, p.O, s.obuf, s.nz, lane);                      // mixture.py:118-156 / :221-270
+                if (lane == 0) { p.out[(size_t)b * p.T + t] = x; s.nz[63] = x; }
+            }
+            __syncthreads();
+            if (t + 1 < p.T) {
+                const float xs = t + 1 < p.Tt ? p.teacher[(size_t)b * p.Tt + t + 1] : s.nz[63];   // wavenet.py:297-305
+                st_granule(p.hmail + ((size_t)b * (p.L + 1)) * RWD + tid, tag + 1u, fmaf(wf, xs, bf), fast_first);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ void __launch_bounds__(WT) wnv_wide_kernel(const WideParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int x = blockIdx.x & 7, li = blockIdx.x >> 3;
+    if (x == p.head_x && li == p.head_li) {
+        run_wide_head(p, p.fast && p.head_x == 0, smem);                       // group 0 lives on XCD 0
+        return;
+    }
+    const int sl = li / PG, j = li % PG, l = x * p.nL + sl;
+    if (sl >= p.nL || l >= p.L) return;
+    // who reads what this group publishes for the NEXT layer: group l + 1 (same XCD unless this is the last group of its XCD) or the head
+    const int next_x = l + 1 < p.L ? (l + 1) / p.nL : p.head_x;
+    run_wide_stage(p, l, j, p.fast && next_x == x, smem);
+}
+
+}  // namespace
+
+// =================================================================================================
+// host side
+// =================================================================================================
+struct WnvWideState {
+    int device = 0;
+    int L = 0, O = 0, cin = 0, cinp = 0, kw = 0, kpre = 0, nkb = 0;
+    float* d_w = nullptr;
+    size_t o_wz = 0, o_wo = 0, o_ws = 0, o_bo = 0, o_bs = 0, o_wpre = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0, o_bh2 = 0, o_wf = 0, o_bf = 0;
+    int* d_dil = nullptr;
+    int* d_histoff = nullptr;
+    long long hist_layer_floats = 0;          // one copy set: sum over layers of rows * 512
+    void* d_state = nullptr;
+    size_t state_cap = 0;
+    unsigned tag_next = 0;
+    size_t mail_bytes = 0;
+    unsigned int* h_status = nullptr;
+    int ncu = 0, n_xcd = 0;
+    bool map_ok = false;
+};
+
+static const char* wide_why_not(const wnv_config& c, int B) {
+    if (!c.scalar_input) return "one-hot models are not covered yet (scalar-input MoL / Gaussian only)";
+    if (c.out_channels > 64) return "needs out_channels <= 64";
+    if (c.residual_channels > RWD || c.gate_channels > 2 * GHD) return "needs residual_channels <= 512 and gate_channels <= 512";
+    if (c.skip_out_channels > KWD) return "needs skip_out_channels <= 256";
+    if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
+    if (c.cin_channels > 128) return "needs cin_channels <= 128";
+    if (c.layers > 31) return "needs layers <= 31 (8 workgroups per layer, 32 CUs per XCD, one more for the head)";
+    if (B > BMAX) return "more than 8 utterances per call";
+    return nullptr;
+}
+bool wnv_wide_supported(const wnv_config& c, int B) { return wide_why_not(c, B) == nullptr; }
+const char* wnv_wide_why_not(const wnv_config& c, int B) { const char* w = wide_why_not(c, B); return w ? w : "supported"; }
+
+void wnv_wide_destroy(WnvWideState* st) {
+    if (!st) return;
+    if (st->d_w) (void)hipFree(st->d_w);
+    if (st->d_dil) (void)hipFree(st->d_dil);
+    if (st->d_histoff) (void)hipFree(st->d_histoff);
+    if (st->d_state) (void)hipFree(st->d_state);
+    if (st->h_status) (void)hipHostFree(st->h_status);
+    delete st;
+}
+
+#define WIDE_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) { err = std::string(#expr) + " failed: " + hipGetErrorString(e__); return WNV_ERR_HIP; } \
+    } while (0)
+
+static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c, const TensorStore& store, std::string& err) {
+    WnvWideState* st = new WnvWideState();
+    *out = st;
+    st->device = device;
+    const int L = c.layers, kw = c.kernel_size, cin = c.cin_channels > 0 ? c.cin_channels : 0, cinp = (cin + 3) & ~3;
+    const int Ra = c.residual_channels, Ga = c.gate_channels, Gha = Ga / 2, Ka = c.skip_out_channels, O = c.out_channels;
+    st->L = L; st->O = O; st->cin = cin; st->cinp = cinp; st->kw = kw;
+    st->kpre = (kw - 1) * RWD + cinp; st->nkb = st->kpre / 4;
+    std::vector<float> blob;
+    auto alloc = [&](size_t n) { size_t o = (blob.size() + 3) & ~(size_t)3; blob.resize(o + n, 0.f); return o; };
+    auto T = [&](const std::string& n) -> const HostTensor& { return *store.get(n); };
+    // padded gate row o in [0, 512): tanh channels 0..255 then sigmoid channels 0..255 -> the model's gate row, or -1
+    auto gate_row = [&](int o) { const int ch = o & (GHD - 1); return ch < Gha ? (o >> 8) * Gha + ch : -1; };
+    // gate row of lane r of slice j: 32 tanh rows then the 32 sigmoid rows of the same channels
+    auto slice_row = [&](int j, int r) { return (r >> 5) * GHD + GS * j + (r & 31); };
+    const size_t n_wz = (size_t)8 * 16 * 64 * 4, n_wo = (size_t)8 * 8 * 64 * 4, n_ws = (size_t)8 * 4 * 64 * 4, n_pre = (size_t)st->nkb * 64 * 4;
+    st->o_wz = alloc((size_t)L * PG * n_wz);
+    st->o_wo = alloc((size_t)L * PG * n_wo);
+    st->o_ws = alloc((size_t)L * PG * n_ws);
+    st->o_bo = alloc((size_t)L * RWD);
+    st->o_bs = alloc((size_t)L * KWD);
+    st->o_wpre = alloc((size_t)L * PG * n_pre);
+    std::vector<int> dil(L), hoff(L);
+    long long hist = 0;
+    const int per = L / c.stacks;
+    for (int l = 0; l < L; ++l) {
+        const std::string pfx = "conv_layers." + std::to_string(l) + ".";
+        const HostTensor& wc = T(pfx + "conv.weight");                 // (G, R, kw)
+        const HostTensor& wout = T(pfx + "conv1x1_out.weight");        // (R, G/2, 1)
+        const HostTensor& wsk = T(pfx + "conv1x1_skip.weight");        // (K, G/2, 1)
+        const HostTensor* wcc = cin > 0 ? &T(pfx + "conv1x1c.weight") : nullptr;   // (G, cin, 1)
+        for (int j = 0; j < PG; ++j) {
+            float* iz = blob.data() + st->o_wz + (size_t)(l * PG + j) * n_wz;
+            float* io = blob.data() + st->o_wo + (size_t)(l * PG + j) * n_wo;
+            float* is = blob.data() + st->o_ws + (size_t)(l * PG + j) * n_ws;
+            float* ip = blob.data() + st->o_wpre + (size_t)(l * PG + j) * n_pre;
+            for (int w = 0; w < 8; ++w)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int go = gate_row(slice_row(j, lane));
+                    for (int cq = 0; cq < 16; ++cq)                     // newest tap, K chunk [64 w, 64 w + 64)
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = 64 * w + 4 * cq + e;
+                            iz[(((size_t)w * 16 + cq) * 64 + lane) * 4 + e] = (go >= 0 && k < Ra) ? wc.data[((size_t)go * Ra + k) * kw + (kw - 1)] : 0.f;
+                        }
+                    const int ro = RS * j + lane;                       // residual row, K chunk [32 w, 32 w + 32) of u
+                    for (int cq = 0; cq < 8; ++cq)
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = 32 * w + 4 * cq + e;
+                            io[(((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = (ro < Ra && k < Gha) ? wout.data[(size_t)ro * Gha + k] : 0.f;
+                        }
+                    const int so = KS * j + (lane & 31), hw = 2 * w + (lane >> 5);      // skip row, K chunk [16 hw, 16 hw + 16)
+                    for (int cq = 0; cq < 4; ++cq)
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = 16 * hw + 4 * cq + e;
+                            is[(((size_t)w * 4 + cq) * 64 + lane) * 4 + e] = (so < Ka && k < Gha) ? wsk.data[(size_t)so * Gha + k] : 0.f;
+                        }
+                }
+            for (int kb = 0; kb < st->nkb; ++kb)                        // older taps (oldest first) then local conditioning, [kb][lane][4]
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int go = gate_row(slice_row(j, lane));
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * kb + e;
+                        float v = 0.f;
+                        if (go >= 0) {
+                            if (k < (kw - 1) * RWD) {
+                                const int tap = k >> 9, ch = k & (RWD - 1);
+                                if (ch < Ra) v = wc.data[((size_t)go * Ra + ch) * kw + tap];
+                            } else if (k - (kw - 1) * RWD < cin) {
+                                v = wcc->data[(size_t)go * cin + (k - (kw - 1) * RWD)];
+                            }
+                        }
+                        ip[((size_t)kb * 64 + lane) * 4 + e] = v;
+                    }
+                }
+        }
+        const HostTensor& bo = T(pfx + "conv1x1_out.bias");
+        std::copy(bo.data.begin(), bo.data.end(), blob.begin() + st->o_bo + (size_t)l * RWD);
+        const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
+        std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bs + (size_t)l * KWD);
+        dil[l] = 1 << (l % per);
+        hoff[l] = (int)hist;
+        hist += (long long)(kw - 1) * dil[l] * RWD;
+    }
+    st->hist_layer_floats = hist;
+    // head: W1 rows (w & 3) 64 + lane, K half (w >> 2) -> [w][32][lane][4];  W2 row lane, K chunk 32 w -> [w][8][lane][4]
+    st->o_wh1 = alloc((size_t)8 * 32 * 64 * 4);
+    st->o_wh2 = alloc((size_t)8 * 8 * 64 * 4);
+    {
+        const HostTensor& w1 = T("last_conv_layers.1.weight");         // (K, K, 1)
+        const HostTensor& w2 = T("last_conv_layers.3.weight");         // (O, K, 1)
+        for (int w = 0; w < 8; ++w)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int row = (w & 3) * 64 + lane;
+                for (int cq = 0; cq < 32; ++cq)
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 128 * (w >> 2) + 4 * cq + e;
+                        blob[st->o_wh1 + (((size_t)w * 32 + cq) * 64 + lane) * 4 + e] = (row < Ka && k < Ka) ? w1.data[(size_t)row * Ka + k] : 0.f;
+                    }
+                for (int cq = 0; cq < 8; ++cq)
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 32 * w + 4 * cq + e;
+                        blob[st->o_wh2 + (((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = (lane < O && k < Ka) ? w2.data[(size_t)lane * Ka + k] : 0.f;
+                    }
+            }
+    }
+    st->o_bh1 = alloc(KWD);
+    std::copy(T("last_conv_layers.1.bias").data.begin(), T("last_conv_layers.1.bias").data.end(), blob.begin() + st->o_bh1);
+    st->o_bh2 = alloc(64);
+    std::copy(T("last_conv_layers.3.bias").data.begin(), T("last_conv_layers.3.bias").data.end(), blob.begin() + st->o_bh2);
+    st->o_wf = alloc(RWD);
+    st->o_bf = alloc(RWD);
+    for (int r = 0; r < Ra; ++r) {
+        blob[st->o_wf + r] = T("first_conv.weight").data[r];           // (R, 1, 1)
+        blob[st->o_bf + r] = T("first_conv.bias").data[r];
+    }
+    WIDE_HIP(hipMalloc((void**)&st->d_w, blob.size() * sizeof(float)));
+    WIDE_HIP(hipMemcpy(st->d_w, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
+    WIDE_HIP(hipMalloc((void**)&st->d_dil, L * sizeof(int)));
+    WIDE_HIP(hipMemcpy(st->d_dil, dil.data(), L * sizeof(int), hipMemcpyHostToDevice));
+    WIDE_HIP(hipMalloc((void**)&st->d_histoff, L * sizeof(int)));
+    WIDE_HIP(hipMemcpy(st->d_histoff, hoff.data(), L * sizeof(int), hipMemcpyHostToDevice));
+    WIDE_HIP(hipHostMalloc((void**)&st->h_status, 64, hipHostMallocDefault));
+    *st->h_status = 0;
+    wnv_status cs = wnv_placement_census(device, &st->ncu, &st->n_xcd, &st->map_ok, err);
+    return cs;
+}
+
+wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c, const TensorStore& store, const WnvGenArgs& ga,
+                             hipStream_t stream, std::string& err) {
+    if (!*pst) {
+        wnv_status st0 = wide_build(pst, device, c, store, err);
+        if (st0 != WNV_OK) { wnv_wide_destroy(*pst); *pst = nullptr; return st0; }
+    }
+    WnvWideState* st = *pst;
+    const int B = ga.B, L = st->L;
+    if (!st->map_ok || st->n_xcd != 8) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "wide kernel: placement census found %d XCDs over %d CUs with the block -> XCD mapping %s (needs 8 XCDs, b %% 8)",
+                 st->n_xcd, st->ncu, st->map_ok ? "as assumed" : "NOT as assumed");
+        err = buf;
+        return WNV_ERR_UNSUPPORTED;
+    }
+    const int cus_per_xcd = st->ncu / 8;
+    const int nL = (L + 7) / 8;                                      // layer groups per XCD
+    // the head goes to the XCD of the last layer when that XCD has a free slot, else to the first XCD that has one
+    int head_x = -1, head_li = -1;
+    auto groups_on = [&](int x) { return std::max(0, std::min(nL, L - x * nL)); };
+    const int last_x = (L - 1) / nL;
+    for (int k = 0; k < 8 && head_x < 0; ++k) {
+        const int x = (last_x + k) % 8;
+        if (groups_on(x) * PG + 1 <= cus_per_xcd) { head_x = x; head_li = groups_on(x) * PG; }
+    }
+    if (head_x < 0 || nL * PG > cus_per_xcd) { err = "wide kernel: not enough CUs per XCD for the layer groups + the head"; return WNV_ERR_UNSUPPORTED; }
+    WideParams p{};
+    p.L = L; p.nL = nL; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.O = st->O; p.cin = st->cin; p.cinp = st->cinp; p.kw = st->kw; p.nz = ga.nz;
+    p.dist = c.output_distribution; p.kpre = st->kpre; p.nkb = st->nkb;
+    p.head_x = head_x; p.head_li = head_li;
+    { const char* e = getenv("WNV_RING_FAST"); p.fast = !(e && e[0] == '0'); }
+    p.skip_scale = (float)std::sqrt(1.0 / L);
+    const float* w = st->d_w;
+    p.wz = w + st->o_wz; p.wo = w + st->o_wo; p.ws = w + st->o_ws; p.bo = w + st->o_bo; p.bs = w + st->o_bs; p.wpre = w + st->o_wpre;
+    p.wh1 = w + st->o_wh1; p.bh1 = w + st->o_bh1; p.wh2 = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf;
+    p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride; p.zb_ld = (c.gate_channels + 3) & ~3; p.gh_model = c.gate_channels / 2;
+    p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
+    p.hist_b_floats = (long long)PG * st->hist_layer_floats;
+    // state: [status 64 B][H B (L+1) 512 u64][U B L 256 u64][SK B (L+1) 256 u64][history B x 8 copies x layers]
+    const size_t head_bytes = 64;
+    const size_t n_h = (size_t)B * (L + 1) * RWD, n_u = (size_t)B * L * GHD, n_s = (size_t)B * (L + 1) * KWD;
+    const size_t mail_bytes = (n_h + n_u + n_s) * sizeof(u64);
+    const size_t hist_bytes = (size_t)B * p.hist_b_floats * sizeof(float);
+    const size_t bytes = head_bytes + mail_bytes + hist_bytes;
+    bool fresh = false;
+    if (bytes > st->state_cap) {
+        if (st->d_state) { WIDE_HIP(hipFree(st->d_state)); st->d_state = nullptr; st->state_cap = 0; }
+        WIDE_HIP(hipMalloc(&st->d_state, bytes));
+        st->state_cap = bytes;
+        fresh = true;
+    }
+    char* base = (char*)st->d_state;
+    if (fresh || mail_bytes != st->mail_bytes || (unsigned long long)st->tag_next + (unsigned long long)ga.T + 2ull > 0xFFFFFFF0ull) {
+        WIDE_HIP(hipMemsetAsync(base, 0, head_bytes + mail_bytes, stream));
+        st->tag_next = 0;
+        st->mail_bytes = mail_bytes;
+    } else {
+        WIDE_HIP(hipMemsetAsync(base, 0, head_bytes, stream));
+    }
+    WIDE_HIP(hipMemsetAsync(base + head_bytes + mail_bytes, 0, hist_bytes, stream));        // clear_buffer (wavenet.py:241)
+    p.tag_base = st->tag_next;
+    st->tag_next += (unsigned)ga.T + 1u;
+    p.status = (unsigned int*)base;
+    p.hmail = (u64*)(base + head_bytes);
+    p.umail = p.hmail + n_h;
+    p.smail = p.umail + n_u;
+    p.hist = (float*)(p.smail + n_s);
+    p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
+    p.out = ga.out; p.params_out = ga.params_out;
+    const size_t lds = std::max(stage_lds_floats(p.kpre), HEAD_LDS_FLOATS) * sizeof(float);
+    if (lds > 160 * 1024) { err = "wide kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
+    WIDE_HIP(hipFuncSetAttribute((const void*)wnv_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    {
+        int per_cu = 0;
+        WIDE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wnv_wide_kernel, WT, lds));
+        const int live = L * PG + 1;
+        if (per_cu < 1 || live > st->ncu * per_cu) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "wide kernel: %d workgroups must be co-resident but the device holds %d", live, st->ncu * std::max(per_cu, 0));
+            err = buf;
+            return WNV_ERR_UNSUPPORTED;
+        }
+    }
+    const int max_li = std::max(nL * PG - 1, head_li);
+    const int grid = 8 * (max_li + 1);
+    hipLaunchKernelGGL(wnv_wide_kernel, dim3(grid), dim3(WT), lds, stream, p);
+    WIDE_HIP(hipGetLastError());
+    WIDE_HIP(hipMemcpyAsync(st->h_status, p.status, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
+    WIDE_HIP(hipStreamSynchronize(stream));
+    if (*st->h_status != 0) {
+        char buf[160];
+        snprintf(buf, sizeof buf, "wide kernel gave up waiting (code 0x%x: 0x1ll = h into group ll, 0x2ll = u inside group ll, 0x3ll = skip, 0x400 = head)", *st->h_status);
+        err = buf;
+        return WNV_ERR_TIMEOUT;
+    }
+    return WNV_OK;
+}
