@@ -1,5 +1,5 @@
 """-m gpu: the group-ring kernel for WIDE models (csrc/wnv_wide.hip, kernel = 3): eight workgroups per layer, weights resident,
-two all-gather hops per layer -- against the CPU oracle, against the generic kernel on the same inputs, and through
+one all-gather hop per layer (the pair (u, h) travels together, gate-to-gate folding on the host) -- against the CPU oracle, against the generic kernel on the same inputs, and through
 size-independent properties at the published 24-layer 512 / 512 / 256 geometry."""
 import time
 

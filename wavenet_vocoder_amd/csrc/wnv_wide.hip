@@ -8,19 +8,20 @@
 //
 //     head -> group 0 -> group 1 -> ... -> group L-1 -> head        (3-4 groups per XCD, consecutive layers share an XCD)
 //
-//   CU j of group l per step (modules.py:127-163, evaluated exactly in the reference's order -- no folding):
-//     gather h_l[t]             512 values published by the 8 CUs of group l-1 (by the head for l = 0)
-//     z   = W_cur[rows_j] h_l + pre_j      64 gate rows (32 tanh + the 32 sigmoid rows of the same channels), K = 512
-//     u_j = tanh . sigmoid                 -> publish 32 values of u_l
-//     gather u_l                256 values published by the 8 CUs of this very group
-//     h_{l+1}[64 j ..] = sqrt(.5) (W_out[rows_j] u_l + b + h_l[64 j ..])          -> publish (the chain goes on)
-//     skip_j += W_skip[rows_j] u_l + b     32 skip channels, handed from CU j of group l to CU j of group l+1; the head gathers
-//     history: every CU keeps its OWN copy of the layer's input history (no cross-CU ordering needed); the older taps and the
-//     local-conditioning 1x1 of the NEXT step -- pre_j[t+1], 282 KB of weights per CU -- stream from L2 / Infinity Cache behind
-//     the chain, once per step for all utterances
-//   two hops (all-gathers of 8 producers) and two mat-vec phases per layer.  Hand-off = the ring kernel's data-tagged 8-byte
-//   granules; plain stores inside an XCD (the host's placement census verified that blocks b and b % 8 share an XCD), write-through
-//   stores across XCDs.  Mat-vec mapping: lane = output row, the 8 waves split K, partial sums meet in LDS.
+// ONE hop and ONE mat-vec phase per layer.  Group l-1 publishes the PAIR (u_{l-1}, h_{l-1}) -- its gate outputs and its own layer
+// input; from that pair alone CU j of group l computes, in one pass over its registers (modules.py:127-163 with the residual
+// recurrence substituted into the next pre-activation, folded on the host in double as in wnv_ring.hip):
+//     z_l   = M_l u_{l-1} + N_l h_{l-1} + c_l + pre_l        64 gate rows;  M_l = sqrt(.5) W_cur,l W_out,l-1, N_l = sqrt(.5) W_cur,l,
+//     u_l   = tanh . sigmoid (z_l)                           c_l = N_l b_out,l-1                        -> publish 32 values
+//     h_l   = sqrt(.5) (W_out,l-1 u_{l-1} + b + h_{l-1})     64 rows: layer l's input, the reference's own recurrence -> publish
+//     s_{l-1} = W_skip,l-1 u_{l-1} + b                       32 skip channels, summed from group to group (CU j -> CU j)
+//   (group 0 reads h_0 from the head: z_0 = W_cur,0 h_0 + pre_0, and passes h_0 on; the last group gathers its own u for the last
+//   skip term, one more hop once per step).  Behind the chain every CU gathers the full h_l its group just produced, keeps its OWN
+//   copy of the layer's input history (no cross-CU ordering needed) and streams the older taps + the local-conditioning 1x1 of the
+//   NEXT step -- pre_j[t+1], 282 KB of weights per CU -- from L2 / Infinity Cache, once per step for all utterances.
+//   Hand-off = the ring kernel's data-tagged 8-byte granules; plain stores inside an XCD (the host's placement census verified that
+//   blocks b and b % 8 share an XCD), write-through stores across XCDs.  Mat-vec mapping: lane = output row, the 8 waves split K,
+//   partial sums meet in LDS.  (v1 of this kernel evaluated the layer unfolded, two hops + two phases per layer: 57 us per step.)
 //
 // Models narrower than 512 / 512 / 256 are zero-padded (exact).  Scalar-input models (MoL / Gaussian, out_channels <= 64);
 // utterances beyond the first share the groups like a systolic array (B <= 8).  Every wait is bounded (WNV_ERR_TIMEOUT).
@@ -46,6 +47,7 @@ constexpr int GS = GHD / PG;       // 32 gate channels per workgroup (64 gate ro
 constexpr int RS = RWD / PG;       // 64 residual rows per workgroup
 constexpr int KS = KWD / PG;       // 32 skip rows per workgroup
 constexpr int BMAX = 8;
+constexpr int XW = GHD + RWD;      // one mailbox slot: 256 gate outputs then 512 layer inputs
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 using u64 = unsigned long long;
@@ -57,14 +59,15 @@ struct WideParams {
     int head_x, head_li, fast;
     unsigned tag_base;
     float skip_scale;
-    const float *wz, *wo, *ws, *bo, *bs, *wpre;           // per (layer, slice) register / stream images
+    const float *wm, *wn, *wo, *ws, *wsl, *bo, *bs, *cvec, *wpre;   // per (layer, slice) register / stream images (wsl: last layer's skip)
     const float *wh1, *bh1, *wh2, *bh2, *wfirst, *bfirst;
     const float* zbias;                                   // generic pack: [B or 1][L][zb_ld], rows = the model's gate rows
     long long zbias_bstride;
     int zb_ld, gh_model;
     const int *lay_dil, *lay_histoff;                     // dilation; float offset of the layer's history inside one copy set
     long long hist_b_floats;                              // floats of history per utterance (all layers, all 8 copies)
-    u64 *hmail, *umail, *smail;                           // H[b][L+1][512], U[b][L][256], SK[b][L+1][256]
+    u64 *xmail, *smail;                                   // X[b][L+1][768] = (u_{l-1} | h_{l-1}) for group l (slot L: the last group's own
+                                                          // outputs); SK[b][L+2][256] running skip sums
     float* hist;
     const float *c_up, *initial, *teacher, *noise;
     u64 seed;
@@ -141,8 +144,8 @@ struct StageLds {
 };
 __device__ __forceinline__ StageLds carve_stage(float* smem, int kpre) {
     StageLds s;
-    s.hx = smem;                           // [512] layer input h_l[t]
-    s.ux = s.hx + RWD;                     // [256] gate outputs u_l[t]
+    s.hx = smem;                           // [512] h_{l-1}[t], then (behind the chain) the full h_l[t]
+    s.ux = s.hx + RWD;                     // [256] gate outputs u_{l-1}[t] (the last group: then its own u)
     s.pz = s.ux + GHD;                     // [8][64] partial z
     s.po = s.pz + 8 * 64;                  // [8][64] partial conv1x1_out
     s.ps = s.po + 8 * 64;                  // [16][32] partial conv1x1_skip
@@ -153,7 +156,7 @@ __device__ __forceinline__ StageLds carve_stage(float* smem, int kpre) {
     (void)kpre;
     return s;
 }
-__host__ __device__ inline size_t stage_lds_floats(int kpre) { return (size_t)RWD + GHD + 3 * 512 + BMAX * 64 + 8 * BMAX * 64 + 16 + (size_t)BMAX * kpre; }
+__host__ __device__ inline size_t stage_lds_floats(int kpre) { return (size_t)RWD + GHD + 3 * 512 + BMAX * 64 + 8 * BMAX * 64 + 16 + (size_t)BMAX * kpre + 8 * 4 * 64 * 4; }
 
 // pre_j[tp] for every utterance: older taps of step tp out of this workgroup's own history copy (zeros before t = 0), the
 // conditioning row c[tp], then the streamed [kpre][64] matrix (one pass over the weights for all utterances)
@@ -181,12 +184,12 @@ __device__ void compute_pre(const WideParams& p, const StageLds& s, int l, int j
     float acc[BMAX];
 #pragma unroll
     for (int b = 0; b < BMAX; ++b) acc[b] = 0.f;
-    for (int kb = kb0; kb < kb1; kb += 8) {
-        float4 w[8];
+    for (int kb = kb0; kb < kb1; kb += 4) {
+        float4 w[4];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) w[q] = kb + q < kb1 ? W[(size_t)(kb + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) w[q] = kb + q < kb1 ? W[(size_t)(kb + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 4; ++q) {
             if (kb + q >= kb1) break;
 #pragma unroll
             for (int b = 0; b < BMAX; ++b) {
@@ -216,14 +219,21 @@ __device__ void compute_pre(const WideParams& p, const StageLds& s, int l, int j
 __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next, float* smem) {
     const StageLds s = carve_stage(smem, p.kpre);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float4 wz[16], wo[8], ws[4];
-    load_img<16>(wz, p.wz + (size_t)(l * PG + j) * 8 * 16 * 64 * 4, wave, lane);
-    load_img<8>(wo, p.wo + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);
-    load_img<4>(ws, p.ws + (size_t)(l * PG + j) * 8 * 4 * 64 * 4, wave, lane);
-    const float bo_r = p.bo[(size_t)l * RWD + RS * j + lane];
-    const float bs_r = p.bs[(size_t)l * KWD + KS * j + (lane & 31)];
+    const bool first = l == 0, last = l == p.L - 1;
+    float4 wn[16], wm[8], wo[8], ws[4];
+    load_img<16>(wn, p.wn + (size_t)(l * PG + j) * 8 * 16 * 64 * 4, wave, lane);      // N_l (group 0: W_cur,0) x h_{l-1}, K chunk 64 wave
+    load_img<8>(wm, p.wm + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);        // M_l x u_{l-1}, K chunk 32 wave (group 0: zeros)
+    load_img<8>(wo, p.wo + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);        // W_out,l-1 rows 64 j + lane
+    load_img<4>(ws, p.ws + (size_t)(l * PG + j) * 8 * 4 * 64 * 4, wave, lane);        // W_skip,l-1 rows 32 j + (lane & 31), K chunk 16 (2 wave + lane / 32)
+    // the last group also holds W_skip,L-1 (same image layout) -- in LDS: the register file is full
+    float4* wsl = reinterpret_cast<float4*>(s.xin + (size_t)BMAX * p.kpre);
+    if (last)
+        for (int c = 0; c < 4; ++c) wsl[(wave * 4 + c) * 64 + lane] = reinterpret_cast<const float4*>(p.wsl + (size_t)j * 8 * 4 * 64 * 4)[(wave * 4 + c) * 64 + lane];
+    const float bo_r = p.bo[(size_t)l * RWD + RS * j + lane];                         // b_out,l-1
+    const float bs_r = p.bs[(size_t)l * KWD + KS * j + (lane & 31)];                  // b_skip,l-1
+    const float bsl_r = p.bs[(size_t)p.L * KWD + KS * j + (lane & 31)];               // b_skip,L-1
+    const float cv_a = p.cvec[(size_t)l * 2 * GHD + GS * j + (lane & 31)], cv_g = p.cvec[(size_t)l * 2 * GHD + GHD + GS * j + (lane & 31)];
     const int d = p.lay_dil[l], rows = (p.kw - 1) * d;
-    const bool fast = p.fast != 0;
     if (tid == 0) s.flags[0] = 0;
     __syncthreads();
     compute_pre(p, s, l, j, 0, tid, lane, wave);                  // pre_j[0]: history is zero, conditioning row c[0]
@@ -231,63 +241,89 @@ __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
         for (int b = 0; b < p.B; ++b) {
-            // ---- gather h_l[t] (chain) ------------------------------------------------------------------------------------
-            if (wave < 4) {
-                if (!recv128(p.hmail + ((size_t)b * (p.L + 1) + l) * RWD + 128 * wave, tag, s.hx + 128 * wave, p.status, 0x100u + (unsigned)l, lane))
-                    s.flags[0] = 1;
-            }
-            __syncthreads();
-            if (s.flags[0]) return;
-            // ---- z = W_cur h + pre ; gate ; publish u_j --------------------------------------------------------------------
-            s.pz[wave * 64 + lane] = dot_bcast<16>(wz, s.hx + 64 * wave);
-            __syncthreads();
-            if (wave == 0 && lane < GS) {
-                float a = s.pre[b * 64 + lane], g = s.pre[b * 64 + 32 + lane];
-#pragma unroll
-                for (int w = 0; w < 8; ++w) { a += s.pz[w * 64 + lane]; g += s.pz[w * 64 + 32 + lane]; }
-                st_granule(p.umail + ((size_t)b * p.L + l) * GHD + GS * j + lane, tag, wide_gate(a, g), fast);      // modules.py:152-154
-            }
-            // ---- gather u_l from the whole group ----------------------------------------------------------------------------
+            u64* x_in = p.xmail + ((size_t)b * (p.L + 1) + l) * XW;
+            u64* x_out = x_in + XW;
+            // ---- gather (u_{l-1}, h_{l-1}) of step t: the chain ------------------------------------------------------------------
             if (wave < 2) {
-                if (!recv128(p.umail + ((size_t)b * p.L + l) * GHD + 128 * wave, tag, s.ux + 128 * wave, p.status, 0x200u + (unsigned)l, lane))
-                    s.flags[0] = 1;
+                if (!first && !recv128(x_in + 128 * wave, tag, s.ux + 128 * wave, p.status, 0x200u + (unsigned)l, lane)) s.flags[0] = 1;
+            } else if (wave < 6) {
+                if (!recv128(x_in + GHD + 128 * (wave - 2), tag, s.hx + 128 * (wave - 2), p.status, 0x100u + (unsigned)l, lane)) s.flags[0] = 1;
             }
             __syncthreads();
             if (s.flags[0]) return;
-            // ---- conv1x1_out (chain) and conv1x1_skip -----------------------------------------------------------------------
-            s.po[wave * 64 + lane] = dot_bcast<8>(wo, s.ux + 32 * wave);
-            s.ps[(2 * wave + (lane >> 5)) * 32 + (lane & 31)] = dot_bcast<4>(ws, s.ux + 16 * (2 * wave + (lane >> 5)));
+            // ---- one pass: z_l, conv1x1_out of layer l-1, conv1x1_skip of layer l-1 -----------------------------------------------
+            {
+                float z = dot_bcast<16>(wn, s.hx + 64 * wave);
+                if (!first) {
+                    z += dot_bcast<8>(wm, s.ux + 32 * wave);
+                    s.po[wave * 64 + lane] = dot_bcast<8>(wo, s.ux + 32 * wave);
+                    s.ps[(2 * wave + (lane >> 5)) * 32 + (lane & 31)] = dot_bcast<4>(ws, s.ux + 16 * (2 * wave + (lane >> 5)));
+                }
+                s.pz[wave * 64 + lane] = z;
+            }
             __syncthreads();
-            if (wave == 0) {
+            float sk_run = 0.f;                                    // wave 2: skip sum up to layer l-1 (kept for the last group)
+            if (wave == 0) {                                       // u_l: lanes c and 32 + c hold the tanh / sigmoid rows of channel 32 j + c
+                float v = s.pre[b * 64 + lane] + ((lane >> 5) ? cv_g : cv_a);
+#pragma unroll
+                for (int w = 0; w < 8; ++w) v += s.pz[w * 64 + lane];
+                const float g = __shfl_xor(v, 32, 64);
+                if (lane < GS) st_granule(x_out + GS * j + lane, tag, wide_gate(v, g), fast_next);                     // modules.py:152-154
+            } else if (wave == 1) {                                // h_l = layer l's input (group 0 passes h_0 on)
                 float o = bo_r;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) o += s.po[w * 64 + lane];
-                if (l + 1 < p.L)                                                 // the last layer's residual output is never used
-                    st_granule(p.hmail + ((size_t)b * (p.L + 1) + l + 1) * RWD + RS * j + lane, tag,
-                               (o + s.hx[RS * j + lane]) * 0.70710678118654752440f, fast_next);                       // modules.py:157-162
-            } else if (wave == 1) {
+                const float hp = s.hx[RS * j + lane];
+                st_granule(x_out + GHD + RS * j + lane, tag, first ? hp : (o + hp) * 0.70710678118654752440f, fast_next);  // modules.py:157-162
+            } else if (wave == 2 && !first) {                      // skip sum over layers 0 .. l-1 (wavenet.py:312)
                 float sk = bs_r, acc = 0.f;
                 bool ok = true;
                 if (lane < KS) {
 #pragma unroll
                     for (int h = 0; h < 16; ++h) sk += s.ps[h * 32 + lane];
                 }
-                if (l > 0) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 1) + l) * KWD + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)l, lane);
+                if (l > 1) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 2) + l) * KWD + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)l, lane);
+                sk_run = acc + sk;
                 if (!ok) s.flags[0] = 1;
-                else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 1) + l + 1) * KWD + KS * j + lane, tag, acc + sk, fast_next);   // wavenet.py:312
+                else if (lane < KS && !last) st_granule(p.smail + ((size_t)b * (p.L + 2) + l + 1) * KWD + KS * j + lane, tag, sk_run, fast_next);
             }
-            // ---- history: this workgroup's own copy of row t ----------------------------------------------------------------
-            if (rows > 0) {
+            // ---- behind the chain: the full h_l this group just produced (history, next step's taps); the last group also needs its
+            //      own u for the last layer's skip term, which the head is waiting for ---------------------------------------------
+            if (last) {
+                if (wave < 2) {
+                    if (!recv128(x_out + 128 * wave, tag, s.ux + 128 * wave, p.status, 0x500u, lane)) s.flags[0] = 1;
+                }
+                __syncthreads();
+                {
+                    float4 wl[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) wl[c] = wsl[(wave * 4 + c) * 64 + lane];
+                    s.ps[(2 * wave + (lane >> 5)) * 32 + (lane & 31)] = dot_bcast<4>(wl, s.ux + 16 * (2 * wave + (lane >> 5)));
+                }
+                __syncthreads();
+                if (wave == 2 && lane < KS && !s.flags[0]) {
+                    float sk = bsl_r + sk_run;
+#pragma unroll
+                    for (int h = 0; h < 16; ++h) sk += s.ps[h * 32 + lane];
+                    st_granule(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + KS * j + lane, tag, sk, fast_next);
+                }
+            }
+            if (!first) {                                          // (group 0: h_0 is already in hx)
+                __syncthreads();                                   // every wave is done with hx
+                if (wave >= 4) {
+                    if (!recv128(x_out + GHD + 128 * (wave - 4), tag, s.hx + 128 * (wave - 4), p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
+                }
+                __syncthreads();
+            }
+            if (s.flags[0]) return;
+            if (rows > 0) {                                        // this workgroup's own copy of history row t
                 float* hist = p.hist + (size_t)b * p.hist_b_floats + (size_t)PG * p.lay_histoff[l] + (size_t)j * rows * RWD;
                 hist[(size_t)(t % rows) * RWD + tid] = s.hx[tid];
             }
             __syncthreads();
-            if (s.flags[0]) return;
         }
-        // ---- behind the chain: pre_j[t + 1] for every utterance (the rows written above are this CU's own stores) ----------------
-        if (t + 1 < p.T) {
-            compute_pre(p, s, l, j, t + 1, tid, lane, wave);
-        }
+        // ---- pre_j[t + 1] for every utterance (the rows written above are this CU's own stores) ------------------------------------
+        if (t + 1 < p.T) compute_pre(p, s, l, j, t + 1, tid, lane, wave);
     }
 }
 
@@ -317,7 +353,7 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
     // the input of step 0 (wavenet.py:283-289, :297-308)
     for (int b = 0; b < p.B; ++b) {
         const float xs = p.Tt > 0 ? p.teacher[(size_t)b * p.Tt] : (p.initial ? p.initial[b] : 0.f);
-        st_granule(p.hmail + ((size_t)b * (p.L + 1)) * RWD + tid, p.tag_base + 1u, fmaf(wf, xs, bf), fast_first);
+        st_granule(p.xmail + ((size_t)b * (p.L + 1)) * XW + GHD + tid, p.tag_base + 1u, fmaf(wf, xs, bf), fast_first);
     }
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
@@ -327,7 +363,7 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
                 s.nz[tid] = p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, b, tid, kind);
             }
             if (wave < 2) {
-                if (!recv128(p.smail + ((size_t)b * (p.L + 1) + p.L) * KWD + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
+                if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
             }
             __syncthreads();
             if (s.flags[0]) return;
@@ -353,7 +389,7 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
             __syncthreads();
             if (t + 1 < p.T) {
                 const float xs = t + 1 < p.Tt ? p.teacher[(size_t)b * p.Tt + t + 1] : s.nz[63];   // wavenet.py:297-305
-                st_granule(p.hmail + ((size_t)b * (p.L + 1)) * RWD + tid, tag + 1u, fmaf(wf, xs, bf), fast_first);
+                st_granule(p.xmail + ((size_t)b * (p.L + 1)) * XW + GHD + tid, tag + 1u, fmaf(wf, xs, bf), fast_first);
             }
             __syncthreads();
         }
@@ -383,7 +419,7 @@ struct WnvWideState {
     int device = 0;
     int L = 0, O = 0, cin = 0, cinp = 0, kw = 0, kpre = 0, nkb = 0;
     float* d_w = nullptr;
-    size_t o_wz = 0, o_wo = 0, o_ws = 0, o_bo = 0, o_bs = 0, o_wpre = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0, o_bh2 = 0, o_wf = 0, o_bf = 0;
+    size_t o_wn = 0, o_wm = 0, o_wo = 0, o_ws = 0, o_wsl = 0, o_bo = 0, o_bs = 0, o_cvec = 0, o_wpre = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0, o_bh2 = 0, o_wf = 0, o_bf = 0;
     int* d_dil = nullptr;
     int* d_histoff = nullptr;
     long long hist_layer_floats = 0;          // one copy set: sum over layers of rows * 512
@@ -441,48 +477,89 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
     auto gate_row = [&](int o) { const int ch = o & (GHD - 1); return ch < Gha ? (o >> 8) * Gha + ch : -1; };
     // gate row of lane r of slice j: 32 tanh rows then the 32 sigmoid rows of the same channels
     auto slice_row = [&](int j, int r) { return (r >> 5) * GHD + GS * j + (r & 31); };
-    const size_t n_wz = (size_t)8 * 16 * 64 * 4, n_wo = (size_t)8 * 8 * 64 * 4, n_ws = (size_t)8 * 4 * 64 * 4, n_pre = (size_t)st->nkb * 64 * 4;
-    st->o_wz = alloc((size_t)L * PG * n_wz);
+    const size_t n_wn = (size_t)8 * 16 * 64 * 4, n_wm = (size_t)8 * 8 * 64 * 4, n_wo = n_wm, n_ws = (size_t)8 * 4 * 64 * 4, n_pre = (size_t)st->nkb * 64 * 4;
+    st->o_wn = alloc((size_t)L * PG * n_wn);
+    st->o_wm = alloc((size_t)L * PG * n_wm);
     st->o_wo = alloc((size_t)L * PG * n_wo);
     st->o_ws = alloc((size_t)L * PG * n_ws);
+    st->o_wsl = alloc((size_t)PG * n_ws);
     st->o_bo = alloc((size_t)L * RWD);
-    st->o_bs = alloc((size_t)L * KWD);
+    st->o_bs = alloc((size_t)(L + 1) * KWD);
+    st->o_cvec = alloc((size_t)L * 2 * GHD);
     st->o_wpre = alloc((size_t)L * PG * n_pre);
     std::vector<int> dil(L), hoff(L);
     long long hist = 0;
     const int per = L / c.stacks;
+    const double rs = std::sqrt(0.5);
+    std::vector<float> cur((size_t)2 * GHD * RWD), mmat((size_t)2 * GHD * GHD);
+    std::vector<double> accd(GHD);
+    // skip image of layer `ls` for slice j
+    auto put_skip = [&](float* is, const HostTensor& wsk, int j) {
+        for (int w = 0; w < 8; ++w)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int so = KS * j + (lane & 31), hw = 2 * w + (lane >> 5);      // skip row, K chunk [16 hw, 16 hw + 16)
+                for (int cq = 0; cq < 4; ++cq)
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 16 * hw + 4 * cq + e;
+                        is[(((size_t)w * 4 + cq) * 64 + lane) * 4 + e] = (so < Ka && k < Gha) ? wsk.data[(size_t)so * Gha + k] : 0.f;
+                    }
+            }
+    };
     for (int l = 0; l < L; ++l) {
-        const std::string pfx = "conv_layers." + std::to_string(l) + ".";
+        const std::string pfx = "conv_layers." + std::to_string(l) + ".", ppx = "conv_layers." + std::to_string(l - 1) + ".";
         const HostTensor& wc = T(pfx + "conv.weight");                 // (G, R, kw)
-        const HostTensor& wout = T(pfx + "conv1x1_out.weight");        // (R, G/2, 1)
-        const HostTensor& wsk = T(pfx + "conv1x1_skip.weight");        // (K, G/2, 1)
         const HostTensor* wcc = cin > 0 ? &T(pfx + "conv1x1c.weight") : nullptr;   // (G, cin, 1)
+        const HostTensor* wout = l > 0 ? &T(ppx + "conv1x1_out.weight") : nullptr; // (R, G/2, 1) of layer l-1
+        const HostTensor* bout = l > 0 ? &T(ppx + "conv1x1_out.bias") : nullptr;
+        const HostTensor* wsk = l > 0 ? &T(ppx + "conv1x1_skip.weight") : nullptr; // (K, G/2, 1) of layer l-1
+        // newest tap as a padded (512 x 512) matrix; folded chain matrices (double accumulation, rounded once):
+        //   M_l = sqrt(.5) W_cur,l W_out,l-1 (512 x 256), N_l = sqrt(.5) W_cur,l, c_l = N_l b_out,l-1;   layer 0: N_0 = W_cur,0, M_0 = 0
+        std::fill(cur.begin(), cur.end(), 0.f);
+        for (int o = 0; o < 2 * GHD; ++o) {
+            const int go = gate_row(o);
+            if (go < 0) continue;
+            for (int k = 0; k < Ra; ++k) cur[(size_t)o * RWD + k] = wc.data[((size_t)go * Ra + k) * kw + (kw - 1)];
+        }
+        std::fill(mmat.begin(), mmat.end(), 0.f);
+        if (l > 0) {
+            for (int o = 0; o < 2 * GHD; ++o) {
+                if (gate_row(o) < 0) continue;
+                std::fill(accd.begin(), accd.end(), 0.0);
+                double cb = 0.0;
+                for (int m = 0; m < Ra; ++m) {
+                    const double cm = (double)cur[(size_t)o * RWD + m];
+                    const float* wrow = wout->data.data() + (size_t)m * Gha;
+                    for (int k = 0; k < Gha; ++k) accd[k] += cm * (double)wrow[k];
+                    cb += cm * (double)bout->data[m];
+                }
+                for (int k = 0; k < Gha; ++k) mmat[(size_t)o * GHD + k] = (float)(rs * accd[k]);
+                blob[st->o_cvec + (size_t)l * 2 * GHD + o] = (float)(rs * cb);
+            }
+        }
         for (int j = 0; j < PG; ++j) {
-            float* iz = blob.data() + st->o_wz + (size_t)(l * PG + j) * n_wz;
+            float* in_ = blob.data() + st->o_wn + (size_t)(l * PG + j) * n_wn;
+            float* im = blob.data() + st->o_wm + (size_t)(l * PG + j) * n_wm;
             float* io = blob.data() + st->o_wo + (size_t)(l * PG + j) * n_wo;
-            float* is = blob.data() + st->o_ws + (size_t)(l * PG + j) * n_ws;
             float* ip = blob.data() + st->o_wpre + (size_t)(l * PG + j) * n_pre;
             for (int w = 0; w < 8; ++w)
                 for (int lane = 0; lane < 64; ++lane) {
-                    const int go = gate_row(slice_row(j, lane));
-                    for (int cq = 0; cq < 16; ++cq)                     // newest tap, K chunk [64 w, 64 w + 64)
+                    const int o = slice_row(j, lane);
+                    for (int cq = 0; cq < 16; ++cq)                     // N_l, K chunk [64 w, 64 w + 64) of h_{l-1}
                         for (int e = 0; e < 4; ++e) {
                             const int k = 64 * w + 4 * cq + e;
-                            iz[(((size_t)w * 16 + cq) * 64 + lane) * 4 + e] = (go >= 0 && k < Ra) ? wc.data[((size_t)go * Ra + k) * kw + (kw - 1)] : 0.f;
+                            const float v = cur[(size_t)o * RWD + k];
+                            in_[(((size_t)w * 16 + cq) * 64 + lane) * 4 + e] = l == 0 ? v : (float)(rs * (double)v);
                         }
-                    const int ro = RS * j + lane;                       // residual row, K chunk [32 w, 32 w + 32) of u
+                    const int ro = RS * j + lane;                       // M_l and W_out,l-1, K chunk [32 w, 32 w + 32) of u_{l-1}
                     for (int cq = 0; cq < 8; ++cq)
                         for (int e = 0; e < 4; ++e) {
                             const int k = 32 * w + 4 * cq + e;
-                            io[(((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = (ro < Ra && k < Gha) ? wout.data[(size_t)ro * Gha + k] : 0.f;
-                        }
-                    const int so = KS * j + (lane & 31), hw = 2 * w + (lane >> 5);      // skip row, K chunk [16 hw, 16 hw + 16)
-                    for (int cq = 0; cq < 4; ++cq)
-                        for (int e = 0; e < 4; ++e) {
-                            const int k = 16 * hw + 4 * cq + e;
-                            is[(((size_t)w * 4 + cq) * 64 + lane) * 4 + e] = (so < Ka && k < Gha) ? wsk.data[(size_t)so * Gha + k] : 0.f;
+                            im[(((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = mmat[(size_t)o * GHD + k];
+                            io[(((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = (l > 0 && ro < Ra && k < Gha) ? wout->data[(size_t)ro * Gha + k] : 0.f;
                         }
                 }
+            if (l > 0) put_skip(blob.data() + st->o_ws + (size_t)(l * PG + j) * n_ws, *wsk, j);
+            if (l == L - 1) put_skip(blob.data() + st->o_wsl + (size_t)j * n_ws, T(pfx + "conv1x1_skip.weight"), j);
             for (int kb = 0; kb < st->nkb; ++kb)                        // older taps (oldest first) then local conditioning, [kb][lane][4]
                 for (int lane = 0; lane < 64; ++lane) {
                     const int go = gate_row(slice_row(j, lane));
@@ -501,10 +578,15 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
                     }
                 }
         }
-        const HostTensor& bo = T(pfx + "conv1x1_out.bias");
-        std::copy(bo.data.begin(), bo.data.end(), blob.begin() + st->o_bo + (size_t)l * RWD);
-        const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
-        std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bs + (size_t)l * KWD);
+        if (l > 0) {
+            std::copy(bout->data.begin(), bout->data.end(), blob.begin() + st->o_bo + (size_t)l * RWD);
+            const HostTensor& bs = T(ppx + "conv1x1_skip.bias");
+            std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bs + (size_t)l * KWD);
+        }
+        if (l == L - 1) {
+            const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
+            std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bs + (size_t)L * KWD);
+        }
         dil[l] = 1 << (l % per);
         hoff[l] = (int)hist;
         hist += (long long)(kw - 1) * dil[l] * RWD;
@@ -586,15 +668,16 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     { const char* e = getenv("WNV_RING_FAST"); p.fast = !(e && e[0] == '0'); }
     p.skip_scale = (float)std::sqrt(1.0 / L);
     const float* w = st->d_w;
-    p.wz = w + st->o_wz; p.wo = w + st->o_wo; p.ws = w + st->o_ws; p.bo = w + st->o_bo; p.bs = w + st->o_bs; p.wpre = w + st->o_wpre;
+    p.wn = w + st->o_wn; p.wm = w + st->o_wm; p.wo = w + st->o_wo; p.ws = w + st->o_ws; p.wsl = w + st->o_wsl; p.bo = w + st->o_bo; p.bs = w + st->o_bs;
+    p.cvec = w + st->o_cvec; p.wpre = w + st->o_wpre;
     p.wh1 = w + st->o_wh1; p.bh1 = w + st->o_bh1; p.wh2 = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf;
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride; p.zb_ld = (c.gate_channels + 3) & ~3; p.gh_model = c.gate_channels / 2;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
     p.hist_b_floats = (long long)PG * st->hist_layer_floats;
-    // state: [status 64 B][H B (L+1) 512 u64][U B L 256 u64][SK B (L+1) 256 u64][history B x 8 copies x layers]
+    // state: [status 64 B][X B (L+1) 768 u64][SK B (L+2) 256 u64][history B x 8 copies x layers]
     const size_t head_bytes = 64;
-    const size_t n_h = (size_t)B * (L + 1) * RWD, n_u = (size_t)B * L * GHD, n_s = (size_t)B * (L + 1) * KWD;
-    const size_t mail_bytes = (n_h + n_u + n_s) * sizeof(u64);
+    const size_t n_x = (size_t)B * (L + 1) * XW, n_s = (size_t)B * (L + 2) * KWD;
+    const size_t mail_bytes = (n_x + n_s) * sizeof(u64);
     const size_t hist_bytes = (size_t)B * p.hist_b_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -616,9 +699,8 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     p.tag_base = st->tag_next;
     st->tag_next += (unsigned)ga.T + 1u;
     p.status = (unsigned int*)base;
-    p.hmail = (u64*)(base + head_bytes);
-    p.umail = p.hmail + n_h;
-    p.smail = p.umail + n_u;
+    p.xmail = (u64*)(base + head_bytes);
+    p.smail = p.xmail + n_x;
     p.hist = (float*)(p.smail + n_s);
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.out = ga.out; p.params_out = ga.params_out;
@@ -644,7 +726,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     WIDE_HIP(hipStreamSynchronize(stream));
     if (*st->h_status != 0) {
         char buf[160];
-        snprintf(buf, sizeof buf, "wide kernel gave up waiting (code 0x%x: 0x1ll = h into group ll, 0x2ll = u inside group ll, 0x3ll = skip, 0x400 = head)", *st->h_status);
+        snprintf(buf, sizeof buf, "wide kernel gave up waiting (code 0x%x: 0x1ll / 0x2ll = h / u into group ll, 0x3ll = skip, 0x400 = head, 0x5.. / 0x6.. = own outputs)", *st->h_status);
         err = buf;
         return WNV_ERR_TIMEOUT;
     }
