@@ -66,6 +66,45 @@ def test_wide_vs_oracle_and_generic(name):
     assert eng.last_kernel() == 3 and torch.equal(auto.cpu(), out), "auto picks the group ring for a wide model"
 
 
+ONEHOT_WIDE = dict(out_channels=256, layers=6, stacks=2, residual_channels=512, gate_channels=512, skip_out_channels=256, kernel_size=3,
+                   dropout=0.0, cin_channels=80)        # the published CMU-ARCTIC geometry (mu-law 256 in / out), six layers of it
+
+
+def test_wide_onehot_vs_oracle_and_generic():
+    """One-hot wide models: the head is two workgroups (hidden layer | output layer + softmax + OneHotCategorical + first_conv row
+    gather).  Teacher-forced probabilities against the oracle, sampled classes of a free run equal the oracle's until a near tie."""
+    kw = ONEHOT_WIDE
+    torch.manual_seed(29)
+    m = tame_head_(wnv.WaveNet(**kw).eval())
+    o = Oracle(oracle_config(kw), m.state_dict())
+    B, Tt, T = 2, 64, 128
+    g = torch.Generator().manual_seed(4)
+    c = torch.randn(B, 80, T, generator=g)
+    idx = torch.randint(0, 256, (B, Tt), generator=g)
+    x = torch.zeros(B, 256, Tt).scatter_(1, idx.unsqueeze(1), 1.0)
+    tape = make_noise_tape(T, B, scalar_input=False, output_distribution="Logistic", out_channels=256, generator=torch.Generator().manual_seed(9))
+    torch.set_num_threads(8)
+    want_p, wparams_tf = o.incremental_forward(test_inputs=x, c=c[:, :, :Tt], T=Tt, softmax=True, quantize=False, noise=tape[:Tt], return_params=True)
+    want, wparams = o.incremental_forward(test_inputs=x, c=c, T=T, noise=tape, return_params=True)          # forced, then free-running classes
+    eng = m.to("cuda")._get_engine()
+    cu = c.transpose(1, 2).contiguous().cuda()
+    tin = x.transpose(1, 2).contiguous().cuda()
+    probs, params_tf, _ = eng.generate(B=B, T=Tt, c_up=cu[:, :Tt].contiguous(), teacher=tin, noise=tape[:Tt].cuda(), softmax=True, quantize=False,
+                                       want_params=True, kernel=3)
+    assert eng.last_kernel() == 3
+    assert float((params_tf.cpu() - wparams_tf).abs().max()) < TOL and float((probs.cpu() - want_p).abs().max()) < TOL
+    out, params, cls = eng.generate(B=B, T=T, c_up=cu, teacher=tin, noise=tape.cuda(), want_params=True, want_index=True, kernel=3)
+    assert torch.equal(out.sum(1), torch.ones(B, T, device="cuda")) and torch.equal(out.argmax(1).int(), cls.int())
+    assert_match_or_near_tie(cls.cpu()[:, :Tt - 1], want.argmax(1)[:, :Tt - 1], wparams[:, :, :Tt - 1], tape[:Tt - 1], kw)
+    hz = assert_free_run_agrees_until_near_tie(cls.cpu(), want.argmax(1), params.cpu(), wparams, tape, kw, t0=Tt - 1, what="wide one-hot")
+    print(f"wide one-hot: forced head outputs vs oracle {float((params_tf.cpu() - wparams_tf).abs().max()):.2e}; free-run horizon {hz} of {T}")
+    gen, gparams, gcls = eng.generate(B=B, T=T, c_up=cu, teacher=tin, noise=tape.cuda(), want_params=True, want_index=True, kernel=1)
+    assert float((params[:, :, :Tt] - gparams[:, :, :Tt]).abs().max()) < 5e-5
+    free, _, fcls = eng.generate(B=B, T=64, c_up=cu[:, :64].contiguous(), noise=tape[:64].cuda(), want_index=True, kernel=3)       # implicit class-127 start
+    free1, _, fcls1 = eng.generate(B=B, T=64, c_up=cu[:, :64].contiguous(), noise=tape[:64].cuda(), want_index=True, kernel=1)
+    assert (fcls == fcls1).float().mean().item() > 0.9
+
+
 def test_wide_published_geometry_properties_and_speed():
     """24 layers, 512 / 512 / 256, 80-mel conditioned MoL (the published CMU-ARCTIC geometry): properties at a length the oracle cannot
     reach, and the reason this kernel exists -- one utterance faster than real time."""
@@ -100,3 +139,16 @@ def test_wide_published_geometry_properties_and_speed():
               f"{per_utt / 16000:.2f}x real time at 16 kHz, {per_utt / 22050:.2f}x at 22.05 kHz, {per_utt / 24000:.2f}x at 24 kHz")
         if Bs == 1:
             assert per_utt > 16000, "a single utterance of the published (16 kHz) geometry must run faster than real time"
+    # the published models themselves are mu-law 256 in / out: the same stack with the one-hot head
+    kw1 = dict(ONEHOT_WIDE, layers=24, stacks=4)
+    torch.manual_seed(1)
+    eng1 = tame_head_(wnv.WaveNet(**kw1).eval()).to("cuda")._get_engine()
+    cu = torch.randn(1, 4096, 80, device="cuda")
+    eng1.generate(B=1, T=4096, c_up=cu, seed=1, kernel=3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out1, _, _ = eng1.generate(B=1, T=4096, c_up=cu, seed=2, kernel=3)
+    torch.cuda.synchronize()
+    per_utt = 4096 / (time.perf_counter() - t0)
+    print(f"24-layer 512/512/256 mu-law-256 model, B = 1: {per_utt / 1e3:.1f} kSamples/s = {per_utt / 16000:.2f}x real time at 16 kHz")
+    assert torch.equal(out1.sum(1), torch.ones(1, 4096, device="cuda")) and per_utt > 16000

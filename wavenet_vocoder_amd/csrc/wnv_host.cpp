@@ -509,6 +509,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     }
     if (kernel == 3) {                     // wide models: one GROUP of 8 workgroups per layer (wnv_wide.hip); same fallback rules as the ring
         if (!wnv_wide_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the group-ring kernel does not cover this configuration: %s", wnv_wide_why_not(c, a->B));
+        HIP_TRY(zero_onehot_out());
         std::string err;
         wnv_status st = wnv_wide_generate(&h->wide_state, h->device, c, h->store, ga, s, err);
         if (st == WNV_OK) { h->last_kernel = 3; return WNV_OK; }

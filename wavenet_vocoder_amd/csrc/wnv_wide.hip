@@ -57,6 +57,9 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 struct WideParams {
     int L, nL, B, T, Tt, O, cin, cinp, kw, nz, dist, kpre, nkb;
     int head_x, head_li, fast;
+    int cin1, softmax, quantize;                          // first_conv input channels (1 = scalar input); categorical switches (wavenet.py:332-335)
+    int* index_out;
+    u64* hidmail;                                         // one-hot models: hidden layer of the head, HID[b][256] (head part A -> part B)
     unsigned tag_base;
     float skip_scale;
     const float *wm, *wn, *wo, *ws, *wsl, *bo, *bs, *cvec, *wpre;   // per (layer, slice) register / stream images (wsl: last layer's skip)
@@ -396,11 +399,139 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
     }
 }
 
+// ---- head of one-hot (mu-law categorical) models: TWO workgroups, because the hidden layer (256 x 256) and the output layer
+// (out_channels x 256, 256 x 256 for mu-law 256) fill a register file each.  Part A: skip sum -> ReLU -> 1x1 -> ReLU -> publish the
+// hidden vector.  Part B: 1x1 -> softmax -> OneHotCategorical (sample_categorical of wnv_sample.h: argmax(p_hat / e)) -> first_conv
+// of the next input (wavenet.py:315-319, :332-335, :297-308) -> publish h_0.  first_conv's matrix is K-major in memory: a sampled
+// class is one 2-KB row gather (bit-identical to F.linear with a one-hot input); teacher-forced inputs, an explicit initial input and
+// fed-back probabilities (quantize = False) take the dense mat-vec.
+__device__ void run_wide_head_a(const WideParams& p, float* smem) {
+    const HeadLds s = carve_head(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4 w1[32];
+    load_img<32>(w1, p.wh1, wave, lane);
+    const float b1 = tid < KWD ? p.bh1[tid] : 0.f;
+    const bool fast = p.fast != 0;                         // part B sits on the same XCD
+    if (tid == 0) s.flags[0] = 0;
+    __syncthreads();
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        for (int b = 0; b < p.B; ++b) {
+            if (wave < 2) {
+                if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+            if (tid < KWD) s.vs[tid] = fmaxf(s.vs[tid] * p.skip_scale, 0.f);                        // wavenet.py:313-316
+            __syncthreads();
+            s.ph[(wave >> 2) * KWD + (wave & 3) * 64 + lane] = dot_bcast<32>(w1, s.vs + 128 * (wave >> 2));
+            __syncthreads();
+            if (tid < KWD) st_granule(p.hidmail + (size_t)b * KWD + tid, tag, fmaxf(s.ph[tid] + s.ph[KWD + tid] + b1, 0.f), fast);   // wavenet.py:317-318
+            __syncthreads();
+        }
+    }
+}
+
+struct CatLds {
+    float *hid, *pout, *obuf, *nz, *vin;
+    int* ints;
+};
+__device__ __forceinline__ CatLds carve_cat(float* smem) {
+    CatLds s;
+    s.hid = smem; s.pout = s.hid + KWD; s.obuf = s.pout + 8 * 256; s.nz = s.obuf + 256; s.vin = s.nz + 256;
+    s.ints = reinterpret_cast<int*>(s.vin + 256);
+    return s;
+}
+constexpr size_t CAT_LDS_FLOATS = KWD + 8 * 256 + 3 * 256 + 16;
+
+__device__ void run_wide_head_b(const WideParams& p, bool fast_first, float* smem) {
+    const CatLds s = carve_cat(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int O = p.O;
+    float4 w2[32];                                         // rows lane + 64 q (q = 0 .. 3), K chunk 32 wave: [wave][q * 8 + c][lane][4]
+    load_img<32>(w2, p.wh2, wave, lane);
+    const float b2 = tid < O ? p.bh2[tid] : 0.f;
+    const float bf = p.bfirst[tid];
+    if (tid == 0) { s.ints[0] = 0; s.ints[1] = 127; }     // abort flag; sampled class
+    __syncthreads();
+    // first_conv of a dense O-vector (global memory or LDS) or of the one-hot class idx -> h_0 of step `tag_next`
+    auto send_input = [&](int b, const float* dense, int idx, unsigned tag_next) {
+        float h;
+        if (dense == nullptr) {
+            h = p.wfirst[(size_t)idx * RWD + tid] + bf;                                              // one row of the K-major matrix
+        } else {
+            for (int k = tid; k < O; k += WT) s.vin[k] = dense[k];
+            __syncthreads();
+            float acc = 0.f;
+            for (int k = 0; k < O; ++k) acc = fmaf(p.wfirst[(size_t)k * RWD + tid], s.vin[k], acc);
+            h = acc + bf;
+            __syncthreads();
+        }
+        st_granule(p.xmail + ((size_t)b * (p.L + 1)) * XW + GHD + tid, tag_next, h, fast_first);
+    };
+    for (int b = 0; b < p.B; ++b) {                        // wavenet.py:283-289: one-hot of class 127 unless given
+        const float* dense = p.Tt > 0 ? p.teacher + (size_t)b * p.Tt * O : (p.initial ? p.initial + (size_t)b * O : nullptr);
+        send_input(b, dense, 127, p.tag_base + 1u);
+    }
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        for (int b = 0; b < p.B; ++b) {
+            if (tid < O) s.nz[tid] = p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, b, tid, 2);   // e ~ Exp(1)
+            if (wave < 2) {
+                if (!recv128(p.hidmail + (size_t)b * KWD + 128 * wave, tag, s.hid + 128 * wave, p.status, 0x480u, lane)) s.ints[0] = 1;
+            }
+            __syncthreads();
+            if (s.ints[0]) return;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 wq[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) wq[c] = w2[q * 8 + c];
+                s.pout[wave * 256 + 64 * q + lane] = dot_bcast<8>(wq, s.hid + 32 * wave);
+            }
+            __syncthreads();
+            if (tid < O) {
+                float o = b2;
+#pragma unroll
+                for (int w = 0; w < 8; ++w) o += s.pout[w * 256 + tid];
+                s.obuf[tid] = o;                                                                     // wavenet.py:319
+                if (p.params_out) p.params_out[((size_t)b * O + tid) * p.T + t] = o;
+            }
+            __syncthreads();
+            if (wave == 0) {                                                                         // wavenet.py:332-335
+                const int idx = sample_categorical(O, s.obuf, s.nz, p.softmax, p.quantize, lane);
+                if (p.quantize) {
+                    if (lane == 0) {
+                        p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;                               // out is pre-zeroed by the host
+                        if (p.index_out) p.index_out[(size_t)b * p.T + t] = idx;
+                        s.ints[1] = idx;
+                    }
+                } else {
+                    for (int n = lane; n < O; n += 64) p.out[((size_t)b * O + n) * p.T + t] = s.obuf[n];
+                }
+            }
+            __syncthreads();
+            if (t + 1 < p.T) {                                                                       // wavenet.py:297-308 for step t + 1
+                const float* dense = nullptr;
+                if (t + 1 < p.Tt) dense = p.teacher + ((size_t)b * p.Tt + t + 1) * O;
+                else if (!p.quantize) dense = s.obuf;                                                // fed-back probabilities
+                send_input(b, dense, s.ints[1], tag + 1u);
+            }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ void __launch_bounds__(WT) wnv_wide_kernel(const WideParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int x = blockIdx.x & 7, li = blockIdx.x >> 3;
     if (x == p.head_x && li == p.head_li) {
-        run_wide_head(p, p.fast && p.head_x == 0, smem);                       // group 0 lives on XCD 0
+        if (p.cin1 == 1) run_wide_head(p, p.fast && p.head_x == 0, smem);      // group 0 lives on XCD 0
+        else run_wide_head_a(p, smem);
+        return;
+    }
+    if (p.cin1 > 1 && x == p.head_x && li == p.head_li + 1) {
+        run_wide_head_b(p, p.fast && p.head_x == 0, smem);
         return;
     }
     const int sl = li / PG, j = li % PG, l = x * p.nL + sl;
@@ -417,7 +548,7 @@ __global__ void __launch_bounds__(WT) wnv_wide_kernel(const WideParams p) {
 // =================================================================================================
 struct WnvWideState {
     int device = 0;
-    int L = 0, O = 0, cin = 0, cinp = 0, kw = 0, kpre = 0, nkb = 0;
+    int L = 0, O = 0, cin = 0, cinp = 0, kw = 0, kpre = 0, nkb = 0, cin1 = 1;
     float* d_w = nullptr;
     size_t o_wn = 0, o_wm = 0, o_wo = 0, o_ws = 0, o_wsl = 0, o_bo = 0, o_bs = 0, o_cvec = 0, o_wpre = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0, o_bh2 = 0, o_wf = 0, o_bf = 0;
     int* d_dil = nullptr;
@@ -433,13 +564,13 @@ struct WnvWideState {
 };
 
 static const char* wide_why_not(const wnv_config& c, int B) {
-    if (!c.scalar_input) return "one-hot models are not covered yet (scalar-input MoL / Gaussian only)";
-    if (c.out_channels > 64) return "needs out_channels <= 64";
+    if (c.scalar_input && c.out_channels > 64) return "scalar-input models need out_channels <= 64";
+    if (!c.scalar_input && c.out_channels > 256) return "one-hot models need out_channels <= 256";
     if (c.residual_channels > RWD || c.gate_channels > 2 * GHD) return "needs residual_channels <= 512 and gate_channels <= 512";
     if (c.skip_out_channels > KWD) return "needs skip_out_channels <= 256";
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 128) return "needs cin_channels <= 128";
-    if (c.layers > 31) return "needs layers <= 31 (8 workgroups per layer, 32 CUs per XCD, one more for the head)";
+    if (c.layers > 31) return "needs layers <= 31 (8 workgroups per layer, 32 CUs per XCD, one or two more for the head)";
     if (B > BMAX) return "more than 8 utterances per call";
     return nullptr;
 }
@@ -592,9 +723,12 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
         hist += (long long)(kw - 1) * dil[l] * RWD;
     }
     st->hist_layer_floats = hist;
-    // head: W1 rows (w & 3) 64 + lane, K half (w >> 2) -> [w][32][lane][4];  W2 row lane, K chunk 32 w -> [w][8][lane][4]
+    // head: W1 rows (w & 3) 64 + lane, K half (w >> 2) -> [w][32][lane][4];  W2: scalar models row lane, K chunk 32 w -> [w][8][lane][4];
+    // one-hot models rows lane + 64 q (q = 0 .. 3), K chunk 32 w -> [w][8 q + c][lane][4]
+    const int cin1 = c.scalar_input ? 1 : O;
+    st->cin1 = cin1;
     st->o_wh1 = alloc((size_t)8 * 32 * 64 * 4);
-    st->o_wh2 = alloc((size_t)8 * 8 * 64 * 4);
+    st->o_wh2 = alloc((size_t)8 * (cin1 > 1 ? 32 : 8) * 64 * 4);
     {
         const HostTensor& w1 = T("last_conv_layers.1.weight");         // (K, K, 1)
         const HostTensor& w2 = T("last_conv_layers.3.weight");         // (O, K, 1)
@@ -606,21 +740,24 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
                         const int k = 128 * (w >> 2) + 4 * cq + e;
                         blob[st->o_wh1 + (((size_t)w * 32 + cq) * 64 + lane) * 4 + e] = (row < Ka && k < Ka) ? w1.data[(size_t)row * Ka + k] : 0.f;
                     }
-                for (int cq = 0; cq < 8; ++cq)
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = 32 * w + 4 * cq + e;
-                        blob[st->o_wh2 + (((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = (lane < O && k < Ka) ? w2.data[(size_t)lane * Ka + k] : 0.f;
-                    }
+                for (int q = 0; q < (cin1 > 1 ? 4 : 1); ++q)
+                    for (int cq = 0; cq < 8; ++cq)
+                        for (int e = 0; e < 4; ++e) {
+                            const int k = 32 * w + 4 * cq + e, orow = lane + 64 * q;
+                            blob[st->o_wh2 + (((size_t)w * (cin1 > 1 ? 32 : 8) + 8 * q + cq) * 64 + lane) * 4 + e] =
+                                (orow < O && k < Ka) ? w2.data[(size_t)orow * Ka + k] : 0.f;
+                        }
             }
     }
     st->o_bh1 = alloc(KWD);
     std::copy(T("last_conv_layers.1.bias").data.begin(), T("last_conv_layers.1.bias").data.end(), blob.begin() + st->o_bh1);
-    st->o_bh2 = alloc(64);
+    st->o_bh2 = alloc(256);
     std::copy(T("last_conv_layers.3.bias").data.begin(), T("last_conv_layers.3.bias").data.end(), blob.begin() + st->o_bh2);
-    st->o_wf = alloc(RWD);
+    // first_conv: (R, 1, 1) for scalar input; one-hot models: (R, O, 1) stored K-major [O][512] (row k = column k of the matrix)
+    st->o_wf = alloc((size_t)cin1 * RWD);
     st->o_bf = alloc(RWD);
     for (int r = 0; r < Ra; ++r) {
-        blob[st->o_wf + r] = T("first_conv.weight").data[r];           // (R, 1, 1)
+        for (int k = 0; k < cin1; ++k) blob[st->o_wf + (size_t)k * RWD + r] = T("first_conv.weight").data[(size_t)r * cin1 + k];
         blob[st->o_bf + r] = T("first_conv.bias").data[r];
     }
     WIDE_HIP(hipMalloc((void**)&st->d_w, blob.size() * sizeof(float)));
@@ -654,17 +791,19 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     const int nL = (L + 7) / 8;                                      // layer groups per XCD
     // the head goes to the XCD of the last layer when that XCD has a free slot, else to the first XCD that has one
     int head_x = -1, head_li = -1;
+    const int n_head = st->cin1 > 1 ? 2 : 1;                        // one-hot models: the head is two workgroups
     auto groups_on = [&](int x) { return std::max(0, std::min(nL, L - x * nL)); };
     const int last_x = (L - 1) / nL;
     for (int k = 0; k < 8 && head_x < 0; ++k) {
         const int x = (last_x + k) % 8;
-        if (groups_on(x) * PG + 1 <= cus_per_xcd) { head_x = x; head_li = groups_on(x) * PG; }
+        if (groups_on(x) * PG + n_head <= cus_per_xcd) { head_x = x; head_li = groups_on(x) * PG; }
     }
     if (head_x < 0 || nL * PG > cus_per_xcd) { err = "wide kernel: not enough CUs per XCD for the layer groups + the head"; return WNV_ERR_UNSUPPORTED; }
     WideParams p{};
     p.L = L; p.nL = nL; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.O = st->O; p.cin = st->cin; p.cinp = st->cinp; p.kw = st->kw; p.nz = ga.nz;
     p.dist = c.output_distribution; p.kpre = st->kpre; p.nkb = st->nkb;
     p.head_x = head_x; p.head_li = head_li;
+    p.cin1 = st->cin1; p.softmax = ga.softmax; p.quantize = ga.quantize; p.index_out = ga.index_out;
     { const char* e = getenv("WNV_RING_FAST"); p.fast = !(e && e[0] == '0'); }
     p.skip_scale = (float)std::sqrt(1.0 / L);
     const float* w = st->d_w;
@@ -677,7 +816,8 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     // state: [status 64 B][X B (L+1) 768 u64][SK B (L+2) 256 u64][history B x 8 copies x layers]
     const size_t head_bytes = 64;
     const size_t n_x = (size_t)B * (L + 1) * XW, n_s = (size_t)B * (L + 2) * KWD;
-    const size_t mail_bytes = (n_x + n_s) * sizeof(u64);
+    const size_t n_hid = (size_t)B * KWD;
+    const size_t mail_bytes = (n_x + n_s + n_hid) * sizeof(u64);
     const size_t hist_bytes = (size_t)B * p.hist_b_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -701,16 +841,17 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     p.status = (unsigned int*)base;
     p.xmail = (u64*)(base + head_bytes);
     p.smail = p.xmail + n_x;
-    p.hist = (float*)(p.smail + n_s);
+    p.hidmail = p.smail + n_s;
+    p.hist = (float*)(p.hidmail + n_hid);
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.out = ga.out; p.params_out = ga.params_out;
-    const size_t lds = std::max(stage_lds_floats(p.kpre), HEAD_LDS_FLOATS) * sizeof(float);
+    const size_t lds = std::max(std::max(stage_lds_floats(p.kpre), HEAD_LDS_FLOATS), CAT_LDS_FLOATS) * sizeof(float);
     if (lds > 160 * 1024) { err = "wide kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
     WIDE_HIP(hipFuncSetAttribute((const void*)wnv_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         int per_cu = 0;
         WIDE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wnv_wide_kernel, WT, lds));
-        const int live = L * PG + 1;
+        const int live = L * PG + n_head;
         if (per_cu < 1 || live > st->ncu * per_cu) {
             char buf[160];
             snprintf(buf, sizeof buf, "wide kernel: %d workgroups must be co-resident but the device holds %d", live, st->ncu * std::max(per_cu, 0));
@@ -718,7 +859,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
             return WNV_ERR_UNSUPPORTED;
         }
     }
-    const int max_li = std::max(nL * PG - 1, head_li);
+    const int max_li = std::max(nL * PG - 1, head_li + n_head - 1);
     const int grid = 8 * (max_li + 1);
     hipLaunchKernelGGL(wnv_wide_kernel, dim3(grid), dim3(WT), lds, stream, p);
     WIDE_HIP(hipGetLastError());
