@@ -152,6 +152,27 @@ def test_ring_multispeaker_16_per_gpu_vs_oracle():
     assert_free_run_agrees_until_near_tie(out, want, params, wparams, tape, kw, t0=Tt - 1, what="cfg4 free part")
 
 
+def test_ring_recipe_batch_of_32_vs_oracle():
+    """The recipes' inference batch (egs/mol/run.sh:31: 32 utterances): four utterances share every ring like a systolic array and a
+    second tap workgroup per layer joins."""
+    name, B, Tt, T = "cfg2_mol", 32, 192, 256
+    kw = CONFIGS[name]
+    m = build(name)
+    o = Oracle(oracle_config(kw), m.state_dict())
+    c, _ = inputs(name, B, T)
+    x = teacher(kw, B, Tt)
+    tape = tape_for(kw, T, B, 2)
+    torch.set_num_threads(8)
+    want, wparams = o.incremental_forward(test_inputs=x, c=c, T=T, noise=tape, return_params=True)
+    eng = m.to("cuda")._get_engine()
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    out, params, _ = eng.generate(B=B, T=T, c_up=c_up, teacher=x.transpose(1, 2).contiguous().cuda(), noise=tape.cuda(), want_params=True, kernel=2)
+    out, params = out.cpu(), params.cpu()
+    assert float((params[:, :, :Tt] - wparams[:, :, :Tt]).abs().max()) < TOL
+    assert_match_or_near_tie(out[:, :, :Tt - 1], want[:, :, :Tt - 1], wparams[:, :, :Tt - 1], tape[:Tt - 1], kw, what="B = 32 forced part")
+    assert_free_run_agrees_until_near_tie(out, want, params, wparams, tape, kw, t0=Tt - 1, what="B = 32 free part")
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
 def test_gaussian_three_channel_head(kernel):
     """out_channels == 3 with output_distribution "Normal": mean = channel 1, log-scale = channel 2, channel 0 unused

@@ -159,9 +159,16 @@ def test_unsupported_configs_say_so():
     kw = dict(CONFIGS["cfg2_mol"], residual_channels=256, gate_channels=512, skip_out_channels=256)      # wider than one CU's layer
     torch.manual_seed(0)
     eng = wnv.WaveNet(**kw).eval().to("cuda")._get_engine()
+    cz = torch.zeros(1, 16, 80, device="cuda")
     with pytest.raises(NotImplementedError, match="ring kernel"):
-        eng.generate(B=1, T=16, c_up=torch.zeros(1, 16, 80, device="cuda"), kernel=2)
-    out, _, _ = eng.generate(B=1, T=16, c_up=torch.zeros(1, 16, 80, device="cuda"), kernel=0)             # auto: the generic kernel
+        eng.generate(B=1, T=16, c_up=cz, kernel=2)
+    out, _, _ = eng.generate(B=1, T=16, c_up=cz, kernel=0)            # auto: the group ring for wide models
+    assert eng.last_kernel() == 3 and torch.isfinite(out).all()
+    kw = dict(kw, skip_out_channels=512)                              # 512 skip channels on a wide model: neither persistent kernel
+    eng = wnv.WaveNet(**kw).eval().to("cuda")._get_engine()
+    with pytest.raises(NotImplementedError, match="group-ring kernel"):
+        eng.generate(B=1, T=16, c_up=cz, kernel=3)
+    out, _, _ = eng.generate(B=1, T=16, c_up=cz, kernel=0)            # auto: the generic kernel
     assert eng.last_kernel() == 1 and torch.isfinite(out).all()
 
 
