@@ -52,6 +52,10 @@ typedef enum wnv_dist {
     WNV_DIST_NORMAL = 2        /* (mixture of) Gaussians, mixture.py:221-270                              */
 } wnv_dist;
 
+typedef enum wnv_upsample_act {    /* upsample_activation of upsample.UpsampleNetwork (upsample.py:30,47-49)                     */
+    WNV_UPACT_NONE = 0, WNV_UPACT_RELU = 1, WNV_UPACT_LEAKY_RELU = 2, WNV_UPACT_TANH = 3, WNV_UPACT_SIGMOID = 4, WNV_UPACT_ELU = 5
+} wnv_upsample_act;
+
 typedef enum wnv_upsample_kind {
     WNV_UPSAMPLE_NONE = 0,     /* upsample_conditional_features=False: c arrives at sample rate           */
     WNV_UPSAMPLE_CONVIN = 1,   /* upsample.ConvInUpsampleNetwork  (upsample.py:69-85)                      */
@@ -77,9 +81,11 @@ typedef struct wnv_config {
     int32_t upsample_kind;          /* wnv_upsample_kind                                                  */
     int32_t n_upsample_scales;
     int32_t upsample_scales[WNV_MAX_UPSAMPLE_STAGES];
-    int32_t freq_axis_kernel_size;  /* only 1 is implemented (all reference presets)                      */
+    int32_t freq_axis_kernel_size;  /* odd, <= 15; taps of the upsampling FIRs along the mel-bin axis (1 in every preset) */
     int32_t cin_pad;
-    int32_t reserved[8];
+    int32_t upsample_activation;    /* wnv_upsample_act: nn module applied after every upsampling stage (upsample.py:47-49) */
+    float   upsample_activation_param; /* LeakyReLU negative_slope / ELU alpha                             */
+    int32_t reserved[6];
 } wnv_config;
 
 /* One named tensor of a reference state_dict.  `name` is the state_dict key, e.g.

@@ -56,6 +56,8 @@ class OracleConfig:
     upsample_net: str = "ConvInUpsampleNetwork"
     upsample_scales: List[int] = field(default_factory=lambda: [4, 4, 4, 4])
     freq_axis_kernel_size: int = 1
+    upsample_activation: str = "none"                      # upsample.py:30,47-49: getattr(nn, name)(**params) after every stage
+    upsample_activation_params: Dict[str, float] = field(default_factory=dict)
     cin_pad: int = 0
     scalar_input: bool = False
     use_speaker_embedding: bool = False
@@ -281,10 +283,14 @@ class Oracle:
             pre = "upsample_net.up_layers."
         c = c.unsqueeze(1)                                                   # upsample.py:58
         fk = cfg.freq_axis_kernel_size
+        act = None if cfg.upsample_activation == "none" else getattr(torch.nn, cfg.upsample_activation)(**cfg.upsample_activation_params)
+        stride = 2 if act is None else 3                                     # up_layers = [stretch, conv(, activation)] per scale
         for i, s in enumerate(cfg.upsample_scales):
             c = F.interpolate(c, scale_factor=(1, s), mode="nearest")        # upsample.py:19-21
-            w = self.st[f"{pre}{2 * i + 1}.weight"]
+            w = self.st[f"{pre}{stride * i + 1}.weight"]
             c = F.conv2d(c, w, padding=((fk - 1) // 2, s))                   # upsample.py:39-42
+            if act is not None:
+                c = act(c)                                                   # upsample.py:47-49
         c = c.squeeze(1)
         if not conv_in:
             indent = cfg.cin_pad * int(np.prod(cfg.upsample_scales))         # upsample.py:36,64-65

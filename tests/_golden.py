@@ -43,6 +43,9 @@ def oracle_config(kwargs):
         upsample_conditional_features=kwargs.get("upsample_conditional_features", False),
         upsample_net=kwargs.get("upsample_net", "ConvInUpsampleNetwork"),
         upsample_scales=list(up.get("upsample_scales", [4, 4, 4, 4])),
+        freq_axis_kernel_size=up.get("freq_axis_kernel_size", 1),
+        upsample_activation=up.get("upsample_activation", "none"),
+        upsample_activation_params=dict(up.get("upsample_activation_params", {})),
         cin_pad=kwargs.get("cin_pad", 0), scalar_input=kwargs.get("scalar_input", False),
         use_speaker_embedding=kwargs.get("use_speaker_embedding", False),
         output_distribution=kwargs.get("output_distribution", "Logistic"))

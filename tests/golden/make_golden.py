@@ -87,6 +87,17 @@ CASES = {
     "ring_onehot_r128": (dict(out_channels=256, layers=2, stacks=1, residual_channels=128, gate_channels=256,
                               skip_out_channels=128, kernel_size=3, dropout=0.0, cin_channels=8), 2, 48, 32,
                          {"c_full": True, "store": "wn"}),
+    # the upsampler options no preset uses (upsample.py:30-49): a per-stage activation and a FIR that also spans the mel-bin axis
+    "mol_upsample_act_freq3": (dict(out_channels=30, cin_channels=6, cin_pad=1, scalar_input=True,
+                                    upsample_conditional_features=True,
+                                    upsample_params=dict(upsample_scales=[2, 4], cin_channels=6, cin_pad=1, freq_axis_kernel_size=3,
+                                                         upsample_activation="LeakyReLU", upsample_activation_params={"negative_slope": 0.4}),
+                                    **COMPACT), 2, 40, 40, {}),
+    "gaussian_upsample_plain_elu": (dict(out_channels=2, cin_channels=5, cin_pad=1, scalar_input=True, output_distribution="Normal",
+                                         upsample_conditional_features=True, upsample_net="UpsampleNetwork",
+                                         upsample_params=dict(upsample_scales=[4, 2], cin_pad=1, freq_axis_kernel_size=5,
+                                                              upsample_activation="ELU", upsample_activation_params={"alpha": 0.7}),
+                                         **COMPACT), 2, 40, 40, {}),
 }
 
 

@@ -197,7 +197,9 @@ def _host_only_engine(kw):
                       scalar_input=kw.get("scalar_input", False), output_distribution=kw.get("output_distribution", "Logistic"),
                       upsample_net=kw.get("upsample_net", "ConvInUpsampleNetwork") if cond else None,
                       upsample_scales=up.get("upsample_scales", []) if cond else [],
-                      freq_axis_kernel_size=up.get("freq_axis_kernel_size", 1), cin_pad=kw.get("cin_pad", 0))
+                      freq_axis_kernel_size=up.get("freq_axis_kernel_size", 1), cin_pad=kw.get("cin_pad", 0),
+                      upsample_activation=up.get("upsample_activation", "none") if cond else "none",
+                      upsample_activation_params=up.get("upsample_activation_params", {}) if cond else {})
     h = C.c_void_p()
     _lib.check(_lib.lib().wnv_create(C.byref(cfg), -1, C.byref(h)))
     return h

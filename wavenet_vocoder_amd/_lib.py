@@ -21,6 +21,9 @@ LIB_PATH = os.environ.get("WNV_LIB") or os.path.join(os.path.dirname(os.path.abs
 
 DIST = {"categorical": 0, "Logistic": 1, "Normal": 2}
 UPSAMPLE = {None: 0, "none": 0, "ConvInUpsampleNetwork": 1, "UpsampleNetwork": 2}
+# upsample_activation (upsample.py:30,47-49: getattr(nn, name)(**params)) -> (wnv_upsample_act, the keyword of its one parameter)
+UPSAMPLE_ACT = {"none": (0, None), "ReLU": (1, None), "LeakyReLU": (2, "negative_slope"), "Tanh": (3, None), "Sigmoid": (4, None), "ELU": (5, "alpha")}
+UPSAMPLE_ACT_DEFAULT = {"negative_slope": 0.01, "alpha": 1.0}
 
 # status codes -> Python exceptions (include/wnv.h "Conventions")
 _STATUS_EXC = {
@@ -46,7 +49,8 @@ class Config(C.Structure):
         ("n_speakers", C.c_int32), ("use_speaker_embedding", C.c_int32), ("scalar_input", C.c_int32),
         ("output_distribution", C.c_int32), ("upsample_kind", C.c_int32), ("n_upsample_scales", C.c_int32),
         ("upsample_scales", C.c_int32 * WNV_MAX_UPSAMPLE_STAGES), ("freq_axis_kernel_size", C.c_int32),
-        ("cin_pad", C.c_int32), ("reserved", C.c_int32 * 8),
+        ("cin_pad", C.c_int32), ("upsample_activation", C.c_int32), ("upsample_activation_param", C.c_float),
+        ("reserved", C.c_int32 * 6),
     ]
 
 

@@ -82,8 +82,10 @@ static std::vector<Expect> expected_tensors(const wnv_config& c) {
             e.push_back({"upsample_net.conv_in.weight", {c.cin_channels, c.cin_channels, 2 * c.cin_pad + 1}});
             pre = "upsample_net.upsample.up_layers.";
         }
+        // up_layers: [Stretch2d, Conv2d(, activation)] per scale (upsample.py:38-49): the conv sits at index 2 i + 1, or 3 i + 1
+        const int stride = c.upsample_activation != WNV_UPACT_NONE ? 3 : 2;
         for (int i = 0; i < c.n_upsample_scales; ++i)
-            e.push_back({pre + std::to_string(2 * i + 1) + ".weight",
+            e.push_back({pre + std::to_string(stride * i + 1) + ".weight",
                          {1, 1, c.freq_axis_kernel_size, 2 * c.upsample_scales[i] + 1}});
     }
     return e;
@@ -115,7 +117,9 @@ static wnv_status validate_config(const wnv_config* c) {
     if (c->upsample_kind < 0 || c->upsample_kind > 2) return fail(WNV_ERR_INVALID_ARG, "unknown upsample_kind");
     if (c->upsample_kind != WNV_UPSAMPLE_NONE) {
         if (c->n_upsample_scales < 0 || c->n_upsample_scales > WNV_MAX_UPSAMPLE_STAGES) return fail(WNV_ERR_INVALID_ARG, "n_upsample_scales");
-        if (c->freq_axis_kernel_size != 1) return fail(WNV_ERR_UNSUPPORTED, "freq_axis_kernel_size != 1 is not implemented");
+        if (c->freq_axis_kernel_size < 1 || c->freq_axis_kernel_size > 15 || c->freq_axis_kernel_size % 2 == 0)
+            return fail(WNV_ERR_UNSUPPORTED, "freq_axis_kernel_size %d: an odd size <= 15 is implemented", c->freq_axis_kernel_size);
+        if (c->upsample_activation < 0 || c->upsample_activation > WNV_UPACT_ELU) return fail(WNV_ERR_INVALID_ARG, "unknown upsample_activation %d", c->upsample_activation);
         for (int i = 0; i < c->n_upsample_scales; ++i)
             if (c->upsample_scales[i] < 1) return fail(WNV_ERR_INVALID_ARG, "upsample scale < 1");
     }
@@ -331,7 +335,7 @@ static wnv_status pack(wnv_engine* h) {
             h->up_off.push_back(-1);
         }
         for (int i = 0; i < c.n_upsample_scales; ++i) {
-            const HostTensor& w = T(pre + std::to_string(2 * i + 1) + ".weight");
+            const HostTensor& w = T(pre + std::to_string((c.upsample_activation != WNV_UPACT_NONE ? 3 : 2) * i + 1) + ".weight");
             h->up_off.push_back((long long)u.size());
             u.insert(u.end(), w.data.begin(), w.data.end());
         }
@@ -419,7 +423,8 @@ extern "C" wnv_status wnv_upsample(wnv_handle h, const float* c_in, int32_t B, i
         const int sc = c.upsample_scales[i];
         const long long indent = (last && c.upsample_kind == WNV_UPSAMPLE_PLAIN) ? (long long)c.cin_pad * total : 0;
         float* dst = last ? c_up : bufs[which];
-        HIP_TRY(wnv_launch_stretch_fir(cur, h->d_up + h->up_off[1 + i], dst, B, cin, Tcur, sc, last ? 1 : 0, indent, s));
+        HIP_TRY(wnv_launch_stretch_fir(cur, h->d_up + h->up_off[1 + i], dst, B, cin, Tcur, sc, last ? 1 : 0, indent, c.freq_axis_kernel_size,
+                                       c.upsample_activation, c.upsample_activation_param, s));
         cur = dst; which ^= 1;
         Tcur *= sc;
     }

@@ -33,10 +33,24 @@ __global__ void wnv_conv_in_kernel(const float* __restrict__ c, const float* __r
     }
 }
 
-// out[row][j] = sum_{m=0..2s} w[m] * rep[j + m - s],  rep[q] = in[row][q / s] for 0 <= q < Tin*s else 0
+// the optional per-stage activation of upsample.py:47-49 (`getattr(nn, upsample_activation)(**params)`): the ones with one parameter at most
+__device__ __forceinline__ float up_act(float x, int act, float a) {
+    switch (act) {
+        case 1: return fmaxf(x, 0.f);                                   // nn.ReLU
+        case 2: return x >= 0.f ? x : a * x;                            // nn.LeakyReLU(negative_slope = a)
+        case 3: return tanhf(x);                                        // nn.Tanh
+        case 4: return 1.0f / (1.0f + expf(-x));                        // nn.Sigmoid
+        case 5: return x > 0.f ? x : a * expm1f(x);                     // nn.ELU(alpha = a)
+        default: return x;
+    }
+}
+
+// out[row][j] = act( sum_f sum_{m=0..2s} w[f][m] * rep[row + f - fk/2][j + m - s] ),  rep[r][q] = in[r][q / s] for 0 <= q < Tin*s and
+// 0 <= r < cin, else 0: Conv2d(1, 1, (fk, 2s+1), padding=((fk-1)/2, s)) over the nearest-stretched map (upsample.py:38-45); fk = 1 in
+// every reference preset
 __global__ void wnv_stretch_fir_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                        float* __restrict__ out, int B, int cin, long long Tin, int scale,
-                                       int transpose_out, long long indent) {
+                                       int transpose_out, long long indent, int fk, int act, float act_p) {
     const long long Tfull = Tin * scale;
     const long long Tout = Tfull - 2 * indent;
     const long long total = (long long)B * cin * Tout;
@@ -53,13 +67,19 @@ __global__ void wnv_stretch_fir_kernel(const float* __restrict__ in, const float
             ch = (int)((i / Tout) % cin);
             b = (int)(i / (Tout * (long long)cin));
         }
-        const float* row = in + ((size_t)b * cin + ch) * Tin;
         const long long jj = j + indent;
         float acc = 0.f;
-        for (int mtap = 0; mtap <= 2 * scale; ++mtap) {
-            const long long q = jj + mtap - scale;
-            if (q >= 0 && q < Tfull) acc = fmaf(w[mtap], row[q / scale], acc);
+        for (int f = 0; f < fk; ++f) {
+            const int r = ch + f - (fk - 1) / 2;
+            if (r < 0 || r >= cin) continue;
+            const float* row = in + ((size_t)b * cin + r) * Tin;
+            const float* wf = w + (size_t)f * (2 * scale + 1);
+            for (int mtap = 0; mtap <= 2 * scale; ++mtap) {
+                const long long q = jj + mtap - scale;
+                if (q >= 0 && q < Tfull) acc = fmaf(wf[mtap], row[q / scale], acc);
+            }
         }
+        acc = up_act(acc, act, act_p);
         if (transpose_out) out[((size_t)b * Tout + j) * cin + ch] = acc;
         else out[((size_t)b * cin + ch) * Tout + j] = acc;
     }
@@ -71,7 +91,7 @@ __global__ void wnv_stretch_fir_kernel(const float* __restrict__ in, const float
 constexpr int UT = 256;
 __global__ void __launch_bounds__(UT) wnv_stretch_fir_tm_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                                                 float* __restrict__ out, int cin, long long Tin, int scale,
-                                                                long long indent, long long Tout, int ni, int tiles) {
+                                                                long long indent, long long Tout, int ni, int tiles, int act, float act_p) {
     extern __shared__ float win[];                         // [cin][ni + 2 (+1: odd stride)]
     const int tid = threadIdx.x;
     const int b = blockIdx.x / tiles;
@@ -100,7 +120,7 @@ __global__ void __launch_bounds__(UT) wnv_stretch_fir_tm_kernel(const float* __r
         } else {
             for (int m = 0; m <= 2 * scale; ++m) acc = fmaf(w[m], row[(tl + m) / scale], acc);
         }
-        dst[i] = acc;
+        dst[i] = up_act(acc, act, act_p);
     }
 }
 
@@ -133,9 +153,9 @@ hipError_t wnv_launch_conv_in(const float* c, const float* w, float* out, int B,
 }
 
 hipError_t wnv_launch_stretch_fir(const float* in, const float* w, float* out, int B, int cin, long long Tin,
-                                  int scale, int transpose_out, long long indent, hipStream_t s) {
+                                  int scale, int transpose_out, long long indent, int fk, int act, float act_p, hipStream_t s) {
     const long long total = (long long)B * cin * (Tin * scale - 2 * indent);
-    if (transpose_out && scale <= 16 && indent % scale == 0 && cin <= 2048) {
+    if (transpose_out && fk == 1 && scale <= 16 && indent % scale == 0 && cin <= 2048) {
         // LDS-tiled last stage: ni input samples per tile such that the window fits 48 KiB
         int ni = 64;
         while (ni > 1 && (size_t)cin * ((ni + 2) | 1) * sizeof(float) > 48 * 1024) ni >>= 1;
@@ -144,12 +164,12 @@ hipError_t wnv_launch_stretch_fir(const float* in, const float* w, float* out, i
         if ((long long)B * tiles <= 0x7fffffffll && (size_t)cin * ((ni + 2) | 1) * sizeof(float) <= 64 * 1024) {
             const size_t lds = (size_t)cin * ((ni + 2) | 1) * sizeof(float);
             hipLaunchKernelGGL(wnv_stretch_fir_tm_kernel, dim3((unsigned)(B * tiles)), dim3(UT), lds, s, in, w, out, cin, Tin, scale,
-                               indent, Tout, ni, (int)tiles);
+                               indent, Tout, ni, (int)tiles, act, act_p);
             return hipGetLastError();
         }
     }
     hipLaunchKernelGGL(wnv_stretch_fir_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w, out, B, cin, Tin,
-                       scale, transpose_out, indent);
+                       scale, transpose_out, indent, fk, act, act_p);
     return hipGetLastError();
 }
 

@@ -27,7 +27,8 @@ def require_gpu_tensor(t: torch.Tensor, what: str) -> None:
 def make_config(*, out_channels, layers, stacks, residual_channels, gate_channels, skip_out_channels,
                 kernel_size, cin_channels, gin_channels, n_speakers, use_speaker_embedding, scalar_input,
                 output_distribution, upsample_net: Optional[str], upsample_scales: Sequence[int],
-                freq_axis_kernel_size: int, cin_pad: int) -> Config:
+                freq_axis_kernel_size: int, cin_pad: int, upsample_activation: str = "none",
+                upsample_activation_params: Optional[dict] = None) -> Config:
     cfg = Config()
     cfg.abi_version = _lib.WNV_ABI_VERSION
     cfg.out_channels = out_channels
@@ -58,6 +59,15 @@ def make_config(*, out_channels, layers, stacks, residual_channels, gate_channel
     for i, s in enumerate(scales):
         cfg.upsample_scales[i] = int(s)
     cfg.freq_axis_kernel_size = int(freq_axis_kernel_size)
+    if upsample_activation not in _lib.UPSAMPLE_ACT:
+        raise NotImplementedError(f"upsample_activation {upsample_activation!r} (implemented: {sorted(_lib.UPSAMPLE_ACT)})")
+    kind, pname = _lib.UPSAMPLE_ACT[upsample_activation]
+    params = dict(upsample_activation_params or {})
+    params.pop("inplace", None)
+    if set(params) - ({pname} if pname else set()):
+        raise NotImplementedError(f"upsample_activation_params {sorted(params)} of {upsample_activation}")
+    cfg.upsample_activation = kind
+    cfg.upsample_activation_param = float(params.get(pname, _lib.UPSAMPLE_ACT_DEFAULT.get(pname, 0.0))) if pname else 0.0
     cfg.cin_pad = int(cin_pad)
     return cfg
 

@@ -43,12 +43,14 @@ def infer_config_kwargs(m) -> dict:
               cin_channels=int(m.cin_channels), gin_channels=gin,
               n_speakers=None if emb is None else int(emb.num_embeddings), use_speaker_embedding=emb is not None,
               scalar_input=bool(m.scalar_input), output_distribution=m.output_distribution,
-              upsample_net=None, upsample_scales=[], freq_axis_kernel_size=1, cin_pad=0)
+              upsample_net=None, upsample_scales=[], freq_axis_kernel_size=1, cin_pad=0, upsample_activation="none",
+              upsample_activation_params={})
     up = getattr(m, "upsample_net", None)
     if up is not None:
         kind = type(up).__name__
         inner = up.upsample if kind == "ConvInUpsampleNetwork" else up
-        scales, freq = [], 1
+        from ._lib import UPSAMPLE_ACT
+        scales, freq, act, act_params = [], 1, "none", {}
         for layer in inner.up_layers:
             name = type(layer).__name__
             if name == "Stretch2d":
@@ -57,13 +59,17 @@ def infer_config_kwargs(m) -> dict:
                 scales.append(int(layer.x_scale))
             elif hasattr(layer, "kernel_size"):
                 freq = int(layer.kernel_size[0])
+            elif name in UPSAMPLE_ACT:                                  # the per-stage activation module (upsample.py:47-49)
+                pname = UPSAMPLE_ACT[name][1]
+                act, act_params = name, ({pname: float(getattr(layer, pname))} if pname else {})
             else:
-                raise NotImplementedError(f"upsample activation {name} is not implemented (no reference preset uses one)")
+                raise NotImplementedError(f"upsample activation {name} is not implemented")
         total = 1
         for s in scales:
             total *= s
         cin_pad = (int(up.conv_in.kernel_size[0]) - 1) // 2 if kind == "ConvInUpsampleNetwork" else int(up.indent) // total
-        kw.update(upsample_net=kind, upsample_scales=scales, freq_axis_kernel_size=freq, cin_pad=cin_pad)
+        kw.update(upsample_net=kind, upsample_scales=scales, freq_axis_kernel_size=freq, cin_pad=cin_pad, upsample_activation=act,
+                  upsample_activation_params=act_params)
     return kw
 
 

@@ -46,10 +46,13 @@ class _SharedFir(WeightNormCompat, nn.Conv2d):
         nn.init.constant_(self.weight, 1.0 / (taps[0] * taps[1]))
 
 
-def _stages(scales, freq_axis_kernel_size, mode):
+def _stages(scales, freq_axis_kernel_size, mode, activation, activation_params):
+    """[stretch, FIR(, activation)] per scale -- the module indices are the reference's state_dict keys (upsample.py:38-49)."""
     layers = []
     for s in scales:
         layers += [Stretch2d(s, 1, mode), _SharedFir(s, freq_axis_kernel_size)]
+        if activation != "none":
+            layers.append(getattr(nn, activation)(**activation_params))
     return nn.ModuleList(layers)
 
 
@@ -57,12 +60,11 @@ class UpsampleNetwork(nn.Module):
     def __init__(self, upsample_scales, upsample_activation="none", upsample_activation_params={},
                  mode="nearest", freq_axis_kernel_size=1, cin_pad=0, cin_channels=80):
         super().__init__()
-        if upsample_activation != "none":
-            raise NotImplementedError("upsample_activation != 'none' (no reference preset uses one) is not implemented")
         self.upsample_scales = [int(s) for s in upsample_scales]
         self.freq_axis_kernel_size = freq_axis_kernel_size
+        self.upsample_activation, self.upsample_activation_params = upsample_activation, dict(upsample_activation_params)
         self.indent = cin_pad * prod(self.upsample_scales)          # samples dropped at either end
-        self.up_layers = _stages(self.upsample_scales, freq_axis_kernel_size, mode)
+        self.up_layers = _stages(self.upsample_scales, freq_axis_kernel_size, mode, upsample_activation, self.upsample_activation_params)
 
     def forward(self, c):
         y = c[:, None]                                               # (B, 1, C, T)
