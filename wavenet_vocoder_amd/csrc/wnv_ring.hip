@@ -85,7 +85,8 @@ struct RingParams {
     unsigned long long seed;
     float *out, *params_out;
     unsigned int* status;
-    unsigned long long* trace;         // optional [T_trace][S+1][8] wall-clock stamps of utterance 0 (debug)
+    unsigned long long* trace;         // optional [T_trace][upr][S+1][16] wall-clock stamps of ring 0's utterances (debug)
+    unsigned long long* trace_tap;     // optional [T_trace][16] stamps of the first pass of layer 0's tap workgroup, part 0
     int trace_t0, trace_n;
 };
 
@@ -321,9 +322,10 @@ __device__ __forceinline__ bool same_xcd_as(const RingParams& p, int reader_a, i
 
 // debug timeline: stamp slot k of (step t, position pos) with the device-wide 100 MHz wall clock
 constexpr int TRW = 16;            // stamp slots per (step, position)
+// (every utterance of ring 0 is stamped: utterance b = j n_rings is the j-th of that ring)
 __device__ __forceinline__ void stamp(const RingParams& p, int b, int t, int pos, int k, int who = 0) {
-    if (p.trace && b == 0 && (int)threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
-        p.trace[((size_t)(t - p.trace_t0) * (p.S + 1) + pos) * TRW + k] = wall_clock64();
+    if (p.trace && b % p.n_rings == 0 && (int)threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
+        p.trace[(((size_t)(t - p.trace_t0) * p.upr + b / p.n_rings) * (p.S + 1) + pos) * TRW + k] = wall_clock64();
 }
 
 // sum over the four adjacent lanes of a quad (the four K-quarters of one output channel): two DPP quad_perm adds
@@ -501,6 +503,9 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
         const int tp = t + 1;
         for (int b0 = part * TB; b0 < p.B; b0 += p.tap_parts * TB) {
             const int nb = min(TB, p.B - b0);
+#define TAP_STAMP(k) do { if (p.trace_tap && l == 0 && part == 0 && b0 == 0 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
+                              p.trace_tap[(size_t)(t - p.trace_t0) * TRW + (k)] = wall_clock64(); } while (0)
+            TAP_STAMP(0);
             // ---- h_l[t] of utterances b0 .. b0+nb-1, forwarded by their stages: wave w takes utterance b0 + w, two granules
             //      per lane (one 16-B load), and files the row in the history ring ------------------------------------------
             if (t >= 0 && wave < nb) {
@@ -516,27 +521,51 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
             }
             __syncthreads();
             if (s.flags[0]) return;
-            // ---- gather: the kw-1 older taps of step tp (zeros before t = 0: the rings start zeroed) and c[tp] ------------
-            for (int idx = tid; idx < nb * (hoff + p.cin); idx += RT) {
-                const int u = idx / (hoff + p.cin), e = idx - u * (hoff + p.cin);
-                const int b = b0 + u;
-                float v;
-                if (e < hoff) {
-                    const int k = e / RC, r = e - k * RC;
-                    v = p.hist[(size_t)b * p.hist_floats + p.lay_histoff[l] + (size_t)((tp + k * d) % rows) * RC + r];
-                } else {
-                    v = p.c_up[((size_t)b * p.T + tp) * p.cin + (e - hoff)];
+            TAP_STAMP(1);
+            // ---- gather: the kw-1 older taps of step tp (zeros before t = 0: the rings start zeroed) and c[tp].  Wave u fetches
+            //      utterance b0 + u: a tap is one contiguous 512-B history row, the conditioning row 4 cin bytes: 16-byte loads,
+            //      all of a lane's loads in flight before the first LDS store (two loads per lane for kw = 3, cin = 80) ---------
+            if (wave < nb) {
+                const int b = b0 + wave;
+                const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
+                const float* cb = p.c_up + ((size_t)b * p.T + tp) * p.cin;
+                float* xu = s.xin + (size_t)wave * kx;
+                const int ntap4 = hoff / 4, ncin4 = (p.cin & 3) == 0 ? p.cin / 4 : 0;
+                constexpr int GQ = 2;                                            // float4s per lane in flight (kw = 3, cin = 80: 84 float4s per utterance)
+                for (int i0 = 0; i0 < ntap4 + ncin4; i0 += 64 * GQ) {
+                    float4 v[GQ];
+#pragma unroll
+                    for (int q = 0; q < GQ; ++q) {
+                        const int i = i0 + 64 * q + lane;
+                        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (i < ntap4) {
+                            const int k = i >> 5, r4 = i & 31;                   // RC / 4 = 32 float4s per row
+                            v[q] = *reinterpret_cast<const float4*>(hb + (size_t)((tp + k * d) % rows) * RC + 4 * r4);
+                        } else if (i < ntap4 + ncin4) {
+                            v[q] = *reinterpret_cast<const float4*>(cb + 4 * (i - ntap4));
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < GQ; ++q) {
+                        const int i = i0 + 64 * q + lane;
+                        if (i < ntap4 + ncin4) *reinterpret_cast<float4*>(xu + 4 * i) = v[q];
+                    }
                 }
-                s.xin[(size_t)u * kx + e] = v;
+                if (ncin4 == 0)                                                  // cin not a multiple of 4: scalar conditioning row
+                    for (int e = lane; e < p.cin; e += 64) xu[hoff + e] = cb[e];
             }
             __syncthreads();
+            TAP_STAMP(2);
             // ---- mat-vec for all utterances of the pass, four at a time (accumulators + weights must fit the register file):
             //      VGPR rows, then LDS rows, then whatever streams -----------------------------------------------------------
 #pragma unroll 1
             for (int u0 = 0; u0 < nb; u0 += 4) {
-                float4 acc[4];
+                // packed FMAs (v_pk_fma_f32: two outputs per instruction, the input broadcast into both halves): this loop is what a
+                // pass costs -- 336 rows x 256 outputs x 8 utterances = 688 k MACs per workgroup -- and the pass time of the tap
+                // workgroups is what bounds the throughput mode (B >= 32: two passes per part and step)
+                f2 acc[4][2];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < 4; ++u) acc[u][0] = acc[u][1] = f2{0.f, 0.f};
                 const float* xb = s.xin + (size_t)u0 * kx + k0;
 #pragma unroll
                 for (int r4 = 0; r4 < KR_MAX / 4; ++r4) {
@@ -547,8 +576,9 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             const float4 w = wreg[4 * r4 + e];
-                            acc[u].x = fmaf(w.x, xs[e], acc[u].x); acc[u].y = fmaf(w.y, xs[e], acc[u].y);
-                            acc[u].z = fmaf(w.z, xs[e], acc[u].z); acc[u].w = fmaf(w.w, xs[e], acc[u].w);
+                            const f2 xx = f2{xs[e], xs[e]};
+                            acc[u][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[u][0]);
+                            acc[u][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[u][1]);
                         }
                     }
                 }
@@ -557,8 +587,9 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float xs = xb[(size_t)u * kx + p.kreg_rows + r];
-                        acc[u].x = fmaf(w.x, xs, acc[u].x); acc[u].y = fmaf(w.y, xs, acc[u].y);
-                        acc[u].z = fmaf(w.z, xs, acc[u].z); acc[u].w = fmaf(w.w, xs, acc[u].w);
+                        const f2 xx = f2{xs, xs};
+                        acc[u][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[u][0]);
+                        acc[u][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[u][1]);
                     }
                 }
                 for (int k = k0 + kres; k < k0 + p.kper && k < p.kpre; ++k) {
@@ -566,13 +597,14 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const float xs = xb[(size_t)u * kx + k - k0];
-                        acc[u].x = fmaf(w.x, xs, acc[u].x); acc[u].y = fmaf(w.y, xs, acc[u].y);
-                        acc[u].z = fmaf(w.z, xs, acc[u].z); acc[u].w = fmaf(w.w, xs, acc[u].w);
+                        const f2 xx = f2{xs, xs};
+                        acc[u][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[u][0]);
+                        acc[u][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[u][1]);
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
-                    *reinterpret_cast<float4*>(s.part + ((size_t)u * RW + wave) * GC + lane * 4) = acc[u];
+                    *reinterpret_cast<float4*>(s.part + ((size_t)u * RW + wave) * GC + lane * 4) = make_float4(acc[u][0].x, acc[u][0].y, acc[u][1].x, acc[u][1].y);
                 __syncthreads();
                 // reduce over the waves and hand pre_l[tp] to the stages: thread (u, n4) finishes four adjacent outputs of
                 // utterance u0 + u -- waves 0-1 serve u = 0, waves 2-3 u = 1, ... -- and the first wave of each pair publishes
@@ -597,12 +629,18 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                         }
                         if (n4 < GC / 4) bulk_store16(rec + 4 + 4 * n4, v);
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __syncthreads();                                             // both waves of the pair have drained their stores
-                    if (live && (tid & 127) == 0) st_granule(reinterpret_cast<u64*>(rec), p.tag_base + (unsigned)tp + 1u, 0.f, false);
                 }
-                __syncthreads();
+                __syncthreads();                                                 // s.part is free for the next four utterances
+                TAP_STAMP(3 + u0 / 4);
             }
+            // every payload of the pass has been issued: ONE drain (the write-through stores' acknowledgements take ~1 us), then
+            // the tag granules of all utterances
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            TAP_STAMP(5);
+            if (tid < nb)
+                st_granule(reinterpret_cast<u64*>(p.pmail + ((size_t)(b0 + tid) * p.L + l) * (4 + GC)), p.tag_base + (unsigned)tp + 1u, 0.f, false);
+#undef TAP_STAMP
         }
     }
 }
@@ -1619,10 +1657,11 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const int trace_n = 8;
     size_t trace_words = 0;
     if (trace_path && *trace_path && p.T > 64) {
-        trace_words = (size_t)trace_n * (st->S + 1) * TRW;
+        trace_words = (size_t)trace_n * upr * (st->S + 1) * TRW + (size_t)trace_n * TRW;
         RING_HIP(hipMalloc((void**)&d_trace, trace_words * sizeof(unsigned long long)));
         RING_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
+        p.trace_tap = d_trace + (size_t)trace_n * upr * (st->S + 1) * TRW;
     }
     if (NK == 1) hipLaunchKernelGGL(wnv_ring_kernel<1>, dim3(grid), dim3(RT), lds, stream, p);
     else if (NK == 2) hipLaunchKernelGGL(wnv_ring_kernel<2>, dim3(grid), dim3(RT), lds, stream, p);
@@ -1643,17 +1682,36 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         RING_HIP(hipMemcpy(tr.data(), d_trace, trace_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         (void)hipFree(d_trace);
         if (FILE* f = fopen(trace_path, "w")) {
-            fprintf(f, "# step pos(S=head) stamps[0..4] in ns relative to the head's send of the first traced step (100 MHz wall clock)\n");
-            const unsigned long long t00 = tr[((size_t)0 * (st->S + 1) + st->S) * TRW + 0];
+            fprintf(f, "# step pos(S=head) stamps in ns relative to the head's send of the first traced step (100 MHz wall clock); utterance 0 of ring 0\n");
+            const unsigned long long t00 = tr[(((size_t)0 * upr + 0) * (st->S + 1) + st->S) * TRW + 0];
             for (int tt = 0; tt < trace_n; ++tt)
                 for (int pos = 0; pos <= st->S; ++pos) {
                     fprintf(f, "%d %d", p.trace_t0 + tt, pos);
                     for (int k = 0; k < TRW; ++k) {
-                        const unsigned long long v = tr[((size_t)tt * (st->S + 1) + pos) * TRW + k];
+                        const unsigned long long v = tr[(((size_t)tt * upr + 0) * (st->S + 1) + pos) * TRW + k];
                         fprintf(f, " %lld", v ? (long long)(v - t00) * 10 : -1LL);
                     }
                     fprintf(f, "\n");
                 }
+            for (int tt = 0; tt < trace_n; ++tt) {                   // first pass of layer 0's tap workgroup (part 0): "#tap step stamps"
+                fprintf(f, "#tap %d", p.trace_t0 + tt);
+                for (int k = 0; k < TRW; ++k) {
+                    const unsigned long long v = tr[(size_t)trace_n * upr * (st->S + 1) * TRW + (size_t)tt * TRW + k];
+                    fprintf(f, " %lld", v ? (long long)(v - t00) * 10 : -1LL);
+                }
+                fprintf(f, "\n");
+            }
+            // the other utterances of ring 0 (when the ring carries several): "#u j step pos stamps" on the same clock
+            for (int j = 1; j < upr; ++j)
+                for (int tt = 0; tt < trace_n; ++tt)
+                    for (int pos = 0; pos <= st->S; ++pos) {
+                        fprintf(f, "#u %d %d %d", j, p.trace_t0 + tt, pos);
+                        for (int k = 0; k < TRW; ++k) {
+                            const unsigned long long v = tr[(((size_t)tt * upr + j) * (st->S + 1) + pos) * TRW + k];
+                            fprintf(f, " %lld", v ? (long long)(v - t00) * 10 : -1LL);
+                        }
+                        fprintf(f, "\n");
+                    }
             fclose(f);
         }
     }
