@@ -582,14 +582,20 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                         }
                     }
                 }
-                for (int r = 0; r < p.klds_rows; ++r) {
-                    const float4 w = s.wl[((size_t)wave * p.klds_rows + r) * 64 + lane];
+                for (int r = 0; r < p.klds_rows; r += 4) {                     // klds_rows is a multiple of 4: one 16-byte x read per utterance
+                    float4 w[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = s.wl[((size_t)wave * p.klds_rows + r + e) * 64 + lane];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
-                        const float xs = xb[(size_t)u * kx + p.kreg_rows + r];
-                        const f2 xx = f2{xs, xs};
-                        acc[u][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[u][0]);
-                        acc[u][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[u][1]);
+                        const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)u * kx + p.kreg_rows + r);
+                        const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const f2 xx = f2{xs[e], xs[e]};
+                            acc[u][0] = __builtin_elementwise_fma(f2{w[e].x, w[e].y}, xx, acc[u][0]);
+                            acc[u][1] = __builtin_elementwise_fma(f2{w[e].z, w[e].w}, xx, acc[u][1]);
+                        }
                     }
                 }
                 for (int k = k0 + kres; k < k0 + p.kper && k < p.kpre; ++k) {
@@ -1625,8 +1631,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     // tap workgroups: K rows per wave (a multiple of 4), first in VGPRs, then in LDS, the remainder streams from L2
     p.kper = (((st->kpre + RW - 1) / RW) + 3) & ~3;
     p.kreg_rows = std::min(p.kper, KR_MAX);
-    p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);
-    while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 150 * 1024) --p.klds_rows;
+    p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);                      // multiples of 4 (kper is one)
+    while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 150 * 1024) p.klds_rows -= 4;
     p.ring_blocks = rstride * P;
     const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
                                 st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
