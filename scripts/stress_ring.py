@@ -49,3 +49,31 @@ for name, Bs in (("cfg1_mulaw256", (1, 8)), ("cfg4_mol_multispeaker", (8, 16))):
             if first is None: first = out.clone()
             assert torch.equal(out, first) and torch.isfinite(out).all(), (name, B, i)
     print(f"{name}: 20 launches each at B = {Bs}: identical ({time.time()-t0:.1f} s)")
+# more utterances per ring than round 1 exercised, and the group-ring kernel for wide models
+t0 = time.time()
+for B in (40, 48, 56, 64):
+    T = 1024
+    out, _, _ = eng.generate(B=B, T=T, c_up=cond(B, T, B), seed=B, kernel=2)
+    ref, _, _ = eng.generate(B=B, T=T, c_up=cond(B, T, B), seed=B, kernel=2)
+    assert torch.equal(out, ref) and torch.isfinite(out).all(), B
+print(f"batch sizes 40..64: deterministic, finite ({time.time()-t0:.1f} s)")
+from tests._configs import inputs
+wm = build("wide_mol_512").to("cuda")
+we = wm._get_engine()
+t0 = time.time()
+for B in (1, 2, 3, 5, 8):
+    T = 1024
+    c, _ = inputs("wide_mol_512", B, T)
+    c_up = we.upsample(c.cuda(), T_expected=T)
+    first = None
+    for i in range(10):
+        out, _, _ = we.generate(B=B, T=T, c_up=c_up, seed=5, kernel=3)
+        if first is None: first = out.clone()
+        assert torch.equal(out, first) and torch.isfinite(out).all(), ("wide", B, i)
+print(f"wide_mol_512 (group ring): 10 launches each at B = 1, 2, 3, 5, 8: identical ({time.time()-t0:.1f} s)")
+t0 = time.time()
+T = 48000
+c, _ = inputs("wide_mol_512", 1, 48128)
+out, _, _ = we.generate(B=1, T=48128, c_up=we.upsample(c.cuda(), T_expected=48128), seed=3, kernel=3)
+torch.cuda.synchronize()
+print(f"wide_mol_512: 48128 samples (3 s at 16 kHz) in {time.time()-t0:.2f} s, std {float(out.std()):.3f}")
