@@ -204,7 +204,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 ring")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic, 2 ring, 3 group ring (wide models)")
     ap.add_argument("--T", type=int, default=T_SAMPLES)
     ap.add_argument("--batch", type=int, default=B_PER_GPU)
     ap.add_argument("--cpu-steps", type=int, default=1024, help="T of the bounded CPU-baseline sample (0 = skip)")
@@ -300,7 +300,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (seeded N(0,1) mel, random-init weights of the egs/mol architecture, in-kernel Philox noise)",
             "config": {"workload": f"{name}: {describe(kw)}, B={B} utterances/GPU x T={T} samples", "batch_per_gpu": B, "T": T,
-                       "kernel": {0: "auto", 1: "generic", 2: "ring"}[args.kernel] + f" (ran: {({1: 'generic', 2: 'ring'}).get(eng.last_kernel(), '?')})",
+                       "kernel": {0: "auto", 1: "generic", 2: "ring", 3: "group ring"}[args.kernel] + f" (ran: {({1: 'generic', 2: 'ring', 3: 'group ring'}).get(eng.last_kernel(), '?')})",
                        "parallelism": f"utterance-sharded x{world}"},
             "kSamples_per_s_per_gpu": round(value / world, 3),
             "samples_per_s_per_utterance": round(per_utt, 1),

@@ -34,7 +34,7 @@ def choice_scores(params, tape, kw, softmax=True):
 def choice_margin(params, tape, kw, softmax=True):
     """(B, T) top-2 margin of the discrete choice (+inf when there is none) and the chosen index (B, T)."""
     s = choice_scores(params, tape, kw, softmax)
-    if s is None:
+    if s is None or s.shape[1] < 2:                                   # no discrete choice (a single Gaussian, a one-component mixture)
         B, _, T = params.shape
         return torch.full((B, T), float("inf"), dtype=torch.float64), torch.zeros(B, T, dtype=torch.long)
     top = s.topk(2, dim=1)

@@ -1284,7 +1284,7 @@ static const char* why_not(const wnv_config& c, int B) {
     if (c.scalar_input && c.out_channels > 128) return "needs out_channels <= 128";
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 512 - (c.kernel_size - 1) * RC) return "too many local-conditioning channels";
-    if (c.layers + (c.skip_out_channels + 127) / 128 > 32) return "too many layers for one ring per XCD";
+    { int nk = (c.skip_out_channels + 127) / 128; if (nk == 3) nk = 4; if (c.layers + nk > 32) return "too many layers for one ring per XCD"; }
     if (B > 64) return "more than 64 utterances per call";
     return nullptr;
 }
@@ -1374,7 +1374,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     // model is embedded by ZERO PADDING: padded residual / gate / skip channels carry exact zeros through every layer
     // (z = 0 -> tanh(0) sigmoid(0) = 0; zero rows and biases), so the live channels see the same sums plus exact-zero terms.
     const int Ra = c.residual_channels, Ga = c.gate_channels, Gha = Ga / 2, Ka = c.skip_out_channels, O = c.out_channels;
-    const int NK = (Ka + RC - 1) / RC;                              // skip passes per stage = head parts per ring
+    int NK = (Ka + RC - 1) / RC;                                    // skip passes per stage = head parts per ring: 1, 2 or 4 (the
+    if (NK == 3) NK = 4;                                            // kernel is instantiated for those; 257 .. 384 channels pad to 512)
     const int K = NK * RC, Kp = K;                                  // padded skip width
     st->L = L; st->S = L; st->K = K; st->Kp = Kp; st->O = O; st->cin = cin; st->kw = kw;
     st->kpre = (kw - 1) * RC + cin;
