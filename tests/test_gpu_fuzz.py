@@ -76,3 +76,28 @@ def test_persistent_kernels_equal_the_generic_kernel(seed, wide):
         assert_free_run_agrees_until_near_tie(i.cpu(), ref_i.cpu(), p.cpu(), ref_p.cpu(), tape, kw, t0=0, what=str(kw))
     auto, _, _ = eng.generate(kernel=0, **args)
     assert eng.last_kernel() == kernel and torch.equal(auto, out)
+
+
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_deep_dilations_and_shared_rings_vs_generic(seed):
+    """One stack of 6-9 layers (dilation up to 256) forced for long enough that the largest history ring wraps, with batch sizes that
+    make several utterances share a ring (and the second tap workgroup join)."""
+    r = random.Random(seed)
+    layers, kwid = r.choice([6, 7, 8, 9]), r.choice([2, 3])
+    wide = seed % 4 == 3
+    kw = dict(out_channels=30, layers=layers, stacks=1, residual_channels=512 if wide else r.choice([96, 128]),
+              gate_channels=512 if wide else 256, skip_out_channels=r.choice([128, 256]), kernel_size=kwid, dropout=0.0, scalar_input=True,
+              output_distribution="Logistic", cin_channels=r.choice([5, 80]))
+    B = r.choice([1, 8]) if wide else r.choice([9, 16, 24, 33])
+    T = (kwid - 1) * 2 ** (layers - 1) * 2 + 40
+    torch.manual_seed(seed)
+    m = tame_head_(wnv.WaveNet(**kw).eval()).to("cuda")
+    eng = m._get_engine()
+    g = torch.Generator().manual_seed(seed)
+    c_up = torch.randn(B, T, kw["cin_channels"], generator=g).cuda()
+    x = torch.tanh(torch.randn(B, T, 1, generator=g) * 0.5).cuda()
+    tape = make_noise_tape(T, B, scalar_input=True, output_distribution="Logistic", out_channels=30, generator=torch.Generator().manual_seed(seed)).cuda()
+    _, ref_p, _ = eng.generate(B=B, T=T, c_up=c_up, teacher=x, noise=tape, want_params=True, kernel=1)
+    _, p, _ = eng.generate(B=B, T=T, c_up=c_up, teacher=x, noise=tape, want_params=True, kernel=3 if wide else 2)
+    err = (p - ref_p).abs()
+    assert float(err.max()) < 5e-5, (kw, B, float(err.max()), int(err.flatten().argmax()))
