@@ -3,6 +3,8 @@ one all-gather hop per layer (the pair (u, h) travels together, gate-to-gate fol
 size-independent properties at the published 24-layer 512 / 512 / 256 geometry."""
 import time
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -152,3 +154,30 @@ def test_wide_published_geometry_properties_and_speed():
     per_utt = 4096 / (time.perf_counter() - t0)
     print(f"24-layer 512/512/256 mu-law-256 model, B = 1: {per_utt / 1e3:.1f} kSamples/s = {per_utt / 16000:.2f}x real time at 16 kHz")
     assert torch.equal(out1.sum(1), torch.ones(1, 4096, device="cuda")) and per_utt > 16000
+
+
+def test_wide_onehot_model_through_batch_wavegen():
+    """The caller's view: a published-geometry (512 / 512 / 256, mu-law 256, 80-mel + ConvInUpsampleNetwork) model through
+    synthesis.batch_wavegen -- upsampling, the group-ring sample loop (auto), the device post-chain -- equals the post-chain oracle
+    applied to the engine's own one-hot output under the same seed."""
+    from oracle import postchain_oracle as P
+    from wavenet_vocoder_amd import synthesis
+    kw = dict(ONEHOT_WIDE, cin_pad=2, upsample_conditional_features=True,
+              upsample_params=dict(upsample_scales=[4, 4, 4, 4], cin_channels=80, cin_pad=2))
+    torch.manual_seed(31)
+    m = tame_head_(wnv.WaveNet(**kw).eval()).to("cuda")
+    B, frames = 2, 3
+    c = torch.randn(B, 80, frames + 4, generator=torch.Generator().manual_seed(1))
+    h = synthesis.default_hparams(input_type="mulaw-quantize", quantize_channels=256, out_channels=256, cin_pad=2, hop_size=256,
+                                  upsample_conditional_features=True)
+    torch.manual_seed(5)
+    wav = synthesis.batch_wavegen(m, c=c, g=None, hparams=h)
+    assert m._get_engine().last_kernel() == 3
+    assert wav.shape == (B, frames * 256) and wav.dtype == np.float32 and np.isfinite(wav).all()
+    torch.manual_seed(5)
+    with torch.no_grad():
+        y_hat = m.incremental_forward(c=c.cuda(), T=frames * 256, softmax=True, quantize=True)
+    assert torch.equal(y_hat.sum(1), torch.ones(B, frames * 256, device="cuda"))
+    want = P.post_chain(y_hat.cpu().numpy(), "mulaw-quantize", quantize_channels=256, postprocess=h.postprocess,
+                        coef=h.preemphasis_coef, global_gain_scale=h.global_gain_scale)
+    assert np.abs(wav - want).max() < 1e-4 * max(1.0, np.abs(want).max())
