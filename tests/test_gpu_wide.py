@@ -27,6 +27,9 @@ CASES = {
                                          n_speakers=3, use_speaker_embedding=True), 3, 64, 128),
     "mol_320_512_256_nine_layers": (dict(out_channels=30, layers=9, stacks=3, residual_channels=320, gate_channels=512, skip_out_channels=256,
                                          kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=20), 8, 48, 96),
+    # more than 8 utterances: the tap stream takes them in two passes, the deferred history copies run two utterances behind
+    "mol_512_384_256_thirteen_utterances": (dict(out_channels=30, layers=4, stacks=2, residual_channels=512, gate_channels=384, skip_out_channels=256,
+                                                 kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=33), 13, 40, 72),
 }
 
 
@@ -124,10 +127,17 @@ def test_wide_published_geometry_properties_and_speed():
     assert torch.equal(pre, full[:, :, :T2]), "prefix property"
     solo, _, _ = eng.generate(B=1, T=T2, c_up=c_up[1:2, :T2].contiguous(), noise=tape[:T2, 1:2].contiguous(), kernel=3)
     assert torch.equal(solo[0], full[1, :, :T2]), "batch members must be independent"
+    B16 = 16
+    c16, _ = inputs(name, B16, T2)
+    cu16 = eng.upsample(c16.cuda(), T_expected=T2)
+    tape16 = tape_for(kw, T2, B16, 10).cuda()
+    many, _, _ = eng.generate(B=B16, T=T2, c_up=cu16, noise=tape16, kernel=3)
+    lone, _, _ = eng.generate(B=1, T=T2, c_up=cu16[11:12].contiguous(), noise=tape16[:, 11:12].contiguous(), kernel=3)
+    assert torch.equal(lone[0], many[11]), "utterance 11 of 16 must not depend on its neighbours"
     assert torch.isfinite(full).all() and float(full.abs().max()) <= 1.0 and float(full.std()) > 1e-3
     gen, _, _ = eng.generate(B=B, T=128, c_up=c_up[:, :128].contiguous(), noise=tape[:128].contiguous(), kernel=1)
     assert float((gen - full[:, :, :128]).abs().max()) < 1e-3                       # the generic kernel's trajectory over a short horizon
-    for Bs in (1, 8):
+    for Bs in (1, 8, 16):
         cs, _ = inputs(name, Bs, 4096)
         cu = eng.upsample(cs.cuda(), T_expected=4096)
         eng.generate(B=Bs, T=4096, c_up=cu, seed=1, kernel=3)

@@ -46,7 +46,7 @@ constexpr int PG = 8;              // workgroups per layer group
 constexpr int GS = GHD / PG;       // 32 gate channels per workgroup (64 gate rows = one per lane)
 constexpr int RS = RWD / PG;       // 64 residual rows per workgroup
 constexpr int KS = KWD / PG;       // 32 skip rows per workgroup
-constexpr int BMAX = 8;
+constexpr int BMAX = 16;                              // utterances per call (the tap stream takes them 8 at a time)
 constexpr int XW = GHD + RWD;      // one mailbox slot: 256 gate outputs then 512 layer inputs
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
@@ -76,7 +76,14 @@ struct WideParams {
     u64 seed;
     float *out, *params_out;
     unsigned int* status;
+    unsigned long long* trace;                            // optional [trace_n][L + 1][8] wall-clock stamps of utterance 0, slice 0 (debug)
+    int trace_t0, trace_n, trace_b;
 };
+
+__device__ __forceinline__ void wstamp(const WideParams& p, int b, int t, int pos, int k, int who) {
+    if (p.trace && b == p.trace_b && (int)threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
+        p.trace[((size_t)(t - p.trace_t0) * (p.L + 1) + pos) * 8 + k] = wall_clock64();
+}
 
 __device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v, bool fast) {
     const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
@@ -90,7 +97,25 @@ __device__ __forceinline__ bool recv128(const u64* g, unsigned tag, float* dst, 
         u4v x;
         asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(g2) : "memory");
         if (__all(x.y == tag && x.w == tag)) {
+            *reinterpret_cast<float2*>(dst + 2 * lane) = make_float2(__uint_as_float(x.x), __uint_as_float(x.z));     // (LDS or global)
+            return true;
+        }
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+    }
+}
+// one wave receives 256 consecutive granules (both loads in flight together)
+__device__ __forceinline__ bool recv256(const u64* g, unsigned tag, float* dst, unsigned int* status, unsigned code, int lane) {
+    const u64* g2 = g + 2 * lane;
+    for (unsigned spins = 0;;) {
+        u4v x, y;
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:1024 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(x), "=&v"(y) : "v"(g2) : "memory");
+        if (__all(x.y == tag && x.w == tag && y.y == tag && y.w == tag)) {
             *reinterpret_cast<float2*>(dst + 2 * lane) = make_float2(__uint_as_float(x.x), __uint_as_float(x.z));
+            *reinterpret_cast<float2*>(dst + 128 + 2 * lane) = make_float2(__uint_as_float(y.x), __uint_as_float(y.z));
             return true;
         }
         if ((++spins & 255u) == 0u) {
@@ -141,71 +166,168 @@ __device__ __forceinline__ void load_img(float4 (&w)[NF4], const float* img, int
     for (int c = 0; c < NF4; ++c) w[c] = src[(size_t)c * 64];
 }
 
+// ---- lane-quad mat-vec: a wave owns 64 rows x one K span.  Lane L = (column i = L & 15, K quarter q = L >> 4) holds, for every k of
+// its quarter, the weights of FOUR rows ("slots": rows i, 32 + i, 16 + i, 48 + i of the wave's 64) -- so a lane reads a quarter of
+// the LDS vector (4x less LDS traffic than one row per lane, which was LDS-bandwidth-bound) and the four quarters are summed with a
+// two-step reduce-scatter on v_permlane32_swap / v_permlane16_swap (VALU, no LDS), after which lane L holds row L.
+template <int NK>
+__device__ __forceinline__ void dot_quad(const float4 (&w)[NK], const float* xq, f2 (&a)[4]) {          // a: slots (0,1),(2,3) x even / odd k
+#pragma unroll
+    for (int c = 0; c < NK / 4; ++c) {
+        const float4 v = reinterpret_cast<const float4*>(xq)[c];
+        a[0] = __builtin_elementwise_fma(f2{w[4 * c].x, w[4 * c].y}, f2{v.x, v.x}, a[0]);
+        a[1] = __builtin_elementwise_fma(f2{w[4 * c].z, w[4 * c].w}, f2{v.x, v.x}, a[1]);
+        a[2] = __builtin_elementwise_fma(f2{w[4 * c + 1].x, w[4 * c + 1].y}, f2{v.y, v.y}, a[2]);
+        a[3] = __builtin_elementwise_fma(f2{w[4 * c + 1].z, w[4 * c + 1].w}, f2{v.y, v.y}, a[3]);
+        a[0] = __builtin_elementwise_fma(f2{w[4 * c + 2].x, w[4 * c + 2].y}, f2{v.z, v.z}, a[0]);
+        a[1] = __builtin_elementwise_fma(f2{w[4 * c + 2].z, w[4 * c + 2].w}, f2{v.z, v.z}, a[1]);
+        a[2] = __builtin_elementwise_fma(f2{w[4 * c + 3].x, w[4 * c + 3].y}, f2{v.w, v.w}, a[2]);
+        a[3] = __builtin_elementwise_fma(f2{w[4 * c + 3].z, w[4 * c + 3].w}, f2{v.w, v.w}, a[3]);
+    }
+}
+// sum over lanes L and L ^ 32: lanes < 32 get a[L] + a[L + 32], lanes >= 32 get b[L - 32] + b[L]
+__device__ __forceinline__ float swap32_sum(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// sum over lanes L and L ^ 16: even 16-lane rows get a[L] + a[L + 16], odd rows get b[L - 16] + b[L]
+__device__ __forceinline__ float swap16_sum(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float reduce_quads(const f2 (&a)[4]) {                                        // -> lane L holds row L
+    const f2 s01 = a[0] + a[2], s23 = a[1] + a[3];
+    return swap16_sum(swap32_sum(s01.x, s01.y), swap32_sum(s23.x, s23.y));
+}
+// skip rows: 32 rows x 32 k per wave; a lane holds rows i and 16 + i for the 8 k of its quarter: w[c] = {ra[2c], rb[2c], ra[2c+1], rb[2c+1]}.
+// Returns the partial sum (over the K quarters q and q ^ 2) of row (L & 15) + 16 (L >> 5).
+__device__ __forceinline__ float dot_skip(const float4 (&w)[4], const float* xq) {
+    const float4 v0 = reinterpret_cast<const float4*>(xq)[0], v1 = reinterpret_cast<const float4*>(xq)[1];
+    f2 a0 = f2{0.f, 0.f}, a1 = f2{0.f, 0.f};
+    a0 = __builtin_elementwise_fma(f2{w[0].x, w[0].y}, f2{v0.x, v0.x}, a0);
+    a1 = __builtin_elementwise_fma(f2{w[0].z, w[0].w}, f2{v0.y, v0.y}, a1);
+    a0 = __builtin_elementwise_fma(f2{w[1].x, w[1].y}, f2{v0.z, v0.z}, a0);
+    a1 = __builtin_elementwise_fma(f2{w[1].z, w[1].w}, f2{v0.w, v0.w}, a1);
+    a0 = __builtin_elementwise_fma(f2{w[2].x, w[2].y}, f2{v1.x, v1.x}, a0);
+    a1 = __builtin_elementwise_fma(f2{w[2].z, w[2].w}, f2{v1.y, v1.y}, a1);
+    a0 = __builtin_elementwise_fma(f2{w[3].x, w[3].y}, f2{v1.z, v1.z}, a0);
+    a1 = __builtin_elementwise_fma(f2{w[3].z, w[3].w}, f2{v1.w, v1.w}, a1);
+    a0 += a1;
+    return swap32_sum(a0.x, a0.y);
+}
+
 struct StageLds {
     float *hx, *ux, *pz, *po, *ps, *pre, *xin, *pt;
     int* flags;
 };
 __device__ __forceinline__ StageLds carve_stage(float* smem, int kpre) {
     StageLds s;
-    s.hx = smem;                           // [512] h_{l-1}[t], then (behind the chain) the full h_l[t]
-    s.ux = s.hx + RWD;                     // [256] gate outputs u_{l-1}[t] (the last group: then its own u)
+    s.hx = smem;                           // [512] h_{l-1}[t]
+    s.ux = s.hx + RWD;                     // [256] gate outputs u_{l-1}[t]
     s.pz = s.ux + GHD;                     // [8][64] partial z
     s.po = s.pz + 8 * 64;                  // [8][64] partial conv1x1_out
     s.ps = s.po + 8 * 64;                  // [16][32] partial conv1x1_skip
     s.pre = s.ps + 16 * 32;                // [BMAX][64] pre_j of the step being computed
     s.pt = s.pre + BMAX * 64;              // [8][BMAX][64] partial taps
     s.flags = reinterpret_cast<int*>(s.pt + 8 * BMAX * 64);
-    s.xin = reinterpret_cast<float*>(s.flags + 16);      // [BMAX][kpre] tap inputs of the next step
+    s.xin = reinterpret_cast<float*>(s.flags + 16);      // [xin_slots(B)][kpre] tap inputs of the next step
     (void)kpre;
     return s;
 }
-__host__ __device__ inline size_t stage_lds_floats(int kpre) { return (size_t)RWD + GHD + 3 * 512 + BMAX * 64 + 8 * BMAX * 64 + 16 + (size_t)BMAX * kpre + 8 * 4 * 64 * 4; }
+__host__ __device__ inline int xin_slots(int B) { return B <= 1 ? 1 : B <= 2 ? 2 : B <= 4 ? 4 : B <= 8 ? 8 : 16; }     // what stream_pre<NB> reads
+__host__ __device__ inline size_t stage_lds_floats(int kpre, int B) { return (size_t)RWD + GHD + 3 * 512 + BMAX * 64 + 8 * BMAX * 64 + 16 + (size_t)xin_slots(B) * kpre; }
+
+__device__ __forceinline__ float reduce_quads2(f2 s01, f2 s23) { return swap16_sum(swap32_sum(s01.x, s01.y), swap32_sum(s23.x, s23.y)); }
+
+// the streamed part of compute_pre for NB utterances (utterances >= p.B, if any, are computed on stale LDS and dropped): wave w takes
+// the 16-k blocks [kb0, kb1); two blocks of weights in flight
+template <int NB>
+__device__ __forceinline__ void stream_pre(const WideParams& p, const StageLds& s, int l, int j, int lane, int wave, int b0 = 0) {
+    const int nb = p.kpre >> 4, per = (nb + 7) >> 3, kb0 = wave * per, kb1 = min(nb, kb0 + per);
+    const float4* W = reinterpret_cast<const float4*>(p.wpre) + ((size_t)(l * PG + j) * nb * 4) * 64 + lane;
+    const float* xq = s.xin + (size_t)b0 * p.kpre + 4 * (lane >> 4);
+    f2 a01[NB], a23[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { a01[b] = f2{0.f, 0.f}; a23[b] = f2{0.f, 0.f}; }
+    float4 w[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[c] = W[(size_t)(min(kb0, nb - 1) * 4 + c) * 64];
+    for (int kb = kb0; kb < kb1; ++kb) {
+        float4 wnx[4];
+        const int kn = kb + 1 < kb1 ? kb + 1 : kb;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) wnx[c] = W[(size_t)(kn * 4 + c) * 64];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float4 x = *reinterpret_cast<const float4*>(xq + (size_t)b * p.kpre + 16 * kb);
+            a01[b] = __builtin_elementwise_fma(f2{w[0].x, w[0].y}, f2{x.x, x.x}, a01[b]);
+            a23[b] = __builtin_elementwise_fma(f2{w[0].z, w[0].w}, f2{x.x, x.x}, a23[b]);
+            a01[b] = __builtin_elementwise_fma(f2{w[1].x, w[1].y}, f2{x.y, x.y}, a01[b]);
+            a23[b] = __builtin_elementwise_fma(f2{w[1].z, w[1].w}, f2{x.y, x.y}, a23[b]);
+            a01[b] = __builtin_elementwise_fma(f2{w[2].x, w[2].y}, f2{x.z, x.z}, a01[b]);
+            a23[b] = __builtin_elementwise_fma(f2{w[2].z, w[2].w}, f2{x.z, x.z}, a23[b]);
+            a01[b] = __builtin_elementwise_fma(f2{w[3].x, w[3].y}, f2{x.w, x.w}, a01[b]);
+            a23[b] = __builtin_elementwise_fma(f2{w[3].z, w[3].w}, f2{x.w, x.w}, a23[b]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) w[c] = wnx[c];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const float v = reduce_quads2(a01[b], a23[b]);
+        if (b0 + b < p.B) s.pt[((size_t)wave * BMAX + b0 + b) * 64 + lane] = v;
+    }
+}
 
 // pre_j[tp] for every utterance: older taps of step tp out of this workgroup's own history copy (zeros before t = 0), the
-// conditioning row c[tp], then the streamed [kpre][64] matrix (one pass over the weights for all utterances)
-__device__ void compute_pre(const WideParams& p, const StageLds& s, int l, int j, int tp, int tid, int lane, int wave) {
+// conditioning row c[tp], then the streamed [kpre][64] matrix (one pass over the weights for all utterances; lane-quad image in
+// blocks of 16 k: a lane holds the 4 row slots x the 4 k of its quarter)
+__device__ void compute_pre(const WideParams& p, const StageLds& s, int l, int j, int tp, int tid, int lane, int wave, int t_stamp = -1) {
     const int d = p.lay_dil[l], rows = (p.kw - 1) * d, hoff = (p.kw - 1) * RWD;
-    for (int b = 0; b < p.B; ++b) {
-        const float* hist = p.hist + (size_t)b * p.hist_b_floats + (size_t)PG * p.lay_histoff[l] + (size_t)j * rows * RWD;
-        float* xb = s.xin + (size_t)b * p.kpre;
-        for (int e = tid; e < p.kpre; e += WT) {
-            float v = 0.f;
-            if (e < hoff) {
-                const int k = e >> 9, r = e & (RWD - 1);
+    const float* hist0 = p.hist + (size_t)PG * p.lay_histoff[l] + (size_t)j * rows * RWD;
+    // tap inputs, four utterances' loads in flight together
+    for (int b0 = 0; b0 < p.B; b0 += 4) {
+        float v[4][3];
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
                 const int tt = tp - (p.kw - 1 - k) * d;                     // conv.py:43-44: tap k (oldest first) looks d (kw-1-k) back
-                if (tt >= 0) v = hist[(size_t)(tt % rows) * RWD + r];       // rows this very workgroup stored (row tp - 1 a barrier ago)
-            } else if (e - hoff < p.cin) {
-                v = p.c_up[((size_t)b * p.T + tp) * p.cin + (e - hoff)];
+                const bool on = b0 + bi < p.B && k < p.kw - 1 && tt >= 0;
+                v[bi][k] = on ? hist0[(size_t)(b0 + bi) * p.hist_b_floats + (size_t)(tt % rows) * RWD + tid] : 0.f;          // rows this very workgroup stored
             }
-            xb[e] = v;
+#pragma unroll
+        for (int bi = 0; bi < 4; ++bi)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+                if (b0 + bi < p.B && k < p.kw - 1) s.xin[(size_t)(b0 + bi) * p.kpre + k * RWD + tid] = v[bi][k];
+    }
+    {   // conditioning rows c[tp] (zero-padded to the 16-k block)
+        const int nc = p.kpre - hoff, total = p.B * nc;
+        for (int i0 = tid; i0 < total; i0 += 4 * WT) {
+            float v[4];
+            int at[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = i0 + q * WT, b = i / nc, e = i - b * nc;
+                at[q] = i < total ? b * p.kpre + hoff + e : -1;
+                v[q] = (i < total && e < p.cin) ? p.c_up[((size_t)b * p.T + tp) * p.cin + e] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (at[q] >= 0) s.xin[at[q]] = v[q];
         }
     }
     __syncthreads();
-    // stream: wave w takes the float4 K-blocks [kb0, kb1); lane = gate row; one accumulator per utterance
-    const int per = (p.nkb + 7) >> 3, kb0 = wave * per, kb1 = min(p.nkb, kb0 + per);
-    const float4* W = reinterpret_cast<const float4*>(p.wpre) + ((size_t)(l * PG + j) * p.nkb) * 64 + lane;
-    float acc[BMAX];
-#pragma unroll
-    for (int b = 0; b < BMAX; ++b) acc[b] = 0.f;
-    for (int kb = kb0; kb < kb1; kb += 4) {
-        float4 w[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) w[q] = kb + q < kb1 ? W[(size_t)(kb + q) * 64] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            if (kb + q >= kb1) break;
-#pragma unroll
-            for (int b = 0; b < BMAX; ++b) {
-                if (b >= p.B) break;
-                const float4 x = *reinterpret_cast<const float4*>(s.xin + (size_t)b * p.kpre + 4 * (kb + q));
-                acc[b] = fmaf(w[q].x, x.x, acc[b]); acc[b] = fmaf(w[q].y, x.y, acc[b]);
-                acc[b] = fmaf(w[q].z, x.z, acc[b]); acc[b] = fmaf(w[q].w, x.w, acc[b]);
-            }
-        }
+    if (j == 0 && t_stamp >= 0) wstamp(p, p.trace_b, t_stamp, l, 5, 0);     // tap inputs in LDS
+    if (p.B == 1) stream_pre<1>(p, s, l, j, lane, wave);
+    else if (p.B == 2) stream_pre<2>(p, s, l, j, lane, wave);
+    else if (p.B <= 4) stream_pre<4>(p, s, l, j, lane, wave);
+    else {
+        stream_pre<8>(p, s, l, j, lane, wave);
+        if (p.B > 8) stream_pre<8>(p, s, l, j, lane, wave, 8);
     }
-#pragma unroll
-    for (int b = 0; b < BMAX; ++b)
-        if (b < p.B) s.pt[((size_t)wave * BMAX + b) * 64 + lane] = acc[b];
+    if (j == 0 && t_stamp >= 0) wstamp(p, p.trace_b, t_stamp, l, 6, 0);     // this wave's share of the stream done
     __syncthreads();
     for (int e = tid; e < p.B * 64; e += WT) {
         const int b = e >> 6, r = e & 63;
@@ -222,63 +344,75 @@ __device__ void compute_pre(const WideParams& p, const StageLds& s, int l, int j
 __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next, float* smem) {
     const StageLds s = carve_stage(smem, p.kpre);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool first = l == 0, last = l == p.L - 1;
+    const bool first = l == 0;
     float4 wn[16], wm[8], wo[8], ws[4];
-    load_img<16>(wn, p.wn + (size_t)(l * PG + j) * 8 * 16 * 64 * 4, wave, lane);      // N_l (group 0: W_cur,0) x h_{l-1}, K chunk 64 wave
-    load_img<8>(wm, p.wm + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);        // M_l x u_{l-1}, K chunk 32 wave (group 0: zeros)
-    load_img<8>(wo, p.wo + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);        // W_out,l-1 rows 64 j + lane
-    load_img<4>(ws, p.ws + (size_t)(l * PG + j) * 8 * 4 * 64 * 4, wave, lane);        // W_skip,l-1 rows 32 j + (lane & 31), K chunk 16 (2 wave + lane / 32)
-    // the last group also holds W_skip,L-1 (same image layout) -- in LDS: the register file is full
-    float4* wsl = reinterpret_cast<float4*>(s.xin + (size_t)BMAX * p.kpre);
-    if (last)
-        for (int c = 0; c < 4; ++c) wsl[(wave * 4 + c) * 64 + lane] = reinterpret_cast<const float4*>(p.wsl + (size_t)j * 8 * 4 * 64 * 4)[(wave * 4 + c) * 64 + lane];
+    load_img<16>(wn, p.wn + (size_t)(l * PG + j) * 8 * 16 * 64 * 4, wave, lane);      // N_l (group 0: W_cur,0) x h_{l-1}, K span 64 wave (lane-quad images)
+    load_img<8>(wm, p.wm + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);        // M_l x u_{l-1}, K span 32 wave (group 0: zeros)
+    load_img<8>(wo, p.wo + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);        // W_out,l-1 rows 64 j + ..
+    load_img<4>(ws, p.ws + (size_t)(l * PG + j) * 8 * 4 * 64 * 4, wave, lane);        // W_skip,l-1 rows 32 j + .., K span 32 wave
     const float bo_r = p.bo[(size_t)l * RWD + RS * j + lane];                         // b_out,l-1
     const float bs_r = p.bs[(size_t)l * KWD + KS * j + (lane & 31)];                  // b_skip,l-1
-    const float bsl_r = p.bs[(size_t)p.L * KWD + KS * j + (lane & 31)];               // b_skip,L-1
     const float cv_a = p.cvec[(size_t)l * 2 * GHD + GS * j + (lane & 31)], cv_g = p.cvec[(size_t)l * 2 * GHD + GHD + GS * j + (lane & 31)];
     const int d = p.lay_dil[l], rows = (p.kw - 1) * d;
+    // this workgroup's own copy of layer l's input history, utterance 0
+    float* const hist0 = p.hist + (size_t)PG * p.lay_histoff[l] + (size_t)j * rows * RWD;
     if (tid == 0) s.flags[0] = 0;
     __syncthreads();
     compute_pre(p, s, l, j, 0, tid, lane, wave);                  // pre_j[0]: history is zero, conditioning row c[0]
 
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        const size_t hrow = rows > 0 ? (size_t)(t % rows) * RWD : 0;
         for (int b = 0; b < p.B; ++b) {
             u64* x_in = p.xmail + ((size_t)b * (p.L + 1) + l) * XW;
             u64* x_out = x_in + XW;
-            // ---- gather (u_{l-1}, h_{l-1}) of step t: the chain ------------------------------------------------------------------
+            // ---- gather (u_{l-1}, h_{l-1}) of step t: the chain.  Meanwhile waves 6 and 7 copy the full h_l of the utterance two back
+            //      (published two passes ago by the eight workgroups of this group) into this workgroup's history -------------------
+            //      (Tried: waves 0 .. 2 publish only and three waves gather 256 granules each, so that the next gather overlaps the
+            //      publish -- +3 % at B = 16, -3 % at B <= 8: the two-load poll is slower than the one-load poll.)
             if (wave < 2) {
                 if (!first && !recv128(x_in + 128 * wave, tag, s.ux + 128 * wave, p.status, 0x200u + (unsigned)l, lane)) s.flags[0] = 1;
             } else if (wave < 6) {
                 if (!recv128(x_in + GHD + 128 * (wave - 2), tag, s.hx + 128 * (wave - 2), p.status, 0x100u + (unsigned)l, lane)) s.flags[0] = 1;
+            } else if (!first && b >= 2 && rows > 0) {
+                const u64* prev = x_out - (size_t)2 * (p.L + 1) * XW + GHD + 256 * (wave - 6);
+                if (!recv256(prev, tag, hist0 + (size_t)(b - 2) * p.hist_b_floats + hrow + 256 * (wave - 6), p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
             }
-            __syncthreads();
-            if (s.flags[0]) return;
+            __syncthreads();                                       // (a timed-out gather is noticed at the end of the step: off the chain)
+            if (j == 0) wstamp(p, b, t, l, 0, 0);                  // inputs gathered
             // ---- one pass: z_l, conv1x1_out of layer l-1, conv1x1_skip of layer l-1 -----------------------------------------------
+            const float hp = s.hx[RS * j + lane];                  // (wave 1 needs it after the barrier, when hx may be refilled)
             {
-                float z = dot_bcast<16>(wn, s.hx + 64 * wave);
+                const int kq = lane >> 4, ps_at = (2 * wave + (kq & 1)) * 32 + (lane & 15) + 16 * (lane >> 5);
+                f2 az[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+                dot_quad<16>(wn, s.hx + 64 * wave + 16 * kq, az);
                 if (!first) {
-                    z += dot_bcast<8>(wm, s.ux + 32 * wave);
-                    s.po[wave * 64 + lane] = dot_bcast<8>(wo, s.ux + 32 * wave);
-                    s.ps[(2 * wave + (lane >> 5)) * 32 + (lane & 31)] = dot_bcast<4>(ws, s.ux + 16 * (2 * wave + (lane >> 5)));
+                    const float* uq = s.ux + 32 * wave + 8 * kq;
+                    dot_quad<8>(wm, uq, az);
+                    f2 ao[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+                    dot_quad<8>(wo, uq, ao);
+                    s.po[wave * 64 + lane] = reduce_quads(ao);
+                    s.ps[ps_at] = dot_skip(ws, uq);
                 }
-                s.pz[wave * 64 + lane] = z;
+                s.pz[wave * 64 + lane] = reduce_quads(az);
             }
+            if (first && rows > 0) hist0[(size_t)b * p.hist_b_floats + hrow + tid] = s.hx[tid];        // group 0: the input is its history row
             __syncthreads();
-            float sk_run = 0.f;                                    // wave 2: skip sum up to layer l-1 (kept for the last group)
+            if (j == 0) wstamp(p, b, t, l, 1, 0);                  // partial sums in LDS
             if (wave == 0) {                                       // u_l: lanes c and 32 + c hold the tanh / sigmoid rows of channel 32 j + c
-                float v = s.pre[b * 64 + lane] + ((lane >> 5) ? cv_g : cv_a);
+                float v = s.pre[b * 64 + lane] + (lane < GS ? cv_a : cv_g);
 #pragma unroll
                 for (int w = 0; w < 8; ++w) v += s.pz[w * 64 + lane];
-                const float g = __shfl_xor(v, 32, 64);
-                if (lane < GS) st_granule(x_out + GS * j + lane, tag, wide_gate(v, g), fast_next);                     // modules.py:152-154
+                const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+                if (lane < GS) st_granule(x_out + GS * j + lane, tag, wide_gate(__uint_as_float(r[0]), __uint_as_float(r[1])), fast_next);   // modules.py:152-154
+                if (j == 0) wstamp(p, b, t, l, 2, 0);              // u published
             } else if (wave == 1) {                                // h_l = layer l's input (group 0 passes h_0 on)
                 float o = bo_r;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) o += s.po[w * 64 + lane];
-                const float hp = s.hx[RS * j + lane];
-                st_granule(x_out + GHD + RS * j + lane, tag, first ? hp : (o + hp) * 0.70710678118654752440f, fast_next);  // modules.py:157-162
-            } else if (wave == 2 && !first) {                      // skip sum over layers 0 .. l-1 (wavenet.py:312)
+                const float hv = first ? hp : (o + hp) * 0.70710678118654752440f;                                        // modules.py:157-162
+                st_granule(x_out + GHD + RS * j + lane, tag, hv, fast_next);
+            } else if (wave == 2 && !first) {                      // skip sum over layers 0 .. l-1 (wavenet.py:312) -> group l + 1 / the tail
                 float sk = bs_r, acc = 0.f;
                 bool ok = true;
                 if (lane < KS) {
@@ -286,47 +420,62 @@ __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next
                     for (int h = 0; h < 16; ++h) sk += s.ps[h * 32 + lane];
                 }
                 if (l > 1) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 2) + l) * KWD + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)l, lane);
-                sk_run = acc + sk;
                 if (!ok) s.flags[0] = 1;
-                else if (lane < KS && !last) st_granule(p.smail + ((size_t)b * (p.L + 2) + l + 1) * KWD + KS * j + lane, tag, sk_run, fast_next);
+                else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 2) + l + 1) * KWD + KS * j + lane, tag, acc + sk, fast_next);
             }
-            // ---- behind the chain: the full h_l this group just produced (history, next step's taps); the last group also needs its
-            //      own u for the last layer's skip term, which the head is waiting for ---------------------------------------------
-            if (last) {
-                if (wave < 2) {
-                    if (!recv128(x_out + 128 * wave, tag, s.ux + 128 * wave, p.status, 0x500u, lane)) s.flags[0] = 1;
-                }
-                __syncthreads();
-                {
-                    float4 wl[4];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) wl[c] = wsl[(wave * 4 + c) * 64 + lane];
-                    s.ps[(2 * wave + (lane >> 5)) * 32 + (lane & 31)] = dot_bcast<4>(wl, s.ux + 16 * (2 * wave + (lane >> 5)));
-                }
-                __syncthreads();
-                if (wave == 2 && lane < KS && !s.flags[0]) {
-                    float sk = bsl_r + sk_run;
-#pragma unroll
-                    for (int h = 0; h < 16; ++h) sk += s.ps[h * 32 + lane];
-                    st_granule(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + KS * j + lane, tag, sk, fast_next);
-                }
+        }
+        // ---- behind the chain: the full h_l of the last two utterances -> history (waves 6, 7), then pre_j[t + 1] for every utterance
+        //      (the history rows are this CU's own stores).  Memory traffic of this CU right after the publish -- polling for the own
+        //      h_l, or the tap stream -- slows the hop to the next group (measured: +4 us per step over 24 groups), hence the pause
+        //      where the deferred copies of the batch loop do not provide one.
+        if (!first && rows > 0 && wave >= 6) {
+            if (p.B <= 2) { __builtin_amdgcn_s_sleep(64); __builtin_amdgcn_s_sleep(64); }
+            for (int bb = max(0, p.B - 2); bb < p.B; ++bb) {
+                const u64* own = p.xmail + ((size_t)bb * (p.L + 1) + l + 1) * XW + GHD + 256 * (wave - 6);
+                if (!recv256(own, tag, hist0 + (size_t)bb * p.hist_b_floats + hrow + 256 * (wave - 6), p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
             }
-            if (!first) {                                          // (group 0: h_0 is already in hx)
-                __syncthreads();                                   // every wave is done with hx
-                if (wave >= 4) {
-                    if (!recv128(x_out + GHD + 128 * (wave - 4), tag, s.hx + 128 * (wave - 4), p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
-                }
-                __syncthreads();
-            }
-            if (s.flags[0]) return;
-            if (rows > 0) {                                        // this workgroup's own copy of history row t
-                float* hist = p.hist + (size_t)b * p.hist_b_floats + (size_t)PG * p.lay_histoff[l] + (size_t)j * rows * RWD;
-                hist[(size_t)(t % rows) * RWD + tid] = s.hx[tid];
+        }
+        __syncthreads();
+        if (s.flags[0]) return;
+        if (j == 0) wstamp(p, p.trace_b, t, l, 3, 0);              // own h stored
+        if (t + 1 < p.T) compute_pre(p, s, l, j, t + 1, tid, lane, wave, t);
+        if (j == 0) wstamp(p, p.trace_b, t, l, 4, 0);                      // next step's pre-activations ready
+    }
+}
+
+// ---- the tail group: conv1x1_skip of the LAST layer (8 workgroups, 32 skip rows each) + the running skip sum -> the head ------------
+__device__ void run_wide_tail(const WideParams& p, int j, bool fast_next, float* smem) {
+    float* ux = smem;                                              // [256] u_{L-1}
+    float* ps = ux + GHD;                                          // [16][32] partial sums
+    int* flags = reinterpret_cast<int*>(ps + 16 * 32);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4 ws[4];
+    load_img<4>(ws, p.wsl + (size_t)j * 8 * 4 * 64 * 4, wave, lane);
+    const float bs_r = p.bs[(size_t)p.L * KWD + KS * j + (lane & 31)];
+    if (tid == 0) flags[0] = 0;
+    __syncthreads();
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        for (int b = 0; b < p.B; ++b) {
+            if (wave < 2) {
+                if (!recv128(p.xmail + ((size_t)b * (p.L + 1) + p.L) * XW + 128 * wave, tag, ux + 128 * wave, p.status, 0x500u, lane)) flags[0] = 1;
             }
             __syncthreads();
+            if (flags[0]) return;
+            ps[(2 * wave + ((lane >> 4) & 1)) * 32 + (lane & 15) + 16 * (lane >> 5)] = dot_skip(ws, ux + 32 * wave + 8 * (lane >> 4));
+            __syncthreads();
+            if (wave == 0) {
+                float sk = bs_r, acc = 0.f;
+                bool ok = true;
+                if (lane < KS) {
+#pragma unroll
+                    for (int h = 0; h < 16; ++h) sk += ps[h * 32 + lane];
+                }
+                if (p.L > 1) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 2) + p.L) * KWD + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)p.L, lane);
+                if (!ok) flags[0] = 1;
+                else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + KS * j + lane, tag, acc + sk, fast_next);
+            }
         }
-        // ---- pre_j[t + 1] for every utterance (the rows written above are this CU's own stores) ------------------------------------
-        if (t + 1 < p.T) compute_pre(p, s, l, j, t + 1, tid, lane, wave);
     }
 }
 
@@ -346,11 +495,18 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
     const HeadLds s = carve_head(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float4 w1[32], w2[8];
-    load_img<32>(w1, p.wh1, wave, lane);                 // rows (wave & 3) 64 + lane, K half (wave >> 2)
-    load_img<8>(w2, p.wh2, wave, lane);                  // row lane (< O), K chunk 32 wave
+    load_img<32>(w1, p.wh1, wave, lane);                 // lane-quad image: rows (wave & 3) 64 + .., K half (wave >> 2)
+    load_img<8>(w2, p.wh2, wave, lane);                  // lane-quad image: rows 0 .. 63 (< O), K span 32 wave
     const float wf = p.wfirst[tid], bf = p.bfirst[tid];
     const float b1 = tid < KWD ? p.bh1[tid] : 0.f;
     const float b2 = lane < p.O ? p.bh2[lane] : 0.f;
+    // output distribution (mixture.py:118-156 / :221-270): which head outputs are mixture logits / mean / log-scale
+    const bool single = p.dist == 2 && p.O <= 3;
+    const int nmix = single ? 0 : p.O / 3;
+    const int o_mean = single ? (p.O == 2 ? 0 : 1) : nmix, o_ls = single ? (p.O == 2 ? 1 : 2) : 2 * nmix;
+    const int nchunk = (nmix + 3) >> 2;
+    float* vbuf = s.nz + 32;                             // [32] mixture logit + Gumbel noise, padded with -inf
+    if (tid < 32) vbuf[tid] = -INFINITY;
     if (tid == 0) s.flags[0] = 0;
     __syncthreads();
     // the input of step 0 (wavenet.py:283-289, :297-308)
@@ -361,40 +517,69 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
         for (int b = 0; b < p.B; ++b) {
+            // ---- everything that does not depend on the network, while the groups work: the noise terms of the sampler ----------
             if (tid < p.nz) {
                 const int kind = (p.dist == 2 && tid == p.nz - 1) ? 1 : 0;
-                s.nz[tid] = p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, b, tid, kind);
+                const float r = p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, b, tid, kind);
+                if (tid < nmix) s.nz[tid] = -logf(-logf(r));                                         // Gumbel noise (mixture.py:138-140)
+                else s.nz[tid] = p.dist == 1 ? logf(r) - logf(1.0f - r) : r;                         // mixture.py:151-152 / :265-267
             }
             if (wave < 2) {
                 if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
+                // (a lane rewrites the two values it has just stored)
+                float2* v2 = reinterpret_cast<float2*>(s.vs + 128 * wave + 2 * lane);
+                *v2 = make_float2(fmaxf(v2->x * p.skip_scale, 0.f), fmaxf(v2->y * p.skip_scale, 0.f));     // wavenet.py:313-316
             }
             __syncthreads();
             if (s.flags[0]) return;
-            if (tid < KWD) s.vs[tid] = fmaxf(s.vs[tid] * p.skip_scale, 0.f);                        // wavenet.py:313-316
-            __syncthreads();
-            s.ph[(wave >> 2) * KWD + (wave & 3) * 64 + lane] = dot_bcast<32>(w1, s.vs + 128 * (wave >> 2));
+            wstamp(p, b, t, p.L, 0, 0);                                                             // skip sum gathered
+            {
+                f2 a[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+                dot_quad<32>(w1, s.vs + 128 * (wave >> 2) + 32 * (lane >> 4), a);
+                s.ph[(wave >> 2) * KWD + (wave & 3) * 64 + lane] = reduce_quads(a);
+            }
             __syncthreads();
             if (tid < KWD) s.hid[tid] = fmaxf(s.ph[tid] + s.ph[KWD + tid] + b1, 0.f);               // wavenet.py:317-318
             __syncthreads();
-            s.pout[wave * 64 + lane] = dot_bcast<8>(w2, s.hid + 32 * wave);
+            {
+                f2 a[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+                dot_quad<8>(w2, s.hid + 32 * wave + 8 * (lane >> 4), a);
+                s.pout[wave * 64 + lane] = reduce_quads(a);
+            }
             __syncthreads();
-            if (wave == 0) {
+            if (wave == 0 && lane < p.O) {
                 float o = b2;
 #pragma unroll
                 for (int w = 0; w < 8; ++w) o += s.pout[w * 64 + lane];
-                if (lane < p.O) {
-                    s.obuf[lane] = o;                                                                // wavenet.py:319
-                    if (p.params_out) p.params_out[((size_t)b * p.O + lane) * p.T + t] = o;
+                s.obuf[lane] = o;                                                                    // wavenet.py:319
+                if (lane < nmix) vbuf[lane] = o + s.nz[lane];
+                if (p.params_out) p.params_out[((size_t)b * p.O + lane) * p.T + t] = o;
+            }
+            __syncthreads();
+            // ---- sample, redundantly in every thread (no cross-lane traffic), then first_conv of step t + 1 ------------------------
+            {
+                int bi = 0;
+                if (nmix > 0) {                                                                      // Gumbel-max, first index wins ties
+                    float best = -INFINITY;
+                    for (int c = 0; c < nchunk; ++c) {
+                        const float4 v = reinterpret_cast<const float4*>(vbuf)[c];
+                        if (v.x > best) { best = v.x; bi = 4 * c; }
+                        if (v.y > best) { best = v.y; bi = 4 * c + 1; }
+                        if (v.z > best) { best = v.z; bi = 4 * c + 2; }
+                        if (v.w > best) { best = v.w; bi = 4 * c + 3; }
+                    }
                 }
-                const float x = sample_scalar(p.dist, p.O, s.obuf, s.nz, lane);                      // mixture.py:118-156 / :221-270
-                if (lane == 0) { p.out[(size_t)b * p.T + t] = x; s.nz[63] = x; }
+                const float mean = s.obuf[o_mean + bi], ls = s.obuf[o_ls + bi], lr = s.nz[nmix];    // mixture.py:143-146 / :258-261
+                float xo = p.dist == 1 ? mean + expf(ls) * lr : lr * expf(ls) + mean;
+                xo = fminf(fmaxf(xo, -1.0f), 1.0f);                                                  // mixture.py:154 / :269
+                if (t + 1 < p.T) {
+                    const float xs = t + 1 < p.Tt ? p.teacher[(size_t)b * p.Tt + t + 1] : xo;        // wavenet.py:297-305
+                    st_granule(p.xmail + ((size_t)b * (p.L + 1)) * XW + GHD + tid, tag + 1u, fmaf(wf, xs, bf), fast_first);
+                }
+                if (tid == 0) p.out[(size_t)b * p.T + t] = xo;
             }
-            __syncthreads();
-            if (t + 1 < p.T) {
-                const float xs = t + 1 < p.Tt ? p.teacher[(size_t)b * p.Tt + t + 1] : s.nz[63];   // wavenet.py:297-305
-                st_granule(p.xmail + ((size_t)b * (p.L + 1)) * XW + GHD + tid, tag + 1u, fmaf(wf, xs, bf), fast_first);
-            }
-            __syncthreads();
+            wstamp(p, b, t, p.L, 1, 0);                                                             // next input sent
+            __syncthreads();                                                                        // obuf / vbuf / nz are free again
         }
     }
 }
@@ -419,12 +604,17 @@ __device__ void run_wide_head_a(const WideParams& p, float* smem) {
         for (int b = 0; b < p.B; ++b) {
             if (wave < 2) {
                 if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
+                // (a lane rewrites the two values it has just stored)
+                float2* v2 = reinterpret_cast<float2*>(s.vs + 128 * wave + 2 * lane);
+                *v2 = make_float2(fmaxf(v2->x * p.skip_scale, 0.f), fmaxf(v2->y * p.skip_scale, 0.f));     // wavenet.py:313-316
             }
             __syncthreads();
             if (s.flags[0]) return;
-            if (tid < KWD) s.vs[tid] = fmaxf(s.vs[tid] * p.skip_scale, 0.f);                        // wavenet.py:313-316
-            __syncthreads();
-            s.ph[(wave >> 2) * KWD + (wave & 3) * 64 + lane] = dot_bcast<32>(w1, s.vs + 128 * (wave >> 2));
+            {
+                f2 a[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+                dot_quad<32>(w1, s.vs + 128 * (wave >> 2) + 32 * (lane >> 4), a);
+                s.ph[(wave >> 2) * KWD + (wave & 3) * 64 + lane] = reduce_quads(a);
+            }
             __syncthreads();
             if (tid < KWD) st_granule(p.hidmail + (size_t)b * KWD + tid, tag, fmaxf(s.ph[tid] + s.ph[KWD + tid] + b1, 0.f), fast);   // wavenet.py:317-318
             __syncthreads();
@@ -534,11 +724,11 @@ __global__ void __launch_bounds__(WT) wnv_wide_kernel(const WideParams p) {
         run_wide_head_b(p, p.fast && p.head_x == 0, smem);
         return;
     }
-    const int sl = li / PG, j = li % PG, l = x * p.nL + sl;
-    if (sl >= p.nL || l >= p.L) return;
-    // who reads what this group publishes for the NEXT layer: group l + 1 (same XCD unless this is the last group of its XCD) or the head
-    const int next_x = l + 1 < p.L ? (l + 1) / p.nL : p.head_x;
-    run_wide_stage(p, l, j, p.fast && next_x == x, smem);
+    const int sl = li / PG, j = li % PG, l = x * p.nL + sl;         // groups 0 .. L-1: the layers; group L: the tail
+    if (sl >= p.nL || l > p.L) return;
+    // who reads what this group publishes: group l + 1 (same XCD unless this is the last group of its XCD); the tail feeds the head
+    if (l == p.L) run_wide_tail(p, j, p.fast && p.head_x == x, smem);
+    else run_wide_stage(p, l, j, p.fast && (l + 1) / p.nL == x, smem);
 }
 
 }  // namespace
@@ -570,8 +760,8 @@ static const char* wide_why_not(const wnv_config& c, int B) {
     if (c.skip_out_channels > KWD) return "needs skip_out_channels <= 256";
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 128) return "needs cin_channels <= 128";
-    if (c.layers > 31) return "needs layers <= 31 (8 workgroups per layer, 32 CUs per XCD, one or two more for the head)";
-    if (B > BMAX) return "more than 8 utterances per call";
+    if (c.layers > 30) return "needs layers <= 30 (8 workgroups per layer and 8 for the tail, 32 CUs per XCD, one or two more for the head)";
+    if (B > BMAX) return "more than 16 utterances per call";
     return nullptr;
 }
 bool wnv_wide_supported(const wnv_config& c, int B) { return wide_why_not(c, B) == nullptr; }
@@ -597,7 +787,7 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
     WnvWideState* st = new WnvWideState();
     *out = st;
     st->device = device;
-    const int L = c.layers, kw = c.kernel_size, cin = c.cin_channels > 0 ? c.cin_channels : 0, cinp = (cin + 3) & ~3;
+    const int L = c.layers, kw = c.kernel_size, cin = c.cin_channels > 0 ? c.cin_channels : 0, cinp = (cin + 15) & ~15;
     const int Ra = c.residual_channels, Ga = c.gate_channels, Gha = Ga / 2, Ka = c.skip_out_channels, O = c.out_channels;
     st->L = L; st->O = O; st->cin = cin; st->cinp = cinp; st->kw = kw;
     st->kpre = (kw - 1) * RWD + cinp; st->nkb = st->kpre / 4;
@@ -625,16 +815,17 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
     std::vector<float> cur((size_t)2 * GHD * RWD), mmat((size_t)2 * GHD * GHD);
     std::vector<double> accd(GHD);
     // skip image of layer `ls` for slice j
+    // lane-quad images (dot_quad / dot_skip): lane = (column i = lane & 15, K quarter q = lane >> 4); row slot e of a lane
+    auto quad_row = [&](int lane, int e) { static const int g[4] = {0, 2, 1, 3}; return 16 * g[e] + (lane & 15); };
     auto put_skip = [&](float* is, const HostTensor& wsk, int j) {
         for (int w = 0; w < 8; ++w)
-            for (int lane = 0; lane < 64; ++lane) {
-                const int so = KS * j + (lane & 31), hw = 2 * w + (lane >> 5);      // skip row, K chunk [16 hw, 16 hw + 16)
+            for (int lane = 0; lane < 64; ++lane)
                 for (int cq = 0; cq < 4; ++cq)
                     for (int e = 0; e < 4; ++e) {
-                        const int k = 16 * hw + 4 * cq + e;
+                        const int so = KS * j + 16 * (e & 1) + (lane & 15);           // skip row
+                        const int k = 32 * w + 8 * (lane >> 4) + 2 * cq + (e >> 1);
                         is[(((size_t)w * 4 + cq) * 64 + lane) * 4 + e] = (so < Ka && k < Gha) ? wsk.data[(size_t)so * Gha + k] : 0.f;
                     }
-            }
     };
     for (int l = 0; l < L; ++l) {
         const std::string pfx = "conv_layers." + std::to_string(l) + ".", ppx = "conv_layers." + std::to_string(l - 1) + ".";
@@ -673,41 +864,39 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
             float* io = blob.data() + st->o_wo + (size_t)(l * PG + j) * n_wo;
             float* ip = blob.data() + st->o_wpre + (size_t)(l * PG + j) * n_pre;
             for (int w = 0; w < 8; ++w)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int o = slice_row(j, lane);
-                    for (int cq = 0; cq < 16; ++cq)                     // N_l, K chunk [64 w, 64 w + 64) of h_{l-1}
-                        for (int e = 0; e < 4; ++e) {
-                            const int k = 64 * w + 4 * cq + e;
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = quad_row(lane, e), o = slice_row(j, r), ro = RS * j + r, q = lane >> 4;
+                        for (int cq = 0; cq < 16; ++cq) {               // N_l, K span [64 w, 64 w + 64) of h_{l-1}
+                            const int k = 64 * w + 16 * q + cq;
                             const float v = cur[(size_t)o * RWD + k];
                             in_[(((size_t)w * 16 + cq) * 64 + lane) * 4 + e] = l == 0 ? v : (float)(rs * (double)v);
                         }
-                    const int ro = RS * j + lane;                       // M_l and W_out,l-1, K chunk [32 w, 32 w + 32) of u_{l-1}
-                    for (int cq = 0; cq < 8; ++cq)
-                        for (int e = 0; e < 4; ++e) {
-                            const int k = 32 * w + 4 * cq + e;
+                        for (int cq = 0; cq < 8; ++cq) {                // M_l and W_out,l-1, K span [32 w, 32 w + 32) of u_{l-1}
+                            const int k = 32 * w + 8 * q + cq;
                             im[(((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = mmat[(size_t)o * GHD + k];
                             io[(((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = (l > 0 && ro < Ra && k < Gha) ? wout->data[(size_t)ro * Gha + k] : 0.f;
                         }
-                }
+                    }
             if (l > 0) put_skip(blob.data() + st->o_ws + (size_t)(l * PG + j) * n_ws, *wsk, j);
             if (l == L - 1) put_skip(blob.data() + st->o_wsl + (size_t)j * n_ws, T(pfx + "conv1x1_skip.weight"), j);
-            for (int kb = 0; kb < st->nkb; ++kb)                        // older taps (oldest first) then local conditioning, [kb][lane][4]
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int go = gate_row(slice_row(j, lane));
-                    for (int e = 0; e < 4; ++e) {
-                        const int k = 4 * kb + e;
-                        float v = 0.f;
-                        if (go >= 0) {
-                            if (k < (kw - 1) * RWD) {
-                                const int tap = k >> 9, ch = k & (RWD - 1);
-                                if (ch < Ra) v = wc.data[((size_t)go * Ra + ch) * kw + tap];
-                            } else if (k - (kw - 1) * RWD < cin) {
-                                v = wcc->data[(size_t)go * cin + (k - (kw - 1) * RWD)];
+            for (int kb = 0; kb < st->kpre / 16; ++kb)                  // older taps (oldest first) then local conditioning: lane-quad blocks of 16 k, [kb][4][lane][4]
+                for (int cq = 0; cq < 4; ++cq)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int e = 0; e < 4; ++e) {
+                            const int go = gate_row(slice_row(j, quad_row(lane, e)));
+                            const int k = 16 * kb + 4 * (lane >> 4) + cq;
+                            float v = 0.f;
+                            if (go >= 0) {
+                                if (k < (kw - 1) * RWD) {
+                                    const int tap = k >> 9, ch = k & (RWD - 1);
+                                    if (ch < Ra) v = wc.data[((size_t)go * Ra + ch) * kw + tap];
+                                } else if (k - (kw - 1) * RWD < cin) {
+                                    v = wcc->data[(size_t)go * cin + (k - (kw - 1) * RWD)];
+                                }
                             }
+                            ip[(((size_t)kb * 4 + cq) * 64 + lane) * 4 + e] = v;
                         }
-                        ip[((size_t)kb * 64 + lane) * 4 + e] = v;
-                    }
-                }
         }
         if (l > 0) {
             std::copy(bout->data.begin(), bout->data.end(), blob.begin() + st->o_bo + (size_t)l * RWD);
@@ -723,7 +912,7 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
         hist += (long long)(kw - 1) * dil[l] * RWD;
     }
     st->hist_layer_floats = hist;
-    // head: W1 rows (w & 3) 64 + lane, K half (w >> 2) -> [w][32][lane][4];  W2: scalar models row lane, K chunk 32 w -> [w][8][lane][4];
+    // head: W1 rows (w & 3) 64 + .., K half (w >> 2), lane-quad -> [w][32][lane][4];  W2: scalar models rows 0 .. 63, K span 32 w, lane-quad -> [w][8][lane][4];
     // one-hot models rows lane + 64 q (q = 0 .. 3), K chunk 32 w -> [w][8 q + c][lane][4]
     const int cin1 = c.scalar_input ? 1 : O;
     st->cin1 = cin1;
@@ -734,19 +923,25 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
         const HostTensor& w2 = T("last_conv_layers.3.weight");         // (O, K, 1)
         for (int w = 0; w < 8; ++w)
             for (int lane = 0; lane < 64; ++lane) {
-                const int row = (w & 3) * 64 + lane;
-                for (int cq = 0; cq < 32; ++cq)
+                for (int cq = 0; cq < 32; ++cq)                         // W1, lane-quad: rows (w & 3) 64 + .., K half (w >> 2)
                     for (int e = 0; e < 4; ++e) {
-                        const int k = 128 * (w >> 2) + 4 * cq + e;
+                        const int row = (w & 3) * 64 + quad_row(lane, e), k = 128 * (w >> 2) + 32 * (lane >> 4) + cq;
                         blob[st->o_wh1 + (((size_t)w * 32 + cq) * 64 + lane) * 4 + e] = (row < Ka && k < Ka) ? w1.data[(size_t)row * Ka + k] : 0.f;
                     }
-                for (int q = 0; q < (cin1 > 1 ? 4 : 1); ++q)
+                if (cin1 == 1) {                                        // W2 of scalar models, lane-quad: rows 0 .. 63, K span 32 w
                     for (int cq = 0; cq < 8; ++cq)
                         for (int e = 0; e < 4; ++e) {
-                            const int k = 32 * w + 4 * cq + e, orow = lane + 64 * q;
-                            blob[st->o_wh2 + (((size_t)w * (cin1 > 1 ? 32 : 8) + 8 * q + cq) * 64 + lane) * 4 + e] =
-                                (orow < O && k < Ka) ? w2.data[(size_t)orow * Ka + k] : 0.f;
+                            const int orow = quad_row(lane, e), k = 32 * w + 8 * (lane >> 4) + cq;
+                            blob[st->o_wh2 + (((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = (orow < O && k < Ka) ? w2.data[(size_t)orow * Ka + k] : 0.f;
                         }
+                } else {
+                    for (int q = 0; q < 4; ++q)
+                        for (int cq = 0; cq < 8; ++cq)
+                            for (int e = 0; e < 4; ++e) {
+                                const int k = 32 * w + 4 * cq + e, orow = lane + 64 * q;
+                                blob[st->o_wh2 + (((size_t)w * 32 + 8 * q + cq) * 64 + lane) * 4 + e] = (orow < O && k < Ka) ? w2.data[(size_t)orow * Ka + k] : 0.f;
+                            }
+                }
             }
     }
     st->o_bh1 = alloc(KWD);
@@ -788,12 +983,13 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
         return WNV_ERR_UNSUPPORTED;
     }
     const int cus_per_xcd = st->ncu / 8;
-    const int nL = (L + 7) / 8;                                      // layer groups per XCD
-    // the head goes to the XCD of the last layer when that XCD has a free slot, else to the first XCD that has one
+    const int NG = L + 1;                                            // groups of 8 workgroups: one per layer + the tail (last skip conv)
+    const int nL = (NG + 7) / 8;                                     // groups per XCD
+    // the head goes to the XCD of the tail group when that XCD has a free slot, else to the first XCD that has one
     int head_x = -1, head_li = -1;
     const int n_head = st->cin1 > 1 ? 2 : 1;                        // one-hot models: the head is two workgroups
-    auto groups_on = [&](int x) { return std::max(0, std::min(nL, L - x * nL)); };
-    const int last_x = (L - 1) / nL;
+    auto groups_on = [&](int x) { return std::max(0, std::min(nL, NG - x * nL)); };
+    const int last_x = (NG - 1) / nL;
     for (int k = 0; k < 8 && head_x < 0; ++k) {
         const int x = (last_x + k) % 8;
         if (groups_on(x) * PG + n_head <= cus_per_xcd) { head_x = x; head_li = groups_on(x) * PG; }
@@ -813,7 +1009,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride; p.zb_ld = (c.gate_channels + 3) & ~3; p.gh_model = c.gate_channels / 2;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
     p.hist_b_floats = (long long)PG * st->hist_layer_floats;
-    // state: [status 64 B][X B (L+1) 768 u64][SK B (L+2) 256 u64][history B x 8 copies x layers]
+    // state: [status 64 B][X B (L+1) 768 u64][SK B (L+2) 256 u64][hidden B 256 u64][history B x 8 copies x layers]
     const size_t head_bytes = 64;
     const size_t n_x = (size_t)B * (L + 1) * XW, n_s = (size_t)B * (L + 2) * KWD;
     const size_t n_hid = (size_t)B * KWD;
@@ -845,13 +1041,13 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     p.hist = (float*)(p.hidmail + n_hid);
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.out = ga.out; p.params_out = ga.params_out;
-    const size_t lds = std::max(std::max(stage_lds_floats(p.kpre), HEAD_LDS_FLOATS), CAT_LDS_FLOATS) * sizeof(float);
+    const size_t lds = std::max(std::max(stage_lds_floats(p.kpre, B), HEAD_LDS_FLOATS), CAT_LDS_FLOATS) * sizeof(float);
     if (lds > 160 * 1024) { err = "wide kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
     WIDE_HIP(hipFuncSetAttribute((const void*)wnv_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         int per_cu = 0;
         WIDE_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)wnv_wide_kernel, WT, lds));
-        const int live = L * PG + n_head;
+        const int live = NG * PG + n_head;
         if (per_cu < 1 || live > st->ncu * per_cu) {
             char buf[160];
             snprintf(buf, sizeof buf, "wide kernel: %d workgroups must be co-resident but the device holds %d", live, st->ncu * std::max(per_cu, 0));
@@ -859,12 +1055,44 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
             return WNV_ERR_UNSUPPORTED;
         }
     }
+    // optional timeline (WNV_WIDE_TRACE=<file>): wall-clock stamps of utterance 0 at slice 0 of every group, 8 steps in mid-run
+    const char* trace_path = getenv("WNV_WIDE_TRACE");
+    unsigned long long* d_trace = nullptr;
+    const int trace_n = 8;
+    size_t trace_words = 0;
+    if (trace_path && *trace_path && p.T > 64) {
+        trace_words = (size_t)trace_n * (L + 1) * 8;
+        WIDE_HIP(hipMalloc((void**)&d_trace, trace_words * sizeof(unsigned long long)));
+        WIDE_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
+        p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
+        { const char* e = getenv("WNV_WIDE_TRACE_B"); p.trace_b = e ? std::min(std::max(atoi(e), 0), B - 1) : 0; }
+    }
     const int max_li = std::max(nL * PG - 1, head_li + n_head - 1);
     const int grid = 8 * (max_li + 1);
     hipLaunchKernelGGL(wnv_wide_kernel, dim3(grid), dim3(WT), lds, stream, p);
     WIDE_HIP(hipGetLastError());
     WIDE_HIP(hipMemcpyAsync(st->h_status, p.status, sizeof(unsigned int), hipMemcpyDeviceToHost, stream));
     WIDE_HIP(hipStreamSynchronize(stream));
+    if (d_trace) {
+        std::vector<unsigned long long> tr(trace_words);
+        WIDE_HIP(hipMemcpy(tr.data(), d_trace, trace_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        (void)hipFree(d_trace);
+        if (FILE* f = fopen(trace_path, "w")) {
+            fprintf(f, "# step group(L = head) stamps in ns (100 MHz wall clock) relative to the head's send before the first traced step: group: inputs gathered | "
+                       "partials in LDS | u published | own h gathered | next pre ready;  head: skip gathered | next input sent\n");
+            const unsigned long long t00 = tr[((size_t)0 * (L + 1) + L) * 8 + 1];
+            for (int tt = 0; tt < trace_n; ++tt)
+                for (int pos = 0; pos <= L; ++pos) {
+                    fprintf(f, "%d %d", p.trace_t0 + tt, pos);
+                    for (int k = 0; k < 8; ++k) {
+                        const unsigned long long v = tr[((size_t)tt * (L + 1) + pos) * 8 + k];
+                        fprintf(f, " %lld", v ? (long long)(v - t00) * 10 : -1LL);
+                    }
+                    fprintf(f, "\n");
+                }
+            fclose(f);
+        }
+    }
     if (*st->h_status != 0) {
         char buf[160];
         snprintf(buf, sizeof buf, "wide kernel gave up waiting (code 0x%x: 0x1ll / 0x2ll = h / u into group ll, 0x3ll = skip, 0x400 = head, 0x5.. / 0x6.. = own outputs)", *st->h_status);
