@@ -6,7 +6,7 @@
 // GROUP RING.  Every layer gets a GROUP of 8 workgroups on one XCD, one per CU, each owning a slice of the layer's OUTPUT
 // channels with its slice of the weights resident in registers:
 //
-//     head -> group 0 -> group 1 -> ... -> group L-1 -> head        (3-4 groups per XCD, consecutive layers share an XCD)
+//     head -> group 0 -> group 1 -> ... -> group L-1 -> tail group -> head        (4 groups per XCD, consecutive layers share an XCD)
 //
 // ONE hop and ONE mat-vec phase per layer.  Group l-1 publishes the PAIR (u_{l-1}, h_{l-1}) -- its gate outputs and its own layer
 // input; from that pair alone CU j of group l computes, in one pass over its registers (modules.py:127-163 with the residual
@@ -15,16 +15,19 @@
 //     u_l   = tanh . sigmoid (z_l)                           c_l = N_l b_out,l-1                        -> publish 32 values
 //     h_l   = sqrt(.5) (W_out,l-1 u_{l-1} + b + h_{l-1})     64 rows: layer l's input, the reference's own recurrence -> publish
 //     s_{l-1} = W_skip,l-1 u_{l-1} + b                       32 skip channels, summed from group to group (CU j -> CU j)
-//   (group 0 reads h_0 from the head: z_0 = W_cur,0 h_0 + pre_0, and passes h_0 on; the last group gathers its own u for the last
-//   skip term, one more hop once per step).  Behind the chain every CU gathers the full h_l its group just produced, keeps its OWN
-//   copy of the layer's input history (no cross-CU ordering needed) and streams the older taps + the local-conditioning 1x1 of the
-//   NEXT step -- pre_j[t+1], 282 KB of weights per CU -- from L2 / Infinity Cache, once per step for all utterances.
+//   (group 0 reads h_0 from the head: z_0 = W_cur,0 h_0 + pre_0, and passes h_0 on; the TAIL group -- 8 more workgroups -- turns
+//   u_{L-1} into the last skip term and hands the finished skip sum to the head).  Behind the chain every CU copies the full h_l its
+//   group produced into its OWN copy of the layer's input history (no cross-CU ordering needed; deferred by two utterances in a
+//   batch, see run_wide_stage) and streams the older taps + the local-conditioning 1x1 of the NEXT step -- pre_j[t+1], 282 KB of
+//   weights per CU -- from L2 / Infinity Cache, once per step for up to 8 utterances (twice for 9 .. 16).
 //   Hand-off = the ring kernel's data-tagged 8-byte granules; plain stores inside an XCD (the host's placement census verified that
-//   blocks b and b % 8 share an XCD), write-through stores across XCDs.  Mat-vec mapping: lane = output row, the 8 waves split K,
-//   partial sums meet in LDS.  (v1 of this kernel evaluated the layer unfolded, two hops + two phases per layer: 57 us per step.)
+//   blocks b and b % 8 share an XCD), write-through stores across XCDs.  Mat-vec mapping: the 8 waves split K; a lane holds four rows
+//   x a K quarter (dot_quad / reduce_quads: v_permlane32_swap + v_permlane16_swap reduce-scatter), partial sums of the waves meet in
+//   LDS.  (v1 of this kernel evaluated the layer unfolded, two hops + two phases per layer: 57 us per step; one row per lane with the
+//   vector broadcast from LDS was LDS-bandwidth-bound: 39 us; now 36 us.)
 //
 // Models narrower than 512 / 512 / 256 are zero-padded (exact).  Scalar-input models (MoL / Gaussian, out_channels <= 64);
-// utterances beyond the first share the groups like a systolic array (B <= 8).  Every wait is bounded (WNV_ERR_TIMEOUT).
+// utterances beyond the first share the groups like a systolic array (B <= 16).  Every wait is bounded (WNV_ERR_TIMEOUT).
 #include "wnv_wide.h"
 
 #include <algorithm>
@@ -69,7 +72,7 @@ struct WideParams {
     int zb_ld, gh_model;
     const int *lay_dil, *lay_histoff;                     // dilation; float offset of the layer's history inside one copy set
     long long hist_b_floats;                              // floats of history per utterance (all layers, all 8 copies)
-    u64 *xmail, *smail;                                   // X[b][L+1][768] = (u_{l-1} | h_{l-1}) for group l (slot L: the last group's own
+    u64 *xmail, *smail;                                   // X[b][L+1][768] = (u_{l-1} | h_{l-1}) for group l (slot L: the tail group's input and the last layer group's own
                                                           // outputs); SK[b][L+2][256] running skip sums
     float* hist;
     const float *c_up, *initial, *teacher, *noise;
