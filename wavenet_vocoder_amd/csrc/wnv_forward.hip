@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "wnv_dev.h"
@@ -158,7 +159,7 @@ __device__ __forceinline__ void fetch_x_chunk(float (&v)[8], const LayerArgs& a,
     v[4] = q.x * ok_q; v[5] = q.y * ok_q; v[6] = q.z * ok_q; v[7] = q.w * ok_q;
 }
 
-__global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a) {
+__global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel_v9(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const Lds s = carve(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -316,6 +317,275 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
 #endif
 }
 
+// =================================================================================================================================
+// v10 of the layer kernel: the same tile (64 time steps x one layer, 4 waves, two workgroups per CU) with the staging SOFTWARE-
+// PIPELINED under the MFMAs.  v9 spent more cycles per K chunk outside the MFMA phase (wait for the prefetch, commit to LDS, two
+// barriers, issue the next fetch: ~4.5 k cycles) than inside it (4.1 k), so even two workgroups per CU left the matrix pipe idle
+// 30 % of the time.  Here the LDS chunk buffers are double (chunks of 16 K rows, 74 KB per workgroup), a step is
+//     [MFMAs of chunk g out of buffer g % 2]  interleaved in program order with
+//     [the LDS commit of chunk g + 1 (registers loaded during step g - 1) into buffer (g + 1) % 2]  and
+//     [the global loads of chunk g + 2 into the other register set]
+// and ends in ONE barrier.  The matrix pipe executes a 32x32x2 MFMA for 64 cycles during which the wave issues the next LDS reads,
+// one ds_write and one global load: nothing but the barrier skew is left outside the MFMA shadow.  The chunk sequence runs
+// through GEMM1 into GEMM2 (and across its column blocks) without draining.
+constexpr int KL = 16;             // K rows per LDS chunk
+constexpr size_t LDS_FLOATS_L = (size_t)2 * KL * XS + (size_t)2 * KL * WS + (size_t)HC * XS;
+struct Stage { float4 w[4]; float4 x; float xok; };  // one chunk in registers: 16 x 256 weights (4 float4 per thread), 64 x 16 activations (one float4 + its zero mask)
+
+struct ChunkSel { const float* W; int ld, nrows, ncols, k0, c0; };
+// chunk g of the sequence: g < n1p GEMM1 (w_in rows 16 g ..; rows past Kin read as zeros), then 8 chunks per column block of [W_out | W_skip]
+__device__ __forceinline__ ChunkSel chunk_sel(const LayerArgs& a, int g, int n1p, int gtot, int Kin, int ntot) {
+    g = min(g, gtot - 1);                                          // past the end: a harmless re-fetch
+    const bool one = g < n1p;
+    const int r = g - n1p;
+    ChunkSel c;
+    c.W = one ? a.w_in : a.w_os; c.ld = one ? 256 : a.nosp; c.nrows = one ? Kin : HC; c.ncols = one ? 256 : ntot;
+    c.k0 = one ? g * KL : (r & 7) * KL; c.c0 = one ? 0 : 256 * (r >> 3);
+    return c;
+}
+// No masks on the weights: a row past the matrix (the partial last GEMM1 chunk, the idle padding step) meets activations that
+// are zeroed, a column past it feeds accumulator columns that are never stored; the clamps keep every address inside the matrix.
+__device__ __forceinline__ float4 fetch_w_piece(const ChunkSel& c, int q, int tid) {
+    const int f = q * FT + tid;
+    const int k = c.k0 + (f >> 6), col = c.c0 + 4 * (f & 63);
+    return *reinterpret_cast<const float4*>(c.W + (size_t)min(k, c.nrows - 1) * c.ld + min(col, c.ncols - 4));
+}
+// activation chunk g of GEMM1 (16 K values: channels 16 (g % 8) .. of tap g / 8, or conditioning channels), time row m, K values 4 sub ..
+// The zero mask (rows before t = 0, rows past T, channels past cin) is returned separately and applied when the chunk is committed,
+// a step later: nothing in the step that issues a load waits for it.  Branch-free: selected pointers, clamped addresses.
+__device__ __forceinline__ float4 fetch_x_piece(const LayerArgs& a, const float* Hin, const float* cr, long long t, int g, int n1, int sub, float& ok) {
+    g = min(g, n1 - 1);
+    const long long tc = min(t, a.T - 1);
+    const int tap = g < 8 * a.kw;                                  // uniform across the workgroup
+    const int j = g >> 3, ch0 = KL * (g & 7) + 4 * sub;
+    const long long tt = tc - (long long)(a.kw - 1 - j) * a.d;
+    const int c0 = KL * (g - 8 * a.kw) + 4 * sub;                  // cin % 4 == 0 on this path (checked by the host)
+    const int cmax = a.cin > 4 ? a.cin - 4 : 0;
+    const float* p_tap = Hin + (size_t)(tt > 0 ? tt : 0) * HC + ch0;
+    const float* p_c = cr + (size_t)tc * a.cin + min(max(c0, 0), cmax);
+    const float* src = tap ? p_tap : p_c;
+    const int valid = (int)(t < a.T) & (tap ? (int)(tt >= 0) : (int)(c0 < a.cin));
+    ok = valid ? 1.0f : 0.0f;
+    return *reinterpret_cast<const float4*>(src);
+}
+
+// One step of the pipeline (see above).  A = K-major A tile of this chunk (+ kl * XS + m0 + jl applied by the caller), Bw = this
+// chunk's weight buffer (+ kl * WS + jl), Rc = the registers of chunk g + 1 (committed to wc_n / xt_n), Rf = where chunk g + 2 lands.
+template <bool XSTAGE, bool MFMA>
+__device__ __forceinline__ void pipe_step(f16v (&acc)[4], const float* A, const float* Bw, const int (&ncol)[4], const Stage& Rc, float* wc_n, float* xt_n,
+                                          Stage& Rf, const ChunkSel& cs, const LayerArgs& a, const float* Hin, const float* cr, long long t, int gx, int n1, int tid) {
+    const int xm = tid >> 2, xsub = tid & 3;
+    if constexpr (MFMA) {
+        float av = A[0];
+        float bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bv[i] = Bw[ncol[i]];
+        __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+#pragma unroll
+        for (int ks = 0; ks < KL / 2; ++ks) {
+            float an = 0.f, bn[4];
+            if (ks + 1 < KL / 2) {
+                an = A[(2 * ks + 2) * XS];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bn[i] = Bw[(2 * ks + 2) * WS + ncol[i]];
+                __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[i], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            // under these MFMAs: one piece of the fetch of chunk g + 2 and one piece of the commit of chunk g + 1
+            if (ks < 4) {
+                Rf.w[ks] = fetch_w_piece(cs, ks, tid);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                reinterpret_cast<float4*>(wc_n)[ks * FT + tid] = Rc.w[ks];
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            } else if (XSTAGE) {
+                if (ks == 4) { Rf.x = fetch_x_piece(a, Hin, cr, t, gx, n1, xsub, Rf.xok); __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); }
+                const float xv = ks == 4 ? Rc.x.x : ks == 5 ? Rc.x.y : ks == 6 ? Rc.x.z : Rc.x.w;
+                xt_n[(4 * xsub + (ks - 4)) * XS + xm] = xv * Rc.xok;
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            if (ks + 1 < KL / 2) {
+                av = an;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bv[i] = bn[i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Rf.w[q] = fetch_w_piece(cs, q, tid);
+        if (XSTAGE) Rf.x = fetch_x_piece(a, Hin, cr, t, gx, n1, xsub, Rf.xok);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(wc_n)[q * FT + tid] = Rc.w[q];
+        if (XSTAGE) {
+            xt_n[(4 * xsub + 0) * XS + xm] = Rc.x.x * Rc.xok; xt_n[(4 * xsub + 1) * XS + xm] = Rc.x.y * Rc.xok;
+            xt_n[(4 * xsub + 2) * XS + xm] = Rc.x.z * Rc.xok; xt_n[(4 * xsub + 3) * XS + xm] = Rc.x.w * Rc.xok;
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const xt0 = smem;                                       // [2][KL][XS] activation chunks, K-major
+    float* const wc0 = smem + 2 * KL * XS;                         // [2][KL][WS] weight chunks
+    float* const ut = wc0 + 2 * KL * WS;                           // [128][XS]   gate outputs, K-major
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / a.tiles_per_utt;
+    const long long t0 = (long long)(blockIdx.x % a.tiles_per_utt) * TM;
+    const int rb = wave & 1, cb = wave >> 1;
+    const int m0 = 32 * rb;
+    const int kl = lane >> 5, jl = lane & 31;
+    const float* Hin = a.Hin + (size_t)b * a.T * HC;
+    const int Kin = a.kw * HC + a.cin;
+    const int n1 = (Kin + KL - 1) / KL, n1p = (n1 + 1) & ~1;       // GEMM1 steps, padded to an even count (the extra step runs no MFMAs)
+    const int ntot = HC + a.K, nblk = (ntot + 255) / 256, gtot = n1p + 8 * nblk;
+    const int xm = tid >> 2, xsub = tid & 3;
+    const long long tx = t0 + xm;
+    const float* cr = a.c_up ? a.c_up + (size_t)b * a.T * a.cin : Hin;      // conditioning rows of this utterance (no c: any valid address)
+
+    f16v acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+    const int ncol1[4] = {64 * cb, 64 * cb + 32, HC + 64 * cb, HC + 64 * cb + 32};      // tanh tiles, sigmoid tiles of the same channels
+    const int ncol2[4] = {128 * cb, 128 * cb + 32, 128 * cb + 64, 128 * cb + 96};
+    Stage RA, RB;
+    // ---- prologue: chunk 0 into buffer 0, chunk 1 into RA ---------------------------------------------------------------------
+    {
+        const ChunkSel c0s = chunk_sel(a, 0, n1p, gtot, Kin, ntot), c1s = chunk_sel(a, 1, n1p, gtot, Kin, ntot);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) RB.w[q] = fetch_w_piece(c0s, q, tid);
+        RB.x = fetch_x_piece(a, Hin, cr, tx, 0, n1, xsub, RB.xok);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) RA.w[q] = fetch_w_piece(c1s, q, tid);
+        RA.x = fetch_x_piece(a, Hin, cr, tx, 1, n1, xsub, RA.xok);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(wc0)[q * FT + tid] = RB.w[q];
+        xt0[(4 * xsub + 0) * XS + xm] = RB.x.x * RB.xok; xt0[(4 * xsub + 1) * XS + xm] = RB.x.y * RB.xok;
+        xt0[(4 * xsub + 2) * XS + xm] = RB.x.z * RB.xok; xt0[(4 * xsub + 3) * XS + xm] = RB.x.w * RB.xok;
+        __syncthreads();
+    }
+    // ---- GEMM1: Z = [taps | c] W_in, two steps per iteration (the register sets swap roles) -------------------------------------
+    for (int g = 0; g < n1p; g += 2) {
+        {
+            const ChunkSel cs = chunk_sel(a, g + 2, n1p, gtot, Kin, ntot);
+            pipe_step<true, true>(acc, xt0 + kl * XS + m0 + jl, wc0 + kl * WS + jl, ncol1, RA, wc0 + KL * WS, xt0 + KL * XS, RB, cs, a, Hin, cr, tx, g + 2, n1, tid);
+        }
+        {
+            const ChunkSel cs = chunk_sel(a, g + 3, n1p, gtot, Kin, ntot);
+            if (g + 1 < n1)
+                pipe_step<true, true>(acc, xt0 + KL * XS + kl * XS + m0 + jl, wc0 + KL * WS + kl * WS + jl, ncol1, RB, wc0, xt0, RA, cs, a, Hin, cr, tx, g + 3, n1, tid);
+            else
+                pipe_step<true, false>(acc, xt0 + KL * XS + kl * XS + m0 + jl, wc0 + KL * WS + kl * WS + jl, ncol1, RB, wc0, xt0, RA, cs, a, Hin, cr, tx, g + 3, n1, tid);
+        }
+    }
+    // ---- bias (+ global conditioning), tanh . sigmoid -> U tile, K-major ---------------------------------------------------
+    {
+        const float* zb = a.zbias + (size_t)b * a.zb_bstride;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ch = 64 * cb + 32 * j + (lane & 31);
+            const float za = zb[ch], zg = zb[HC + ch];
+#pragma unroll
+            for (int v = 0; v < 16; ++v)
+                ut[ch * XS + m0 + acc_row(v, lane)] = fwd_gate(acc[j][v] + za, acc[2 + j][v] + zg);      // modules.py:152-154
+        }
+    }
+    __syncthreads();
+    // ---- GEMM2: [out | skip] = U [W_out | W_skip], in column blocks of 256 ---------------------------------------------------
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int c0 = 256 * blk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
+        for (int kc = 0; kc < HC / KL; kc += 2) {
+            const int g = n1p + 8 * blk + kc;
+            {
+                const ChunkSel cs = chunk_sel(a, g + 2, n1p, gtot, Kin, ntot);
+                pipe_step<false, true>(acc, ut + kc * KL * XS + kl * XS + m0 + jl, wc0 + kl * WS + jl, ncol2, RA, wc0 + KL * WS, xt0, RB, cs, a, Hin, cr, tx, 0, n1, tid);
+            }
+            {
+                const ChunkSel cs = chunk_sel(a, g + 3, n1p, gtot, Kin, ntot);
+                pipe_step<false, true>(acc, ut + (kc + 1) * KL * XS + kl * XS + m0 + jl, wc0 + KL * WS + kl * WS + jl, ncol2, RB, wc0, xt0, RA, cs, a, Hin, cr, tx, 0, n1, tid);
+            }
+        }
+        // epilogue in two passes: every residual / skip value this thread needs is requested first (64 loads in flight), then the
+        // results are combined and stored.  (Load -> add -> store per element serialises on the memory latency: the compiler
+        // cannot prove that Hout / Skip do not alias Hin; the phase trace showed 43 % of a workgroup's time here.)
+        const bool interior = t0 + TM <= a.T && c0 + 256 <= ntot;        // uniform: no per-element conditions, no branches
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {                          // two tiles at a time: 32 loads in flight, 32 registers
+            float prev[2][16];
+            if (interior) {
+                // Addresses as  WAVE-UNIFORM row pointer (scalar registers) + ONE 32-bit per-lane offset: row v of the accumulator is
+                // time step t0 + m0 + 8 (v / 4) + v % 4 (+ 4 for the upper half-wave), column gc; a 32-column tile lies entirely in
+                // the residual block or entirely in the skip block.  (Per-element 64-bit addresses cost 64 VGPRs here and pushed the
+                // kernel into 87 spilled registers.)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col0 = __builtin_amdgcn_readfirstlane(c0 + 128 * cb + 32 * (2 * half + j));      // first column of the tile
+                    const bool res = col0 < HC;
+                    const int ld = res ? HC : a.K;
+                    const float* base = (res ? Hin + col0 : a.Skip + (size_t)b * a.T * a.K + (col0 - HC)) + (size_t)(t0 + m0) * ld;
+                    const int loff = 4 * (lane >> 5) * ld + (lane & 31);
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) prev[j][v] = (base + (size_t)(8 * (v >> 2) + (v & 3)) * ld)[loff];
+                }
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int i = 2 * half + j;
+                    const int col0 = __builtin_amdgcn_readfirstlane(c0 + 128 * cb + 32 * i);
+                    const bool res = col0 < HC;
+                    const int ld = res ? HC : a.K;
+                    const float bias = a.b_os[col0 + (lane & 31)];
+                    float* base = (res ? a.Hout + (size_t)b * a.T * HC + col0 : a.Skip + (size_t)b * a.T * a.K + (col0 - HC)) + (size_t)(t0 + m0) * ld;
+                    const int loff = 4 * (lane >> 5) * ld + (lane & 31);
+                    const float scale = res ? 0.70710678118654752440f : 1.0f;        // (out + residual) * sqrt(0.5) | skips += s
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) (base + (size_t)(8 * (v >> 2) + (v & 3)) * ld)[loff] = (prev[j][v] + (acc[i][v] + bias)) * scale;
+                }
+                continue;
+            }
+            // edge tiles (the last time tile of an utterance, a partial column block): the same addressing with per-element
+            // predicates; rows are 32-bit offsets from wave-uniform bases, so nothing 64-bit is kept per element
+            const int rows_left = (int)min((long long)TM, a.T - t0) - m0;         // valid rows of this wave's 32-row block (may be <= 0)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col0 = __builtin_amdgcn_readfirstlane(c0 + 128 * cb + 32 * (2 * half + j));
+                const bool res = col0 < HC;
+                const int ld = res ? HC : a.K;
+                const float* base = (res ? Hin : a.Skip + (size_t)b * a.T * a.K - HC) + (size_t)(t0 + m0) * ld;
+                const int gc = col0 + (lane & 31);
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = acc_row(v, lane);
+                    prev[j][v] = (gc < ntot && row < rows_left) ? base[row * ld + gc] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int i = 2 * half + j;
+                const int col0 = __builtin_amdgcn_readfirstlane(c0 + 128 * cb + 32 * i);
+                const bool res = col0 < HC;
+                const int ld = res ? HC : a.K;
+                const int gc = col0 + (lane & 31);
+                if (gc >= ntot) continue;
+                const float bias = a.b_os[gc];
+                float* base = (res ? a.Hout + (size_t)b * a.T * HC : a.Skip + (size_t)b * a.T * a.K - HC) + (size_t)(t0 + m0) * ld;
+                const float scale = res ? 0.70710678118654752440f : 1.0f;            // modules.py:157-162 | wavenet.py:196-198
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int row = acc_row(v, lane);
+                    if (row < rows_left) base[row * ld + gc] = (prev[j][v] + (acc[i][v] + bias)) * scale;
+                }
+            }
+        }
+    }
+}
+
 struct HeadArgs {
     const float* Skip; float* out;                      // (B, T, K) -> (B, O, T)
     const float *w_h1, *b_h1, *w_h2, *b_h2;             // K-major [K][kp], [kp], [K][op], [op]
@@ -447,8 +717,11 @@ hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_ho
                            H0, m.cin1, T, n);
     }
     const int tiles = (int)((T + TM - 1) / TM);
-    const size_t lds = LDS_FLOATS * sizeof(float);
-    e = hipFuncSetAttribute((const void*)wnv_fwd_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const size_t lds = LDS_FLOATS * sizeof(float), lds_l = LDS_FLOATS_L * sizeof(float);
+    static const bool use_v9 = [] { const char* e = getenv("WNV_FWD_V9"); return e && e[0] == '1'; }();       // the previous layer kernel, for A/B runs
+    e = hipFuncSetAttribute((const void*)wnv_fwd_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute((const void*)wnv_fwd_layer_kernel_v9, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute((const void*)wnv_fwd_head_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -460,7 +733,8 @@ hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_ho
         la.zbias = a.zbias + (size_t)l * m.Gp; la.zb_bstride = a.zbias_bstride;
         la.w_in = d_W + Ld.w_in; la.w_os = d_W + Ld.w_os; la.b_os = d_W + Ld.b_os;
         la.T = T; la.tiles_per_utt = tiles; la.d = Ld.dilation; la.kw = m.kw; la.cin = m.cin; la.K = m.K; la.nosp = m.NOSp;
-        hipLaunchKernelGGL(wnv_fwd_layer_kernel, dim3((unsigned)(B * tiles)), dim3(FT), lds, s, la);
+        if (use_v9) hipLaunchKernelGGL(wnv_fwd_layer_kernel_v9, dim3((unsigned)(B * tiles)), dim3(FT), lds, s, la);
+        else hipLaunchKernelGGL(wnv_fwd_layer_kernel, dim3((unsigned)(B * tiles)), dim3(FT), lds_l, s, la);
         std::swap(in, out);
     }
 #ifdef WNV_FWD_TRACE
