@@ -452,6 +452,10 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
     const int ncol1[4] = {64 * cb, 64 * cb + 32, HC + 64 * cb, HC + 64 * cb + 32};      // tanh tiles, sigmoid tiles of the same channels
     const int ncol2[4] = {128 * cb, 128 * cb + 32, 128 * cb + 64, 128 * cb + 96};
     Stage RA, RB;
+#ifdef WNV_FWD_TRACE
+    unsigned long long ph__[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev__ = __builtin_readcyclecounter();
+#endif
     // ---- prologue: chunk 0 into buffer 0, chunk 1 into RA ---------------------------------------------------------------------
     {
         const ChunkSel c0s = chunk_sel(a, 0, n1p, gtot, Kin, ntot), c1s = chunk_sel(a, 1, n1p, gtot, Kin, ntot);
@@ -467,6 +471,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
         xt0[(4 * xsub + 2) * XS + xm] = RB.x.z * RB.xok; xt0[(4 * xsub + 3) * XS + xm] = RB.x.w * RB.xok;
         __syncthreads();
     }
+    FWD_STAMP(0);                                                 // 0: prologue
     // ---- GEMM1: Z = [taps | c] W_in, two steps per iteration (the register sets swap roles) -------------------------------------
     for (int g = 0; g < n1p; g += 2) {
         {
@@ -481,6 +486,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
                 pipe_step<true, false>(acc, xt0 + KL * XS + kl * XS + m0 + jl, wc0 + KL * WS + kl * WS + jl, ncol1, RB, wc0, xt0, RA, cs, a, Hin, cr, tx, g + 3, n1, tid);
         }
     }
+    FWD_STAMP(5);                                                 // 5: GEMM1 steps
     // ---- bias (+ global conditioning), tanh . sigmoid -> U tile, K-major ---------------------------------------------------
     {
         const float* zb = a.zbias + (size_t)b * a.zb_bstride;
@@ -494,6 +500,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
         }
     }
     __syncthreads();
+    FWD_STAMP(6);                                                 // 6: gate
     // ---- GEMM2: [out | skip] = U [W_out | W_skip], in column blocks of 256 ---------------------------------------------------
     for (int blk = 0; blk < nblk; ++blk) {
         const int c0 = 256 * blk;
@@ -512,6 +519,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
                 pipe_step<false, true>(acc, ut + (kc + 1) * KL * XS + kl * XS + m0 + jl, wc0 + KL * WS + kl * WS + jl, ncol2, RB, wc0, xt0, RA, cs, a, Hin, cr, tx, 0, n1, tid);
             }
         }
+        FWD_STAMP(7);                                             // 7: GEMM2 steps
         // epilogue in two passes: every residual / skip value this thread needs is requested first (64 loads in flight), then the
         // results are combined and stored.  (Load -> add -> store per element serialises on the memory latency: the compiler
         // cannot prove that Hout / Skip do not alias Hin; the phase trace showed 43 % of a workgroup's time here.)
@@ -583,7 +591,14 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
                 }
             }
         }
+        FWD_STAMP(8);                                             // 8: epilogue
     }
+#ifdef WNV_FWD_TRACE
+    if (tid == 0) {
+        for (int q = 0; q < 9; ++q) atomicAdd(&g_fwd_phase[q], ph__[q]);
+        atomicAdd(&g_fwd_phase[15], 1ull);
+    }
+#endif
 }
 
 struct HeadArgs {
