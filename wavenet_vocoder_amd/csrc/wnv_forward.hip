@@ -77,59 +77,96 @@ struct LayerArgs {
 // padded to even (a padding step runs no MFMAs).  Then GEMM2: for each block of 128 output channels, 4 chunks = rows [32 c, 32 c + 32)
 // of [W_out | W_skip] x the block's 128 columns.  A chunk is 1024 float4 in both cases, row-major: thread tid stages the float4s
 // q * 256 + tid (q = 0 .. 3), a wave reads a contiguous KiB per load and writes 64 consecutive 16-byte LDS slots per store.
-struct ChunkSel { const float* W; int ld, nrows, ncols, k0, c0, sh; };
-__device__ __forceinline__ ChunkSel chunk_sel(const LayerArgs& a, int g, int n1p, int gtot, int Kin, int ntot) {
+//
+// NO VECTOR ALU WORK IN THE STEPS.  On this chip an ordinary VALU instruction takes matrix-pipe time (scripts/ubench_mfma_peak.hip:
+// every VALU op issued between f32 MFMAs costs 3 - 5 cycles of the 64 an MFMA takes; f32 MFMA and packed f32 FMA share their peak rate),
+// and v11's steps carried ~200 of them per 64 MFMAs (per-element addresses, clamps, masks): 22 % of the pipe.  Every global address
+// of a step is therefore  WAVE-UNIFORM base (scalar ALU) + a per-thread byte offset computed ONCE per tile;  masks, clamps and
+// unaligned windows are resolved by uniform branches into a fast kind (nothing but loads and LDS stores) and a generic slow kind
+// (edge tiles, partial chunks, time steps before the utterance starts).
+struct Thr {                                             // per-thread constants of the staging maps
+    unsigned w1;                                         // GEMM1 weight chunk: float4 tid of a contiguous 16 KB chunk
+    unsigned w2;                                         // GEMM2 weight chunk: row tid / 32 (+ 8 q), float4 tid % 32 of [32][128] in a matrix of row stride nosp
+    unsigned xtap;                                       // tap rows: row tid / 16, time 8 (tid % 16) of channel-major (., T)
+    unsigned xcond;                                      // conditioning: time tid / 2, channels 8 (tid % 2) of time-major (., cin)
+    int l_tap, l_cond;                                   // where those land in the K-major LDS chunk (floats)
+};
+
+struct WSel { const float* base; unsigned qstride; bool fast, one; int k0, c0; };        // fast: base + Thr offset + q * qstride (bytes); else generic
+__device__ __forceinline__ WSel w_sel(const LayerArgs& a, int g, int n1p, int gtot, int Kin) {
     g = min(g, gtot - 1);                                          // past the end: a harmless re-fetch
-    const bool one = g < n1p;
+    WSel w;
+    w.one = g < n1p;
     const int r = g - n1p;
-    ChunkSel c;
-    c.W = one ? a.w_in : a.w_os; c.ld = one ? 256 : a.nosp; c.nrows = one ? Kin : HC; c.ncols = one ? 256 : ntot;
-    c.k0 = one ? g * KT : (r & 3) * 32; c.c0 = one ? 0 : 128 * (r >> 2); c.sh = one ? 6 : 5;
-    return c;
+    w.k0 = w.one ? g * KT : (r & 3) * 32; w.c0 = w.one ? 0 : 128 * (r >> 2);
+    w.fast = !w.one || w.k0 + KT <= Kin;
+    w.base = w.one ? a.w_in + (size_t)w.k0 * 256 : a.w_os + (size_t)w.k0 * a.nosp + w.c0;
+    w.qstride = w.one ? 4096u : 32u * (unsigned)a.nosp;            // 4 rows of 256 floats | 8 rows of the [W_out | W_skip] matrix
+    return w;
 }
 // No masks on the weights: a row past the matrix (the partial last GEMM1 chunk, the idle padding step) meets activations that are
-// zeroed, a column past it feeds accumulator rows that are never stored; the clamps keep every address inside the matrix.
-__device__ __forceinline__ float4 fetch_w_piece(const ChunkSel& c, int q, int tid) {
-    const int f = q * FT + tid;
-    const int k = c.k0 + (f >> c.sh), col = c.c0 + 4 * (f & ((1 << c.sh) - 1));
-    return *reinterpret_cast<const float4*>(c.W + (size_t)min(k, c.nrows - 1) * c.ld + min(col, c.ncols - 4));
+// zeroed, a column past it feeds accumulator rows that are never stored; the clamps of the generic kind keep every address inside.
+__device__ __forceinline__ float4 fetch_w_piece(const WSel& w, const LayerArgs& a, const Thr& th, int q, int tid, int Kin) {
+    if (w.fast) return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.base) + (size_t)(w.one ? th.w1 : th.w2) + (size_t)q * w.qstride);
+    const int f = q * FT + tid, k = w.k0 + (f >> 6), col = 4 * (f & 63);          // (only GEMM1 chunks can be partial)
+    return *reinterpret_cast<const float4*>(a.w_in + (size_t)min(k, Kin - 1) * 256 + col);
 }
 
-// One chunk in registers: the weights, the activations (8 floats per thread) and which of those are real (bit e of xmask; the rest
-// are zeros: rows before t = 0, rows past T, channels past cin).  The mask is applied when the chunk is committed to LDS, a step after
-// the loads were issued: nothing in the step that issues a load waits for it.
-struct Stage { float4 w[4]; float4 x[2]; unsigned xmask; };
+// One chunk in registers: the weights and the activations -- 8 floats per thread; an unaligned tap window is loaded as three aligned
+// float4 and cut at commit time; the generic kind carries a validity mask (bit e of xmask: rows before t = 0, rows past T, channels past
+// cin read as zeros), applied at commit: nothing in the step that issues a load waits for it.
+struct Stage { float4 w[4]; float4 x[3]; unsigned xmask; };
 
 // activation chunk g of GEMM1: tap chunks (g < 8 kw: channels 16 (g % 8) .. + 16 of tap g / 8, oldest first, conv.py:55-61) come
-// from the channel-major layer input -- thread (row r = tid / 16, 8 consecutive time steps m8 = 8 (tid % 16)); conditioning chunks
-// (modules.py:141-144) from the time-major c -- thread (time m = tid / 2, 8 channels).  Branch-free inside each kind.
-__device__ __forceinline__ void fetch_x(Stage& R, const LayerArgs& a, int b, long long t0, int g, int n1, int tid, bool aligned_T) {
-    g = min(g, n1 - 1);
+// from the channel-major layer input -- thread (row tid / 16, 8 consecutive time steps 8 (tid % 16)); conditioning chunks
+// (modules.py:141-144) from the time-major c -- thread (time tid / 2, 8 channels).
+// kind 0: tap, 16-byte aligned window; 1 .. 3: tap, the window starts r floats into the first of three aligned float4; 4: full
+// conditioning chunk; 5: generic (element loads, clamped addresses, mask).
+struct XSel { int kind; const float* base; int g; };
+__device__ __forceinline__ XSel x_sel(const LayerArgs& a, int b, long long t0, int g, int n1, bool aligned_T) {
+    XSel x;
+    x.g = g = min(g, n1 - 1);
     if (g < 8 * a.kw) {
-        const int j = g >> 3, ch = KT * (g & 7) + (tid >> 4), m8 = 8 * (tid & 15);
-        const long long shift = (long long)(a.kw - 1 - j) * a.d;
-        const float* row = a.Hin + ((size_t)b * HC + ch) * a.T;
-        const long long ts = t0 + m8 - shift;
-        if (aligned_T && (shift & 3) == 0 && t0 >= shift && t0 + TN <= a.T) {      // uniform: interior tile, 16-byte aligned window
-            R.x[0] = *reinterpret_cast<const float4*>(row + ts);
-            R.x[1] = *reinterpret_cast<const float4*>(row + ts + 4);
-            R.xmask = 0xFFu;
-        } else {
-            float v[8];
-            unsigned mk = 0;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const long long te = ts + e;
-                v[e] = row[min(max(te, 0ll), a.T - 1)];
-                mk |= (te >= 0 && te < a.T) ? (1u << e) : 0u;
-            }
-            R.x[0] = make_float4(v[0], v[1], v[2], v[3]);
-            R.x[1] = make_float4(v[4], v[5], v[6], v[7]);
-            R.xmask = mk;
-        }
+        const long long shift = (long long)(a.kw - 1 - (g >> 3)) * a.d;
+        const int r = (int)((4 - (shift & 3)) & 3);
+        const long long start = t0 - shift - r;                    // (t0 + 8 (tid % 16) - shift) rounded down to a multiple of 4
+        x.base = a.Hin + ((size_t)b * HC + KT * (g & 7)) * a.T + start;
+        x.kind = (aligned_T && start >= 0 && t0 + TN <= a.T) ? r : 5;
     } else {
-        const int m = tid >> 1, c = KT * (g - 8 * a.kw) + 8 * (tid & 1);            // cin % 4 == 0 on this path (checked by the host)
-        const long long t = t0 + m;
+        const int c0 = KT * (g - 8 * a.kw);
+        x.base = a.c_up + ((size_t)b * a.T + t0) * a.cin + c0;
+        x.kind = (t0 + TN <= a.T && c0 + KT <= a.cin) ? 4 : 5;
+    }
+    return x;
+}
+__device__ __forceinline__ void fetch_x(Stage& R, const XSel& x, const LayerArgs& a, const Thr& th, int b, long long t0, int tid) {
+    if (x.kind < 4) {
+        const char* p = reinterpret_cast<const char*>(x.base) + (size_t)th.xtap;
+        R.x[0] = *reinterpret_cast<const float4*>(p);
+        R.x[1] = *reinterpret_cast<const float4*>(p + 16);
+        if (x.kind > 0) R.x[2] = *reinterpret_cast<const float4*>(p + 32);
+    } else if (x.kind == 4) {
+        const char* p = reinterpret_cast<const char*>(x.base) + (size_t)th.xcond;
+        R.x[0] = *reinterpret_cast<const float4*>(p);
+        R.x[1] = *reinterpret_cast<const float4*>(p + 16);
+    } else if (x.g < 8 * a.kw) {
+        const int ch = KT * (x.g & 7) + (tid >> 4);
+        const long long ts = t0 + 8 * (tid & 15) - (long long)(a.kw - 1 - (x.g >> 3)) * a.d;
+        const float* row = a.Hin + ((size_t)b * HC + ch) * a.T;
+        float v[8];
+        unsigned mk = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const long long te = ts + e;
+            v[e] = row[min(max(te, 0ll), a.T - 1)];
+            mk |= (te >= 0 && te < a.T) ? (1u << e) : 0u;
+        }
+        R.x[0] = make_float4(v[0], v[1], v[2], v[3]);
+        R.x[1] = make_float4(v[4], v[5], v[6], v[7]);
+        R.xmask = mk;
+    } else {
+        const int c = KT * (x.g - 8 * a.kw) + 8 * (tid & 1);                          // cin % 4 == 0 on this path (checked by the host)
+        const long long t = t0 + (tid >> 1);
         const float* p = a.c_up + ((size_t)b * a.T + min(t, a.T - 1)) * a.cin;
         R.x[0] = *reinterpret_cast<const float4*>(p + min(c, a.cin - 4));
         R.x[1] = *reinterpret_cast<const float4*>(p + min(c + 4, a.cin - 4));
@@ -139,23 +176,30 @@ __device__ __forceinline__ void fetch_x(Stage& R, const LayerArgs& a, int b, lon
 __device__ __forceinline__ float4 masked(const float4& v, unsigned m4) {
     return make_float4((m4 & 1u) ? v.x : 0.f, (m4 & 2u) ? v.y : 0.f, (m4 & 4u) ? v.z : 0.f, (m4 & 8u) ? v.w : 0.f);
 }
-// commit piece `part` (0, 1) of the activations of chunk g into the K-major LDS chunk xt [16][XT]
-__device__ __forceinline__ void commit_x(float* xt, const Stage& R, const LayerArgs& a, int g, int n1, int tid, int part) {
-    g = min(g, n1 - 1);
-    const float4 v = masked(R.x[part], R.xmask >> (4 * part));
-    if (g < 8 * a.kw) {
-        *reinterpret_cast<float4*>(xt + (tid >> 4) * XT + 8 * (tid & 15) + 4 * part) = v;
+// commit the activations of a chunk into the K-major LDS chunk xt [16][XT]
+__device__ __forceinline__ void commit_x(float* xt, const Stage& R, const XSel& x, const LayerArgs& a, const Thr& th) {
+    float4 lo = R.x[0], hi = R.x[1];
+    const bool tap = x.g < 8 * a.kw;
+    if (x.kind == 1) { lo = make_float4(R.x[0].y, R.x[0].z, R.x[0].w, R.x[1].x); hi = make_float4(R.x[1].y, R.x[1].z, R.x[1].w, R.x[2].x); }
+    else if (x.kind == 2) { lo = make_float4(R.x[0].z, R.x[0].w, R.x[1].x, R.x[1].y); hi = make_float4(R.x[1].z, R.x[1].w, R.x[2].x, R.x[2].y); }
+    else if (x.kind == 3) { lo = make_float4(R.x[0].w, R.x[1].x, R.x[1].y, R.x[1].z); hi = make_float4(R.x[1].w, R.x[2].x, R.x[2].y, R.x[2].z); }
+    else if (x.kind == 5) { lo = masked(lo, R.xmask); hi = masked(hi, R.xmask >> 4); }
+    if (tap) {
+        *reinterpret_cast<float4*>(xt + th.l_tap) = lo;
+        *reinterpret_cast<float4*>(xt + th.l_tap + 4) = hi;
     } else {
-        float* dst = xt + (8 * (tid & 1) + 4 * part) * XT + (tid >> 1);
-        dst[0] = v.x; dst[XT] = v.y; dst[2 * XT] = v.z; dst[3 * XT] = v.w;
+        float* dst = xt + th.l_cond;
+        dst[0] = lo.x; dst[XT] = lo.y; dst[2 * XT] = lo.z; dst[3 * XT] = lo.w;
+        dst[4 * XT] = hi.x; dst[5 * XT] = hi.y; dst[6 * XT] = hi.z; dst[7 * XT] = hi.w;
     }
 }
 
 // ---- one GEMM1 step: 64 MFMAs (8 k-pairs x 8 channel tiles) out of chunk buffers (xt, wc); in their shadow the commit of chunk
-// g + 1 (registers Rc, loaded a step ago) into the other buffers and the loads of chunk g + 2 into Rf.  Ends in the one barrier.
+// g + 1 (registers Rc, loaded a step ago; selector xc) into the other buffers and the loads of chunk g + 2 (selectors wf, xf) into Rf.
+// Ends in the one barrier.
 template <bool MFMA>
-__device__ __forceinline__ void gemm1_step(f16v (&acc)[8], const float* xt, const float* wc, const Stage& Rc, float* xt_n, float* wc_n, Stage& Rf,
-                                           const ChunkSel& cs, const LayerArgs& a, int b, long long t0, int g, int n1, int tid, int lane, int wave, bool aligned_T) {
+__device__ __forceinline__ void gemm1_step(f16v (&acc)[8], const float* xt, const float* wc, const Stage& Rc, const XSel& xc, float* xt_n, float* wc_n, Stage& Rf,
+                                           const WSel& wf, const XSel& xf, const LayerArgs& a, const Thr& th, int b, long long t0, int Kin, int tid, int lane, int wave) {
     if constexpr (MFMA) {
         const float* Xb = xt + (lane >> 5) * XT + 32 * wave + (lane & 31);
         const float* Wa = wc + (lane >> 5) * 256 + (lane & 31);
@@ -177,16 +221,12 @@ __device__ __forceinline__ void gemm1_step(f16v (&acc)[8], const float* xt, cons
             for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
             if (ks < 4) {
-                Rf.w[ks] = fetch_w_piece(cs, ks, tid);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                Rf.w[ks] = fetch_w_piece(wf, a, th, ks, tid, Kin);
                 reinterpret_cast<float4*>(wc_n)[ks * FT + tid] = Rc.w[ks];
-                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
             } else if (ks == 4) {
-                fetch_x(Rf, a, b, t0, g + 2, n1, tid, aligned_T);
+                fetch_x(Rf, xf, a, th, b, t0, tid);
             } else if (ks == 5) {
-                commit_x(xt_n, Rc, a, g + 1, n1, tid, 0);
-            } else if (ks == 6) {
-                commit_x(xt_n, Rc, a, g + 1, n1, tid, 1);
+                commit_x(xt_n, Rc, xc, a, th);
             }
             if (ks + 1 < KT / 2) {
                 bv = bn;
@@ -196,12 +236,11 @@ __device__ __forceinline__ void gemm1_step(f16v (&acc)[8], const float* xt, cons
         }
     } else {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Rf.w[q] = fetch_w_piece(cs, q, tid);
-        fetch_x(Rf, a, b, t0, g + 2, n1, tid, aligned_T);
+        for (int q = 0; q < 4; ++q) Rf.w[q] = fetch_w_piece(wf, a, th, q, tid, Kin);
+        fetch_x(Rf, xf, a, th, b, t0, tid);
 #pragma unroll
         for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(wc_n)[q * FT + tid] = Rc.w[q];
-        commit_x(xt_n, Rc, a, g + 1, n1, tid, 0);
-        commit_x(xt_n, Rc, a, g + 1, n1, tid, 1);
+        commit_x(xt_n, Rc, xc, a, th);
     }
     __syncthreads();
 }
@@ -209,8 +248,8 @@ __device__ __forceinline__ void gemm1_step(f16v (&acc)[8], const float* xt, cons
 // ---- one GEMM2 step: 64 MFMAs (16 k-pairs x 4 channel tiles).  B operand = the gated accumulator registers u[0 .. 15] of one
 // 32-channel tile (register s holds channels 8 (s / 4) + s % 4 and + 4 of the tile: the k pair of MFMA s); A = the matching rows
 // of the weight chunk [32 k][128 channels].  Weight staging as in gemm1_step.
-__device__ __forceinline__ void gemm2_step(f16v (&acc)[4], const f16v& u, const float* wc, const Stage& Rc, float* wc_n, Stage& Rf, const ChunkSel& cs,
-                                           int tid, int lane) {
+__device__ __forceinline__ void gemm2_step(f16v (&acc)[4], const f16v& u, const float* wc, const Stage& Rc, float* wc_n, Stage& Rf, const WSel& wf,
+                                           const LayerArgs& a, const Thr& th, int Kin, int tid, int lane) {
     const float* Wa = wc + (4 * (lane >> 5)) * 128 + (lane & 31);
     float av[4];
 #pragma unroll
@@ -229,7 +268,7 @@ __device__ __forceinline__ void gemm2_step(f16v (&acc)[4], const f16v& u, const 
         for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], u[s], acc[i], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
         if (s < 4) {
-            Rf.w[s] = fetch_w_piece(cs, s, tid);
+            Rf.w[s] = fetch_w_piece(wf, a, th, s, tid, Kin);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         } else if (s >= 8 && s < 12) {
             reinterpret_cast<float4*>(wc_n)[(s - 8) * FT + tid] = Rc.w[s - 8];
@@ -256,12 +295,14 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
     const int ntot = HC + a.K, nblk = ntot / HC, gtot = n1p + 4 * nblk;
     const bool aligned_T = (a.T & 3) == 0;
     const bool interior = t0 + TN <= a.T;
+    Thr th;
+    th.w1 = 16u * (unsigned)tid;
+    th.w2 = 4u * ((unsigned)(tid >> 5) * (unsigned)a.nosp + 4u * (unsigned)(tid & 31));
+    th.xtap = 4u * ((unsigned)(tid >> 4) * (unsigned)a.T + 8u * (unsigned)(tid & 15));          // (T <= 2^26: the host checks)
+    th.xcond = 4u * ((unsigned)(tid >> 1) * (unsigned)a.cin + 8u * (unsigned)(tid & 1));
+    th.l_tap = (tid >> 4) * XT + 8 * (tid & 15);
+    th.l_cond = 8 * (tid & 1) * XT + (tid >> 1);
 
-    f16v acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[i][v] = 0.f;
     Stage RA, RB;
 #ifdef WNV_FWD_TRACE
     unsigned long long ph__[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -272,91 +313,97 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
     {
         bz[tid] = a.zbias[(size_t)b * a.zb_bstride + tid];
         for (int i = tid; i < ntot; i += FT) bz[256 + i] = a.b_os[i];
-        const ChunkSel c0s = chunk_sel(a, 0, n1p, gtot, Kin, ntot), c1s = chunk_sel(a, 1, n1p, gtot, Kin, ntot);
+        const WSel w0 = w_sel(a, 0, n1p, gtot, Kin), w1 = w_sel(a, 1, n1p, gtot, Kin);
+        const XSel x0 = x_sel(a, b, t0, 0, n1, aligned_T), x1 = x_sel(a, b, t0, 1, n1, aligned_T);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) RB.w[q] = fetch_w_piece(c0s, q, tid);
-        fetch_x(RB, a, b, t0, 0, n1, tid, aligned_T);
+        for (int q = 0; q < 4; ++q) RB.w[q] = fetch_w_piece(w0, a, th, q, tid, Kin);
+        fetch_x(RB, x0, a, th, b, t0, tid);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) RA.w[q] = fetch_w_piece(c1s, q, tid);
-        fetch_x(RA, a, b, t0, 1, n1, tid, aligned_T);
+        for (int q = 0; q < 4; ++q) RA.w[q] = fetch_w_piece(w1, a, th, q, tid, Kin);
+        fetch_x(RA, x1, a, th, b, t0, tid);
 #pragma unroll
         for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(wc0)[q * FT + tid] = RB.w[q];
-        commit_x(xt0, RB, a, 0, n1, tid, 0);
-        commit_x(xt0, RB, a, 0, n1, tid, 1);
+        commit_x(xt0, RB, x0, a, th);
         __syncthreads();
     }
+    // the gate bias (+ global conditioning) is the accumulators' initial value (LDS reads, no vector ALU work)
+    f16v acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][v] = bz[32 * i + acc_row(v, lane)];
     FWD_STAMP(0);                                                 // 0: prologue
     // ---- GEMM1: Z^T = W_in^T [taps | c]^T, two steps per iteration (the register sets swap roles) -------------------------------
     for (int g = 0; g < n1p; g += 2) {
         {
-            const ChunkSel cs = chunk_sel(a, g + 2, n1p, gtot, Kin, ntot);
-            gemm1_step<true>(acc, xt0, wc0, RA, xt0 + KT * XT, wc0 + WCH, RB, cs, a, b, t0, g, n1, tid, lane, wave, aligned_T);
+            const WSel wf = w_sel(a, g + 2, n1p, gtot, Kin);
+            const XSel xc = x_sel(a, b, t0, g + 1, n1, aligned_T), xf = x_sel(a, b, t0, g + 2, n1, aligned_T);
+            gemm1_step<true>(acc, xt0, wc0, RA, xc, xt0 + KT * XT, wc0 + WCH, RB, wf, xf, a, th, b, t0, Kin, tid, lane, wave);
         }
         {
-            const ChunkSel cs = chunk_sel(a, g + 3, n1p, gtot, Kin, ntot);
-            if (g + 1 < n1) gemm1_step<true>(acc, xt0 + KT * XT, wc0 + WCH, RB, xt0, wc0, RA, cs, a, b, t0, g + 1, n1, tid, lane, wave, aligned_T);
-            else gemm1_step<false>(acc, xt0 + KT * XT, wc0 + WCH, RB, xt0, wc0, RA, cs, a, b, t0, g + 1, n1, tid, lane, wave, aligned_T);
+            const WSel wf = w_sel(a, g + 3, n1p, gtot, Kin);
+            const XSel xc = x_sel(a, b, t0, g + 2, n1, aligned_T), xf = x_sel(a, b, t0, g + 3, n1, aligned_T);
+            if (g + 1 < n1) gemm1_step<true>(acc, xt0 + KT * XT, wc0 + WCH, RB, xc, xt0, wc0, RA, wf, xf, a, th, b, t0, Kin, tid, lane, wave);
+            else gemm1_step<false>(acc, xt0 + KT * XT, wc0 + WCH, RB, xc, xt0, wc0, RA, wf, xf, a, th, b, t0, Kin, tid, lane, wave);
         }
     }
     FWD_STAMP(5);                                                 // 5: GEMM1 steps
-    // ---- bias (+ global conditioning), tanh . sigmoid, in registers: u[i] = gate channels 32 i .. 32 i + 31 of this wave's 32 time
-    //      steps, already in the layout GEMM2 wants for its B operand -----------------------------------------------------------------
+    // ---- tanh . sigmoid, in registers: u[i] = gate channels 32 i .. 32 i + 31 of this wave's 32 time steps, already in the layout
+    //      GEMM2 wants for its B operand (modules.py:152-154) ---------------------------------------------------------------------
     f16v u[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int ch = 32 * i + acc_row(v, lane);
-            u[i][v] = fwd_gate(acc[i][v] + bz[ch], acc[4 + i][v] + bz[HC + ch]);          // modules.py:152-154
-        }
+        for (int v = 0; v < 16; ++v) u[i][v] = fwd_gate(acc[i][v], acc[4 + i][v]);
     FWD_STAMP(6);                                                 // 6: gate
     // ---- GEMM2: [out | skip]^T = [W_out | W_skip]^T U^T in blocks of 128 output channels; epilogue per block --------------------------
     const long long tl = t0 + 32 * wave + (lane & 31);              // this lane's time step
+    // addresses of the epilogue = WAVE-UNIFORM row pointer (scalar registers: channel 32 i + 8 (v / 4) + v % 4 of the block) + ONE
+    // 32-bit per-lane offset (4 (lane / 32) rows + the lane's time step; the host checks T <= 2^26)
+    const int loff = (int)(4 * (lane >> 5) * a.T + min(tl, a.T - 1));
+    const bool live = interior || tl < a.T;
     for (int blk = 0; blk < nblk; ++blk) {
+        // block 0 is the residual output (modules.py:157-162: (out + x) sqrt(.5)), the others accumulate into the skip sum
+        // (wavenet.py:196-198).  Row = channel, lane = time: every access is a 128-byte run along time.
+        const bool res = blk == 0;
+        const float* src = res ? a.Hin + (size_t)b * HC * a.T : a.Skip + ((size_t)b * a.K + (size_t)(blk - 1) * HC) * a.T;
+        float* dst = res ? a.Hout + (size_t)b * HC * a.T : a.Skip + ((size_t)b * a.K + (size_t)(blk - 1) * HC) * a.T;
+        const float* bias = bz + 256 + HC * blk;
+        // the accumulators start from  bias + (what the result is added to): requested here, consumed by the first MFMAs four steps
+        // of staging later -- the read-modify-write of the epilogue costs no waiting and no vector ALU work
         f16v o[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) o[i][v] = 0.f;
+            for (int v = 0; v < 16; ++v) o[i][v] = (src + (size_t)(32 * i + 8 * (v >> 2) + (v & 3)) * a.T)[loff];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) o[i][v] += bias[32 * i + acc_row(v, lane)];
         const int g = n1p + 4 * blk;
         {
-            const ChunkSel cs = chunk_sel(a, g + 2, n1p, gtot, Kin, ntot);
-            gemm2_step(o, u[0], wc0, RA, wc0 + WCH, RB, cs, tid, lane);
+            const WSel wf = w_sel(a, g + 2, n1p, gtot, Kin);
+            gemm2_step(o, u[0], wc0, RA, wc0 + WCH, RB, wf, a, th, Kin, tid, lane);
         }
         {
-            const ChunkSel cs = chunk_sel(a, g + 3, n1p, gtot, Kin, ntot);
-            gemm2_step(o, u[1], wc0 + WCH, RB, wc0, RA, cs, tid, lane);
+            const WSel wf = w_sel(a, g + 3, n1p, gtot, Kin);
+            gemm2_step(o, u[1], wc0 + WCH, RB, wc0, RA, wf, a, th, Kin, tid, lane);
         }
         {
-            const ChunkSel cs = chunk_sel(a, g + 4, n1p, gtot, Kin, ntot);
-            gemm2_step(o, u[2], wc0, RA, wc0 + WCH, RB, cs, tid, lane);
+            const WSel wf = w_sel(a, g + 4, n1p, gtot, Kin);
+            gemm2_step(o, u[2], wc0, RA, wc0 + WCH, RB, wf, a, th, Kin, tid, lane);
         }
         {
-            const ChunkSel cs = chunk_sel(a, g + 5, n1p, gtot, Kin, ntot);
-            gemm2_step(o, u[3], wc0 + WCH, RB, wc0, RA, cs, tid, lane);
+            const WSel wf = w_sel(a, g + 5, n1p, gtot, Kin);
+            gemm2_step(o, u[3], wc0 + WCH, RB, wc0, RA, wf, a, th, Kin, tid, lane);
         }
         FWD_STAMP(7);                                             // 7: GEMM2 steps
-        // epilogue: block 0 is the residual output (modules.py:157-162: (out + x) sqrt(.5)), the others accumulate into the skip sum
-        // (wavenet.py:196-198).  Row = channel, lane = time: every access is a 128-byte run along time.  16 loads in flight, then 16 stores.
-        const bool res = blk == 0;
-        const float* src = res ? a.Hin + (size_t)b * HC * a.T : a.Skip + ((size_t)b * a.K + (size_t)(blk - 1) * HC) * a.T;
-        float* dst = res ? a.Hout + (size_t)b * HC * a.T : a.Skip + ((size_t)b * a.K + (size_t)(blk - 1) * HC) * a.T;
         const float scale = res ? 0.70710678118654752440f : 1.0f;
-        const float* bias = bz + 256 + HC * blk;
-        // addresses = WAVE-UNIFORM row pointer (scalar registers: channel 32 i + 8 (v / 4) + v % 4 of the block) + ONE 32-bit per-lane
-        // offset (4 (lane / 32) rows + the lane's time step; the host checks T <= 2^26): per-element 64-bit addresses cost 64 VGPRs
-        const int loff = (int)(4 * (lane >> 5) * a.T + min(tl, a.T - 1));
-        const bool live = interior || tl < a.T;
+        if (live) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float prev[16];
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) prev[v] = (src + (size_t)(32 * i + 8 * (v >> 2) + (v & 3)) * a.T)[loff];
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const float r = (prev[v] + (o[i][v] + bias[32 * i + acc_row(v, lane)])) * scale;
-                if (live) (dst + (size_t)(32 * i + 8 * (v >> 2) + (v & 3)) * a.T)[loff] = r;
-            }
+                for (int v = 0; v < 16; ++v) (dst + (size_t)(32 * i + 8 * (v >> 2) + (v & 3)) * a.T)[loff] = res ? o[i][v] * scale : o[i][v];
         }
         FWD_STAMP(8);                                             // 8: epilogue
     }
