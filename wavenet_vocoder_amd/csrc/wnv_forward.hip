@@ -66,302 +66,212 @@ __device__ unsigned long long g_fwd_phase[16];
 
 struct LayerArgs {
     const float* Hin; float* Hout; float* Skip;        // (B, 128, T), (B, 128, T), (B, K, T): channel-major
-    const float* c_up;                                  // (B, T, cin) time-major (what the engine's upsampler writes), or null
+    const float* c_cm;                                  // (B, cp, T): the conditioning, transposed once per call (cp = cin padded to 16, zero rows)
     const float* zbias; long long zb_bstride;           // per utterance [256]: conv bias (+ Wg g), this layer
     const float *w_in, *w_os, *b_os;                    // K-major [kw*128 + cin][256], [128][nosp], [nosp]
-    long long T; int tiles_per_utt, d, kw, cin, K, nosp;
+    long long T; int tiles_per_utt, d, kw, cin, cp, K, nosp;
 };
 
-// ---- the chunk sequence of one tile -------------------------------------------------------------------------------------------
-// g < n1p: GEMM1 chunk g = rows [16 g, 16 g + 16) of W_in (all 256 columns) + the matching activation rows; n1p = the chunk count
-// padded to even (a padding step runs no MFMAs).  Then GEMM2: for each block of 128 output channels, 4 chunks = rows [32 c, 32 c + 32)
-// of [W_out | W_skip] x the block's 128 columns.  A chunk is 1024 float4 in both cases, row-major: thread tid stages the float4s
-// q * 256 + tid (q = 0 .. 3), a wave reads a contiguous KiB per load and writes 64 consecutive 16-byte LDS slots per store.
-//
-// NO VECTOR ALU WORK IN THE STEPS.  On this chip an ordinary VALU instruction takes matrix-pipe time (scripts/ubench_mfma_peak.hip:
-// every VALU op issued between f32 MFMAs costs 3 - 5 cycles of the 64 an MFMA takes; f32 MFMA and packed f32 FMA share their peak rate),
-// and v11's steps carried ~200 of them per 64 MFMAs (per-element addresses, clamps, masks): 22 % of the pipe.  Every global address
-// of a step is therefore  WAVE-UNIFORM base (scalar ALU) + a per-thread byte offset computed ONCE per tile;  masks, clamps and
-// unaligned windows are resolved by uniform branches into a fast kind (nothing but loads and LDS stores) and a generic slow kind
-// (edge tiles, partial chunks, time steps before the utterance starts).
-struct Thr {                                             // per-thread constants of the staging maps
-    unsigned w1;                                         // GEMM1 weight chunk: float4 tid of a contiguous 16 KB chunk
-    unsigned w2;                                         // GEMM2 weight chunk: row tid / 32 (+ 8 q), float4 tid % 32 of [32][128] in a matrix of row stride nosp
-    unsigned xtap;                                       // tap rows: row tid / 16, time 8 (tid % 16) of channel-major (., T)
-    unsigned xcond;                                      // conditioning: time tid / 2, channels 8 (tid % 2) of time-major (., cin)
-    int l_tap, l_cond;                                   // where those land in the K-major LDS chunk (floats)
+// =================================================================================================================================
+// v13: NOTHING BUT MFMAs, LDS reads AND LOADS IN THE STEPS.
+// Measured on this chip (scripts/ubench_mfma_peak.hip, ubench_mfma_mix.hip): the f32 matrix pipe sustains 155 TFLOP/s from registers,
+// but every ordinary VALU instruction issued between MFMAs costs 3 - 5 of the 64 cycles an MFMA takes, and so does every staging
+// instruction that moves data through the vector registers (global load -> VGPR -> ds_write).  So a step of 64 MFMAs consists of
+//   * the B operand (activations X[k][time]: lane = (k parity, time)) loaded STRAIGHT from the channel-major activations, one
+//     global_load_dword per k pair, prefetched a step ahead: no LDS copy of the activations at all, any dilation / alignment, and the
+//     conditioning is one more channel-major matrix (transposed once per call);
+//   * the weights DMA-ed global -> LDS (global_load_lds_dwordx4: no registers, no ds_write), chunk g + 1 during step g;
+//   * the A operand (weights W[k][channel]: lane = (k parity, row)) as ds_read_b128: tile i, row r of a wave's output is channel
+//     128 (i / 4) + 4 r + i % 4, so the 8 (4) tiles of a lane's row are consecutive floats of the chunk row;
+//   * addresses = wave-uniform base (scalar ALU) + a per-lane offset computed once per tile.
+// The channel <-> (tile, row) map is free: the tanh and sigmoid halves still meet in the same lane and register, GEMM2's K order and
+// the epilogue's row pointers follow it.
+// =================================================================================================================================
+constexpr int WCHL = 4096;         // floats per weight chunk buffer: [16 k][256 channels] (GEMM1) or [32 k][128 channels] (GEMM2)
+
+// (Inline assembly on purpose: behind the builtin the compiler treats the DMA as an LDS store that may alias every later ds_read and
+// puts s_waitcnt vmcnt(0) in front of the step's first operand read -- the whole load latency exposed, every step.  The wait this kernel
+// needs is the one before the barrier that hands the buffer over, and it is written out there.)
+__device__ __forceinline__ void dma16(const void* g, float* lds_wave_base) {        // 64 lanes x 16 bytes -> 1 KB of LDS at lds_wave_base (+ 16 lane)
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(l) : "memory", "m0");
+}
+
+struct Lane {                                            // per-lane constants
+    unsigned w1;                                         // GEMM1 weight chunk: float4 tid of a contiguous 16 KB chunk (bytes)
+    unsigned w2;                                         // GEMM2 weight chunk: rows 4 (tid / 32 + 8 q) + c, float4 tid % 32 (bytes, q = 0)
+    unsigned xo;                                         // B operand: row (lane / 32), time 32 wave + lane % 32 of a (., T) matrix (bytes)
+    int a1, a2;                                          // A operand reads: float offsets of this lane in a GEMM1 / GEMM2 chunk
 };
 
-struct WSel { const float* base; unsigned qstride; bool fast, one; int k0, c0; };        // fast: base + Thr offset + q * qstride (bytes); else generic
-__device__ __forceinline__ WSel w_sel(const LayerArgs& a, int g, int n1p, int gtot, int Kin) {
-    g = min(g, gtot - 1);                                          // past the end: a harmless re-fetch
-    WSel w;
-    w.one = g < n1p;
-    const int r = g - n1p;
-    w.k0 = w.one ? g * KT : (r & 3) * 32; w.c0 = w.one ? 0 : 128 * (r >> 2);
-    w.fast = !w.one || w.k0 + KT <= Kin;
-    w.base = w.one ? a.w_in + (size_t)w.k0 * 256 : a.w_os + (size_t)w.k0 * a.nosp + w.c0;
-    w.qstride = w.one ? 4096u : 32u * (unsigned)a.nosp;            // 4 rows of 256 floats | 8 rows of the [W_out | W_skip] matrix
-    return w;
-}
-// No masks on the weights: a row past the matrix (the partial last GEMM1 chunk, the idle padding step) meets activations that are
-// zeroed, a column past it feeds accumulator rows that are never stored; the clamps of the generic kind keep every address inside.
-__device__ __forceinline__ float4 fetch_w_piece(const WSel& w, const LayerArgs& a, const Thr& th, int q, int tid, int Kin) {
-    if (w.fast) return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(w.base) + (size_t)(w.one ? th.w1 : th.w2) + (size_t)q * w.qstride);
-    const int f = q * FT + tid, k = w.k0 + (f >> 6), col = 4 * (f & 63);          // (only GEMM1 chunks can be partial)
-    return *reinterpret_cast<const float4*>(a.w_in + (size_t)min(k, Kin - 1) * 256 + col);
-}
-
-// One chunk in registers: the weights and the activations -- 8 floats per thread; an unaligned tap window is loaded as three aligned
-// float4 and cut at commit time; the generic kind carries a validity mask (bit e of xmask: rows before t = 0, rows past T, channels past
-// cin read as zeros), applied at commit: nothing in the step that issues a load waits for it.
-struct Stage { float4 w[4]; float4 x[3]; unsigned xmask; };
-
-// activation chunk g of GEMM1: tap chunks (g < 8 kw: channels 16 (g % 8) .. + 16 of tap g / 8, oldest first, conv.py:55-61) come
-// from the channel-major layer input -- thread (row tid / 16, 8 consecutive time steps 8 (tid % 16)); conditioning chunks
-// (modules.py:141-144) from the time-major c -- thread (time tid / 2, 8 channels).
-// kind 0: tap, 16-byte aligned window; 1 .. 3: tap, the window starts r floats into the first of three aligned float4; 4: full
-// conditioning chunk; 5: generic (element loads, clamped addresses, mask).
-struct XSel { int kind; const float* base; int g; };
-__device__ __forceinline__ XSel x_sel(const LayerArgs& a, int b, long long t0, int g, int n1, bool aligned_T) {
-    XSel x;
-    x.g = g = min(g, n1 - 1);
-    if (g < 8 * a.kw) {
-        const long long shift = (long long)(a.kw - 1 - (g >> 3)) * a.d;
-        const int r = (int)((4 - (shift & 3)) & 3);
-        const long long start = t0 - shift - r;                    // (t0 + 8 (tid % 16) - shift) rounded down to a multiple of 4
-        x.base = a.Hin + ((size_t)b * HC + KT * (g & 7)) * a.T + start;
-        x.kind = (aligned_T && start >= 0 && t0 + TN <= a.T) ? r : 5;
-    } else {
-        const int c0 = KT * (g - 8 * a.kw);
-        x.base = a.c_up + ((size_t)b * a.T + t0) * a.cin + c0;
-        x.kind = (t0 + TN <= a.T && c0 + KT <= a.cin) ? 4 : 5;
-    }
-    return x;
-}
-__device__ __forceinline__ void fetch_x(Stage& R, const XSel& x, const LayerArgs& a, const Thr& th, int b, long long t0, int tid) {
-    if (x.kind < 4) {
-        const char* p = reinterpret_cast<const char*>(x.base) + (size_t)th.xtap;
-        R.x[0] = *reinterpret_cast<const float4*>(p);
-        R.x[1] = *reinterpret_cast<const float4*>(p + 16);
-        if (x.kind > 0) R.x[2] = *reinterpret_cast<const float4*>(p + 32);
-    } else if (x.kind == 4) {
-        const char* p = reinterpret_cast<const char*>(x.base) + (size_t)th.xcond;
-        R.x[0] = *reinterpret_cast<const float4*>(p);
-        R.x[1] = *reinterpret_cast<const float4*>(p + 16);
-    } else if (x.g < 8 * a.kw) {
-        const int ch = KT * (x.g & 7) + (tid >> 4);
-        const long long ts = t0 + 8 * (tid & 15) - (long long)(a.kw - 1 - (x.g >> 3)) * a.d;
-        const float* row = a.Hin + ((size_t)b * HC + ch) * a.T;
-        float v[8];
-        unsigned mk = 0;
+// DMA of weight chunk g into LDS buffer `dst` (this wave's quarter of each of the 4 KB-quarters).  GEMM1 chunk g = rows [16 g, +16) of
+// W_in (rows past the matrix: clamped -- they meet zero activations); GEMM2 chunk (blk, c) = rows {4 rr + c} x columns [128 blk, +128).
+__device__ __forceinline__ void dma_chunk(const LayerArgs& a, const Lane& ln, int g, int n1, int Kin, float* dst, int tid, int wave) {
+    if (g < n1) {
+        const int k0 = g * KT;
+        if (k0 + KT <= Kin) {
+            const char* base = reinterpret_cast<const char*>(a.w_in + (size_t)k0 * 256) + ln.w1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const long long te = ts + e;
-            v[e] = row[min(max(te, 0ll), a.T - 1)];
-            mk |= (te >= 0 && te < a.T) ? (1u << e) : 0u;
-        }
-        R.x[0] = make_float4(v[0], v[1], v[2], v[3]);
-        R.x[1] = make_float4(v[4], v[5], v[6], v[7]);
-        R.xmask = mk;
-    } else {
-        const int c = KT * (x.g - 8 * a.kw) + 8 * (tid & 1);                          // cin % 4 == 0 on this path (checked by the host)
-        const long long t = t0 + (tid >> 1);
-        const float* p = a.c_up + ((size_t)b * a.T + min(t, a.T - 1)) * a.cin;
-        R.x[0] = *reinterpret_cast<const float4*>(p + min(c, a.cin - 4));
-        R.x[1] = *reinterpret_cast<const float4*>(p + min(c + 4, a.cin - 4));
-        R.xmask = (t < a.T && c < a.cin ? 0x0Fu : 0u) | (t < a.T && c + 4 < a.cin ? 0xF0u : 0u);
-    }
-}
-__device__ __forceinline__ float4 masked(const float4& v, unsigned m4) {
-    return make_float4((m4 & 1u) ? v.x : 0.f, (m4 & 2u) ? v.y : 0.f, (m4 & 4u) ? v.z : 0.f, (m4 & 8u) ? v.w : 0.f);
-}
-// commit the activations of a chunk into the K-major LDS chunk xt [16][XT]
-__device__ __forceinline__ void commit_x(float* xt, const Stage& R, const XSel& x, const LayerArgs& a, const Thr& th) {
-    float4 lo = R.x[0], hi = R.x[1];
-    const bool tap = x.g < 8 * a.kw;
-    if (x.kind == 1) { lo = make_float4(R.x[0].y, R.x[0].z, R.x[0].w, R.x[1].x); hi = make_float4(R.x[1].y, R.x[1].z, R.x[1].w, R.x[2].x); }
-    else if (x.kind == 2) { lo = make_float4(R.x[0].z, R.x[0].w, R.x[1].x, R.x[1].y); hi = make_float4(R.x[1].z, R.x[1].w, R.x[2].x, R.x[2].y); }
-    else if (x.kind == 3) { lo = make_float4(R.x[0].w, R.x[1].x, R.x[1].y, R.x[1].z); hi = make_float4(R.x[1].w, R.x[2].x, R.x[2].y, R.x[2].z); }
-    else if (x.kind == 5) { lo = masked(lo, R.xmask); hi = masked(hi, R.xmask >> 4); }
-    if (tap) {
-        *reinterpret_cast<float4*>(xt + th.l_tap) = lo;
-        *reinterpret_cast<float4*>(xt + th.l_tap + 4) = hi;
-    } else {
-        float* dst = xt + th.l_cond;
-        dst[0] = lo.x; dst[XT] = lo.y; dst[2 * XT] = lo.z; dst[3 * XT] = lo.w;
-        dst[4 * XT] = hi.x; dst[5 * XT] = hi.y; dst[6 * XT] = hi.z; dst[7 * XT] = hi.w;
-    }
-}
-
-// ---- one GEMM1 step: 64 MFMAs (8 k-pairs x 8 channel tiles) out of chunk buffers (xt, wc); in their shadow the commit of chunk
-// g + 1 (registers Rc, loaded a step ago; selector xc) into the other buffers and the loads of chunk g + 2 (selectors wf, xf) into Rf.
-// Ends in the one barrier.
-template <bool MFMA>
-__device__ __forceinline__ void gemm1_step(f16v (&acc)[8], const float* xt, const float* wc, const Stage& Rc, const XSel& xc, float* xt_n, float* wc_n, Stage& Rf,
-                                           const WSel& wf, const XSel& xf, const LayerArgs& a, const Thr& th, int b, long long t0, int Kin, int tid, int lane, int wave) {
-    if constexpr (MFMA) {
-        const float* Xb = xt + (lane >> 5) * XT + 32 * wave + (lane & 31);
-        const float* Wa = wc + (lane >> 5) * 256 + (lane & 31);
-        float bv = Xb[0];
-        float av[8];
+            for (int q = 0; q < 4; ++q) dma16(base + q * 4096, dst + (q * FT + 64 * wave) * 4);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) av[i] = Wa[32 * i];
-        __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-#pragma unroll
-        for (int ks = 0; ks < KT / 2; ++ks) {
-            float bn = 0.f, an[8];
-            if (ks + 1 < KT / 2) {
-                bn = Xb[(2 * ks + 2) * XT];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) an[i] = Wa[(2 * ks + 2) * 256 + 32 * i];
-                __builtin_amdgcn_sched_group_barrier(0x100, 9, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv, acc[i], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-            if (ks < 4) {
-                Rf.w[ks] = fetch_w_piece(wf, a, th, ks, tid, Kin);
-                reinterpret_cast<float4*>(wc_n)[ks * FT + tid] = Rc.w[ks];
-            } else if (ks == 4) {
-                fetch_x(Rf, xf, a, th, b, t0, tid);
-            } else if (ks == 5) {
-                commit_x(xt_n, Rc, xc, a, th);
-            }
-            if (ks + 1 < KT / 2) {
-                bv = bn;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) av[i] = an[i];
+            for (int q = 0; q < 4; ++q) {
+                const int f = q * FT + tid, k = min(k0 + (f >> 6), Kin - 1);
+                dma16(a.w_in + (size_t)k * 256 + 4 * (f & 63), dst + (q * FT + 64 * wave) * 4);
             }
         }
     } else {
+        const int r = g - n1, c = r & 3, blk = r >> 2;
+        const char* base = reinterpret_cast<const char*>(a.w_os + (size_t)c * a.nosp + 128 * blk) + ln.w2;
+        const size_t qs = (size_t)32 * a.nosp * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Rf.w[q] = fetch_w_piece(wf, a, th, q, tid, Kin);
-        fetch_x(Rf, xf, a, th, b, t0, tid);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(wc_n)[q * FT + tid] = Rc.w[q];
-        commit_x(xt_n, Rc, xc, a, th);
+        for (int q = 0; q < 4; ++q) dma16(base + q * qs, dst + (q * FT + 64 * wave) * 4);
     }
+}
+
+// B operands of GEMM1 chunk g for this lane: 8 k pairs -> 8 registers.  Rows [16 (g % 8), +16) of tap g / 8 of the layer input, shifted
+// by the tap's dilation (conv.py:55-61: oldest tap first), or rows of the conditioning.  Time steps before the utterance read as zero
+// (uniform slow variant); time steps past T are loaded from wherever the row runs on to (inside the scratch) and never stored.
+__device__ __forceinline__ void load_b(float (&xb)[8], const LayerArgs& a, const Lane& ln, int b, long long t0, int g, int wave, int lane) {
+    const bool tap = g < 8 * a.kw;
+    const long long shift = tap ? (long long)(a.kw - 1 - (g >> 3)) * a.d : 0;
+    const float* rows = tap ? a.Hin + ((size_t)b * HC + KT * (g & 7)) * a.T : a.c_cm + ((size_t)b * a.cp + KT * (g - 8 * a.kw)) * a.T;
+    const char* base = reinterpret_cast<const char*>(rows + (t0 - shift)) + ln.xo;
+    const size_t ks2 = (size_t)2 * a.T * 4;
+    if (t0 >= shift) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xb[ks] = *reinterpret_cast<const float*>(base + ks * ks2);
+    } else {
+        const long long tl = t0 + 32 * wave + (lane & 31) - shift;                  // this lane's (possibly negative) time step
+        const char* basec = base + (tl < 0 ? -tl * 4 : 0);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const float v = *reinterpret_cast<const float*>(basec + ks * ks2);
+            xb[ks] = tl < 0 ? 0.f : v;
+        }
+    }
+}
+
+// ---- one GEMM1 step: 64 MFMAs out of weight buffer wc and the B registers xb; in their shadow the DMA of chunk g + 1 into wc_n and
+// the B loads of chunk g + 1 into xn.  Ends in the one barrier (after the DMA has landed).
+__device__ __forceinline__ void gemm1_step(f16v (&acc)[8], const float (&xb)[8], float (&xn)[8], const float* wc, float* wc_n, const LayerArgs& a, const Lane& ln,
+                                           int b, long long t0, int g, int n1, int Kin, int tid, int lane, int wave) {
+    const float4* Wa = reinterpret_cast<const float4*>(wc + ln.a1);
+    float4 av0 = Wa[0], av1 = Wa[32];
+    dma_chunk(a, ln, g + 1, n1, Kin, wc_n, tid, wave);
+    load_b(xn, a, ln, b, t0, min(g + 1, n1 - 1), wave, lane);               // (after the last chunk: a harmless re-load)
+#pragma unroll
+    for (int ks = 0; ks < KT / 2; ++ks) {
+        float4 an0 = av0, an1 = av1;
+        if (ks + 1 < KT / 2) {
+            an0 = Wa[(2 * ks + 2) * 64];
+            an1 = Wa[(2 * ks + 2) * 64 + 32];
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.x, xb[ks], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.y, xb[ks], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.z, xb[ks], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0.w, xb[ks], acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.x, xb[ks], acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.y, xb[ks], acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.z, xb[ks], acc[6], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1.w, xb[ks], acc[7], 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        av0 = an0; av1 = an1;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                           // vmcnt(0): the DMA of the next chunk has landed
     __syncthreads();
 }
 
-// ---- one GEMM2 step: 64 MFMAs (16 k-pairs x 4 channel tiles).  B operand = the gated accumulator registers u[0 .. 15] of one
-// 32-channel tile (register s holds channels 8 (s / 4) + s % 4 and + 4 of the tile: the k pair of MFMA s); A = the matching rows
-// of the weight chunk [32 k][128 channels].  Weight staging as in gemm1_step.
-__device__ __forceinline__ void gemm2_step(f16v (&acc)[4], const f16v& u, const float* wc, const Stage& Rc, float* wc_n, Stage& Rf, const WSel& wf,
-                                           const LayerArgs& a, const Thr& th, int Kin, int tid, int lane) {
-    const float* Wa = wc + (4 * (lane >> 5)) * 128 + (lane & 31);
-    float av[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) av[i] = Wa[32 * i];
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+// ---- one GEMM2 step: 64 MFMAs (16 k-pairs x 4 channel tiles).  B operand = the gated accumulator registers u[0 .. 15] of gate tile c
+// (register s of a lane holds gate channel 4 (8 (s / 4) + 4 (lane / 32) + s % 4) + c: the k pair of MFMA s); A = row
+// 8 (s / 4) + 4 (lane / 32) + s % 4 of the weight chunk [32 k][128 channels], one ds_read_b128 for the four tiles.
+__device__ __forceinline__ void gemm2_step(f16v (&acc)[4], const f16v& u, const float* wc, float* wc_n, const LayerArgs& a, const Lane& ln, int g, int gtot, int n1,
+                                           int Kin, int tid, int lane, int wave) {
+    const float4* Wa = reinterpret_cast<const float4*>(wc + ln.a2);
+    float4 av = Wa[0];
+    if (g + 1 < gtot) dma_chunk(a, ln, g + 1, n1, Kin, wc_n, tid, wave);
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        float an[4];
+        float4 an = av;
         if (s + 1 < 16) {
-            const int rown = 8 * ((s + 1) >> 2) + ((s + 1) & 3);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) an[i] = Wa[rown * 128 + 32 * i];
-            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            an = Wa[(8 * ((s + 1) >> 2) + ((s + 1) & 3)) * 32];
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], u[s], acc[i], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, u[s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, u[s], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, u[s], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, u[s], acc[3], 0, 0, 0);
         __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        if (s < 4) {
-            Rf.w[s] = fetch_w_piece(wf, a, th, s, tid, Kin);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-        } else if (s >= 8 && s < 12) {
-            reinterpret_cast<float4*>(wc_n)[(s - 8) * FT + tid] = Rc.w[s - 8];
-            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
-        }
-        if (s + 1 < 16) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) av[i] = an[i];
-        }
+        av = an;
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
 }
 
 __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const xt0 = smem;                                       // [2][KT][XT] activation chunks, K-major
-    float* const wc0 = smem + 2 * KT * XT;                         // [2][WCH]    weight chunks
-    float* const bz = wc0 + 2 * WCH;                               // [256] gate bias (+ Wg g), then [128 + K] b_out | b_skip
+    float* const wc0 = smem;                                       // [2][WCHL] weight chunks
+    float* const bz = wc0 + 2 * WCHL;                              // [256] gate bias (+ Wg g), then [128 + K] b_out | b_skip
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.tiles_per_utt;
     const long long t0 = (long long)(blockIdx.x % a.tiles_per_utt) * TN;
-    const int Kin = a.kw * HC + a.cin;
-    const int n1 = (Kin + KT - 1) / KT, n1p = (n1 + 1) & ~1;       // GEMM1 steps, padded to an even count (the extra step runs no MFMAs)
-    const int ntot = HC + a.K, nblk = ntot / HC, gtot = n1p + 4 * nblk;
-    const bool aligned_T = (a.T & 3) == 0;
-    const bool interior = t0 + TN <= a.T;
-    Thr th;
-    th.w1 = 16u * (unsigned)tid;
-    th.w2 = 4u * ((unsigned)(tid >> 5) * (unsigned)a.nosp + 4u * (unsigned)(tid & 31));
-    th.xtap = 4u * ((unsigned)(tid >> 4) * (unsigned)a.T + 8u * (unsigned)(tid & 15));          // (T <= 2^26: the host checks)
-    th.xcond = 4u * ((unsigned)(tid >> 1) * (unsigned)a.cin + 8u * (unsigned)(tid & 1));
-    th.l_tap = (tid >> 4) * XT + 8 * (tid & 15);
-    th.l_cond = 8 * (tid & 1) * XT + (tid >> 1);
-
-    Stage RA, RB;
+    const int Kin = a.kw * HC + a.cin;                             // rows of W_in
+    const int n1 = 8 * a.kw + a.cp / KT;                           // GEMM1 steps (the conditioning is padded to whole chunks)
+    const int ntot = HC + a.K, nblk = ntot / HC, gtot = n1 + 4 * nblk;
+    const int jl = lane & 31, kl = lane >> 5;
+    Lane ln;
+    ln.w1 = 16u * (unsigned)tid;
+    ln.w2 = 4u * (4u * (unsigned)(tid >> 5) * (unsigned)a.nosp + 4u * (unsigned)(tid & 31));
+    ln.xo = 4u * ((unsigned)kl * (unsigned)a.T + 32u * (unsigned)wave + (unsigned)jl);          // (T <= 2^24: the host checks)
+    ln.a1 = kl * 256 + 4 * jl;
+    ln.a2 = 4 * kl * 128 + 4 * jl;
 #ifdef WNV_FWD_TRACE
     unsigned long long ph__[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long t_prev__ = __builtin_readcyclecounter();
     const unsigned long long wall0__ = wall_clock64();
 #endif
-    // ---- prologue: biases, chunk 0 into buffer 0, chunk 1 into RA -------------------------------------------------------------
-    {
-        bz[tid] = a.zbias[(size_t)b * a.zb_bstride + tid];
-        for (int i = tid; i < ntot; i += FT) bz[256 + i] = a.b_os[i];
-        const WSel w0 = w_sel(a, 0, n1p, gtot, Kin), w1 = w_sel(a, 1, n1p, gtot, Kin);
-        const XSel x0 = x_sel(a, b, t0, 0, n1, aligned_T), x1 = x_sel(a, b, t0, 1, n1, aligned_T);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) RB.w[q] = fetch_w_piece(w0, a, th, q, tid, Kin);
-        fetch_x(RB, x0, a, th, b, t0, tid);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) RA.w[q] = fetch_w_piece(w1, a, th, q, tid, Kin);
-        fetch_x(RA, x1, a, th, b, t0, tid);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) reinterpret_cast<float4*>(wc0)[q * FT + tid] = RB.w[q];
-        commit_x(xt0, RB, x0, a, th);
-        __syncthreads();
-    }
-    // the gate bias (+ global conditioning) is the accumulators' initial value (LDS reads, no vector ALU work)
+    // ---- prologue: biases, weight chunk 0, B operands of chunk 0 ----------------------------------------------------------------
+    float xa[8], xb[8];
+    dma_chunk(a, ln, 0, n1, Kin, wc0, tid, wave);
+    load_b(xa, a, ln, b, t0, 0, wave, lane);
+    bz[tid] = a.zbias[(size_t)b * a.zb_bstride + tid];
+    for (int i = tid; i < ntot; i += FT) bz[256 + i] = a.b_os[i];
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+    // the gate bias (+ global conditioning) is the accumulators' initial value (LDS reads, no vector ALU work); tile i, row r = gate
+    // row 128 (i / 4) + 4 r + i % 4
     f16v acc[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[i][v] = bz[32 * i + acc_row(v, lane)];
+        for (int v = 0; v < 16; ++v) acc[i][v] = bz[128 * (i >> 2) + 4 * acc_row(v, lane) + (i & 3)];
     FWD_STAMP(0);                                                 // 0: prologue
-    // ---- GEMM1: Z^T = W_in^T [taps | c]^T, two steps per iteration (the register sets swap roles) -------------------------------
-    for (int g = 0; g < n1p; g += 2) {
-        {
-            const WSel wf = w_sel(a, g + 2, n1p, gtot, Kin);
-            const XSel xc = x_sel(a, b, t0, g + 1, n1, aligned_T), xf = x_sel(a, b, t0, g + 2, n1, aligned_T);
-            gemm1_step<true>(acc, xt0, wc0, RA, xc, xt0 + KT * XT, wc0 + WCH, RB, wf, xf, a, th, b, t0, Kin, tid, lane, wave);
-        }
-        {
-            const WSel wf = w_sel(a, g + 3, n1p, gtot, Kin);
-            const XSel xc = x_sel(a, b, t0, g + 2, n1, aligned_T), xf = x_sel(a, b, t0, g + 3, n1, aligned_T);
-            if (g + 1 < n1) gemm1_step<true>(acc, xt0 + KT * XT, wc0 + WCH, RB, xc, xt0, wc0, RA, wf, xf, a, th, b, t0, Kin, tid, lane, wave);
-            else gemm1_step<false>(acc, xt0 + KT * XT, wc0 + WCH, RB, xc, xt0, wc0, RA, wf, xf, a, th, b, t0, Kin, tid, lane, wave);
-        }
+    // ---- GEMM1: Z^T = W_in^T [taps | c]^T, two steps per iteration (the B register sets swap roles) ------------------------------
+    // (ONE inlined copy of the step: alternatives that merge -- role-swapped register sets, a last step without prefetch -- make the
+    // register allocator copy or spill the 128 accumulator registers at the merge; the B registers are moved instead: 8 v_mov per step)
+    for (int g = 0; g < n1; ++g) {
+        const int par = g & 1;
+        gemm1_step(acc, xa, xb, wc0 + par * WCHL, wc0 + (par ^ 1) * WCHL, a, ln, b, t0, g, n1, Kin, tid, lane, wave);
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) xa[ks] = xb[ks];
     }
     FWD_STAMP(5);                                                 // 5: GEMM1 steps
-    // ---- tanh . sigmoid, in registers: u[i] = gate channels 32 i .. 32 i + 31 of this wave's 32 time steps, already in the layout
-    //      GEMM2 wants for its B operand (modules.py:152-154) ---------------------------------------------------------------------
-    f16v u[4];
+    // ---- tanh . sigmoid, in registers: u[i][v] = gate channel 4 row + i of this lane's time step (modules.py:152-154) ---------------
+    //      In place: the gated values take the tanh tiles' registers, the sigmoid tiles' registers become GEMM2's accumulators.
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) u[i][v] = fwd_gate(acc[i][v], acc[4 + i][v]);
+        for (int v = 0; v < 16; ++v) acc[i][v] = fwd_gate(acc[i][v], acc[4 + i][v]);
+    f16v (&u)[4] = *reinterpret_cast<f16v(*)[4]>(&acc[0]);
+    f16v (&o)[4] = *reinterpret_cast<f16v(*)[4]>(&acc[4]);
     FWD_STAMP(6);                                                 // 6: gate
     // ---- GEMM2: [out | skip]^T = [W_out | W_skip]^T U^T in blocks of 128 output channels; epilogue per block --------------------------
-    const long long tl = t0 + 32 * wave + (lane & 31);              // this lane's time step
-    // addresses of the epilogue = WAVE-UNIFORM row pointer (scalar registers: channel 32 i + 8 (v / 4) + v % 4 of the block) + ONE
-    // 32-bit per-lane offset (4 (lane / 32) rows + the lane's time step; the host checks T <= 2^26)
-    const int loff = (int)(4 * (lane >> 5) * a.T + min(tl, a.T - 1));
-    const bool live = interior || tl < a.T;
+    const long long tl = t0 + 32 * wave + jl;                       // this lane's time step
+    // epilogue addresses = WAVE-UNIFORM row pointer (channel 32 (v / 4) + 4 (v % 4) + i of the block) + ONE 32-bit per-lane offset
+    // (16 (lane / 32) rows + the lane's time step; the host checks T <= 2^24)
+    const int loff = (int)(16 * kl * a.T + min(tl, a.T - 1));
+    const bool live = tl < a.T;
     for (int blk = 0; blk < nblk; ++blk) {
         // block 0 is the residual output (modules.py:157-162: (out + x) sqrt(.5)), the others accumulate into the skip sum
         // (wavenet.py:196-198).  Row = channel, lane = time: every access is a 128-byte run along time.
@@ -369,42 +279,31 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
         const float* src = res ? a.Hin + (size_t)b * HC * a.T : a.Skip + ((size_t)b * a.K + (size_t)(blk - 1) * HC) * a.T;
         float* dst = res ? a.Hout + (size_t)b * HC * a.T : a.Skip + ((size_t)b * a.K + (size_t)(blk - 1) * HC) * a.T;
         const float* bias = bz + 256 + HC * blk;
-        // the accumulators start from  bias + (what the result is added to): requested here, consumed by the first MFMAs four steps
-        // of staging later -- the read-modify-write of the epilogue costs no waiting and no vector ALU work
-        f16v o[4];
+        // the accumulators start from the bias (LDS reads: no vector ALU work)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) o[i][v] = (src + (size_t)(32 * i + 8 * (v >> 2) + (v & 3)) * a.T)[loff];
+            for (int v = 0; v < 16; ++v) o[i][v] = bias[4 * acc_row(v, lane) + i];
+        const int g2 = n1 + 4 * blk;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) o[i][v] += bias[32 * i + acc_row(v, lane)];
-        const int g = n1p + 4 * blk;
-        {
-            const WSel wf = w_sel(a, g + 2, n1p, gtot, Kin);
-            gemm2_step(o, u[0], wc0, RA, wc0 + WCH, RB, wf, a, th, Kin, tid, lane);
-        }
-        {
-            const WSel wf = w_sel(a, g + 3, n1p, gtot, Kin);
-            gemm2_step(o, u[1], wc0 + WCH, RB, wc0, RA, wf, a, th, Kin, tid, lane);
-        }
-        {
-            const WSel wf = w_sel(a, g + 4, n1p, gtot, Kin);
-            gemm2_step(o, u[2], wc0, RA, wc0 + WCH, RB, wf, a, th, Kin, tid, lane);
-        }
-        {
-            const WSel wf = w_sel(a, g + 5, n1p, gtot, Kin);
-            gemm2_step(o, u[3], wc0 + WCH, RB, wc0, RA, wf, a, th, Kin, tid, lane);
+        for (int c = 0; c < 4; ++c) {
+            const int par = (g2 + c) & 1;
+            gemm2_step(o, u[c], wc0 + par * WCHL, wc0 + (par ^ 1) * WCHL, a, ln, g2 + c, gtot, n1, Kin, tid, lane, wave);
         }
         FWD_STAMP(7);                                             // 7: GEMM2 steps
-        const float scale = res ? 0.70710678118654752440f : 1.0f;
-        if (live) {
+        // all 64 addends requested, then 64 stores: one memory round trip per block
+        float prev[4][16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int v = 0; v < 16; ++v) (dst + (size_t)(32 * i + 8 * (v >> 2) + (v & 3)) * a.T)[loff] = res ? o[i][v] * scale : o[i][v];
-        }
+            for (int v = 0; v < 16; ++v) prev[i][v] = (src + (size_t)(32 * (v >> 2) + 4 * (v & 3) + i) * a.T)[loff];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float r = res ? (prev[i][v] + o[i][v]) * 0.70710678118654752440f : prev[i][v] + o[i][v];
+                if (live) (dst + (size_t)(32 * (v >> 2) + 4 * (v & 3) + i) * a.T)[loff] = r;
+            }
         FWD_STAMP(8);                                             // 8: epilogue
     }
 #ifdef WNV_FWD_TRACE
@@ -414,6 +313,22 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
         atomicAdd(&g_fwd_phase[15], 1ull);
     }
 #endif
+}
+
+// the conditioning, time-major (B, T, cin) as the upsampler writes it -> channel-major (B, cp, T), rows cin .. cp - 1 zero
+__global__ void wnv_fwd_ctrans_kernel(const float* __restrict__ c, float* __restrict__ out, int cin, int cp, long long T) {
+    __shared__ float tile[64][129];                                // [time][channel]
+    const int b = blockIdx.y;
+    const long long t0 = (long long)blockIdx.x * 64;
+    const int tid = threadIdx.x;
+    const int nt = (int)min((long long)64, T - t0);
+    const float* src = c + ((size_t)b * T + t0) * cin;
+    for (int i = tid; i < nt * cin; i += 256) tile[i / cin][i % cin] = src[i];          // contiguous rows
+    __syncthreads();
+    for (int i = tid; i < cp * 64; i += 256) {
+        const int ch = i >> 6, t = i & 63;
+        if (t < nt) out[((size_t)b * cp + ch) * T + t0 + t] = ch < cin ? tile[t][ch] : 0.f;
+    }
 }
 
 // ---- head: relu -> 1x1 -> relu -> 1x1 (wavenet.py:200-207) on the same tile shape, transposed the same way; 4 % of the work, plain
@@ -538,12 +453,14 @@ const char* wnv_forward_why_not(const WnvModelDev& m) {
     if (m.K % HC != 0) return "needs skip_out_channels to be a multiple of 128";
     if (m.O > 256) return "needs out_channels <= 256";
     if (m.Rp != m.R) return "padded residual width";
-    if (m.cin > 0 && (m.cin & 3) != 0) return "needs cin_channels to be a multiple of 4";
+    if (m.cin > 128) return "needs cin_channels <= 128";
     return nullptr;
 }
 
 size_t wnv_forward_scratch_floats(const WnvModelDev& m, int B, long long T) {
-    return (size_t)B * T * (2 * HC + m.K);
+    const int cp = (m.cin + KT - 1) / KT * KT;
+    return (size_t)B * T * (2 * HC + m.K + cp) + 1024;       // activations (ping, pong), skip sum, channel-major conditioning, slack: a tile's
+                                                             // last B-operand loads may run up to 127 floats past a row
 }
 
 hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_host, const float* d_W, const WnvForwardArgs& a,
@@ -561,7 +478,11 @@ hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_ho
                            H0, m.cin1, T, n);
     }
     const int tiles = (int)((T + TN - 1) / TN);
-    const size_t lds_l = ((size_t)2 * KT * XT + 2 * WCH + 256 + HC + m.K) * sizeof(float);
+    const int cp = (m.cin + KT - 1) / KT * KT;
+    float* c_cm = Skip + (size_t)B * T * m.K;
+    if (m.cin > 0)
+        hipLaunchKernelGGL(wnv_fwd_ctrans_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)B), dim3(256), 0, s, a.c_up, c_cm, m.cin, cp, T);
+    const size_t lds_l = ((size_t)2 * WCHL + 256 + HC + m.K) * sizeof(float);
     const size_t lds_h = ((size_t)2 * KT * XT + 2 * WCH) * sizeof(float);
     e = hipFuncSetAttribute((const void*)wnv_fwd_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
     if (e != hipSuccess) return e;
@@ -569,7 +490,7 @@ hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_ho
     for (int l = 0; l < m.L; ++l) {
         const WnvLayerDev& Ld = layers_host[l];
         LayerArgs la{};
-        la.Hin = in; la.Hout = out; la.Skip = Skip; la.c_up = m.cin > 0 ? a.c_up : nullptr;
+        la.Hin = in; la.Hout = out; la.Skip = Skip; la.c_cm = c_cm; la.cp = cp;
         la.zbias = a.zbias + (size_t)l * m.Gp; la.zb_bstride = a.zbias_bstride;
         la.w_in = d_W + Ld.w_in; la.w_os = d_W + Ld.w_os; la.b_os = d_W + Ld.b_os;
         la.T = T; la.tiles_per_utt = tiles; la.d = Ld.dilation; la.kw = m.kw; la.cin = m.cin; la.K = m.K; la.nosp = m.NOSp;
