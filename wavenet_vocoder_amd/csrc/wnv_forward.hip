@@ -94,7 +94,24 @@ constexpr int WCHL = 4096;         // floats per weight chunk buffer: [16 k][256
 // needs is the one before the barrier that hands the buffer over, and it is written out there.)
 __device__ __forceinline__ void dma16(const void* g, float* lds_wave_base) {        // 64 lanes x 16 bytes -> 1 KB of LDS at lds_wave_base (+ 16 lane)
     const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(l) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(g), "s"(l) : "memory");
+}
+// the same with the address as  wave-uniform base (scalar registers) + 32-bit per-lane byte offset: no vector ALU work at all
+__device__ __forceinline__ void dma16s(const void* ubase, unsigned voff, float* lds_wave_base) {
+    const unsigned l = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)lds_wave_base);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(ubase), "s"(l) : "memory");
+}
+
+// raw buffer access:  wave-uniform descriptor (base) + 32-bit per-lane byte offset + wave-uniform byte offset -- an address with no vector
+// ALU instruction behind it (a flat / global access would build a 64-bit address per lane)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void buf_store(float v, __amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)voff, (int)soff, 0);
 }
 
 struct Lane {                                            // per-lane constants
@@ -110,9 +127,9 @@ __device__ __forceinline__ void dma_chunk(const LayerArgs& a, const Lane& ln, in
     if (g < n1) {
         const int k0 = g * KT;
         if (k0 + KT <= Kin) {
-            const char* base = reinterpret_cast<const char*>(a.w_in + (size_t)k0 * 256) + ln.w1;
+            const char* base = reinterpret_cast<const char*>(a.w_in + (size_t)k0 * 256);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dma16(base + q * 4096, dst + (q * FT + 64 * wave) * 4);
+            for (int q = 0; q < 4; ++q) dma16s(base + q * 4096, ln.w1, dst + (q * FT + 64 * wave) * 4);
         } else {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -122,10 +139,10 @@ __device__ __forceinline__ void dma_chunk(const LayerArgs& a, const Lane& ln, in
         }
     } else {
         const int r = g - n1, c = r & 3, blk = r >> 2;
-        const char* base = reinterpret_cast<const char*>(a.w_os + (size_t)c * a.nosp + 128 * blk) + ln.w2;
+        const char* base = reinterpret_cast<const char*>(a.w_os + (size_t)c * a.nosp + 128 * blk);
         const size_t qs = (size_t)32 * a.nosp * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) dma16(base + q * qs, dst + (q * FT + 64 * wave) * 4);
+        for (int q = 0; q < 4; ++q) dma16s(base + q * qs, ln.w2, dst + (q * FT + 64 * wave) * 4);
     }
 }
 
@@ -136,12 +153,14 @@ __device__ __forceinline__ void load_b(float (&xb)[8], const LayerArgs& a, const
     const bool tap = g < 8 * a.kw;
     const long long shift = tap ? (long long)(a.kw - 1 - (g >> 3)) * a.d : 0;
     const float* rows = tap ? a.Hin + ((size_t)b * HC + KT * (g & 7)) * a.T : a.c_cm + ((size_t)b * a.cp + KT * (g - 8 * a.kw)) * a.T;
-    const char* base = reinterpret_cast<const char*>(rows + (t0 - shift)) + ln.xo;
-    const size_t ks2 = (size_t)2 * a.T * 4;
+    const char* ubase = reinterpret_cast<const char*>(rows + (t0 - shift));       // wave-uniform; the lane offset is added LAST (scalar base +
+    const size_t ks2 = (size_t)2 * a.T * 4;                                        // 32-bit vector offset: no address arithmetic in vector registers)
     if (t0 >= shift) {
+        const __amdgpu_buffer_rsrc_t r = make_rsrc(ubase);
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) xb[ks] = *reinterpret_cast<const float*>(base + ks * ks2);
+        for (int ks = 0; ks < 8; ++ks) xb[ks] = buf_load(r, ln.xo, (unsigned)(ks * ks2));
     } else {
+        const char* base = ubase + ln.xo;
         const long long tl = t0 + 32 * wave + (lane & 31) - shift;                  // this lane's (possibly negative) time step
         const char* basec = base + (tl < 0 ? -tl * 4 : 0);
 #pragma unroll
@@ -268,9 +287,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
     FWD_STAMP(6);                                                 // 6: gate
     // ---- GEMM2: [out | skip]^T = [W_out | W_skip]^T U^T in blocks of 128 output channels; epilogue per block --------------------------
     const long long tl = t0 + 32 * wave + jl;                       // this lane's time step
-    // epilogue addresses = WAVE-UNIFORM row pointer (channel 32 (v / 4) + 4 (v % 4) + i of the block) + ONE 32-bit per-lane offset
-    // (16 (lane / 32) rows + the lane's time step; the host checks T <= 2^24)
-    const int loff = (int)(16 * kl * a.T + min(tl, a.T - 1));
+    const unsigned eoff = 4u * (unsigned)(16 * kl * a.T + min(tl, a.T - 1));      // (the host checks T <= 2^24)
     const bool live = tl < a.T;
     for (int blk = 0; blk < nblk; ++blk) {
         // block 0 is the residual output (modules.py:157-162: (out + x) sqrt(.5)), the others accumulate into the skip sum
@@ -291,19 +308,29 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
             gemm2_step(o, u[c], wc0 + par * WCHL, wc0 + (par ^ 1) * WCHL, a, ln, g2 + c, gtot, n1, Kin, tid, lane, wave);
         }
         FWD_STAMP(7);                                             // 7: GEMM2 steps
-        // all 64 addends requested, then 64 stores: one memory round trip per block
+        // all 64 addends requested, then 64 stores: one memory round trip per block.  Channel 32 (v / 4) + 4 (v % 4) + i of the block =
+        // buffer descriptor of the 32-channel group v / 4 + wave-uniform row offset + the lane's offset (16 (lane / 32) rows + time)
         float prev[4][16];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int q = 0; q < 4; ++q) {
+            const __amdgpu_buffer_rsrc_t rs = make_rsrc(src + (size_t)32 * q * a.T);
 #pragma unroll
-            for (int v = 0; v < 16; ++v) prev[i][v] = (src + (size_t)(32 * (v >> 2) + 4 * (v & 3) + i) * a.T)[loff];
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+                for (int e = 0; e < 4; ++e) prev[i][4 * q + e] = buf_load(rs, eoff, (unsigned)((4 * e + i) * a.T * 4));
+        }
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const float r = res ? (prev[i][v] + o[i][v]) * 0.70710678118654752440f : prev[i][v] + o[i][v];
-                if (live) (dst + (size_t)(32 * (v >> 2) + 4 * (v & 3) + i) * a.T)[loff] = r;
-            }
+        for (int q = 0; q < 4; ++q) {
+            const __amdgpu_buffer_rsrc_t rd = make_rsrc(dst + (size_t)32 * q * a.T);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int v = 4 * q + e;
+                    const float r = res ? (prev[i][v] + o[i][v]) * 0.70710678118654752440f : prev[i][v] + o[i][v];
+                    if (live) buf_store(r, rd, eoff, (unsigned)((4 * e + i) * a.T * 4));
+                }
+        }
         FWD_STAMP(8);                                             // 8: epilogue
     }
 #ifdef WNV_FWD_TRACE
