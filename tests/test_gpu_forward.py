@@ -19,7 +19,7 @@ NAMES = ["cfg1_mulaw256", "cfg1b_mulaw256_intree", "cfg2_mol", "cfg3_gaussian", 
 @pytest.mark.parametrize("name", NAMES)
 def test_forward_vs_oracle_and_torch_graph(name):
     kw = CONFIGS[name]
-    B, T = 2, 512 + 37          # not a multiple of the 64-step tile (c is given at sample rate below)
+    B, T = 2, 512 + 37          # not a multiple of the 128-step tile, nor of 4 (c is given at sample rate below)
     m = build(name)
     o = Oracle(oracle_config(kw), m.state_dict())
     g = torch.Generator().manual_seed(8)
@@ -68,3 +68,45 @@ def test_unsupported_shapes_raise_and_module_falls_back():
     with torch.no_grad():
         y = m(x)                                                      # torch ops
     assert y.shape == (1, 256, 64)
+
+
+ODD = {
+    # conditioning that is no multiple of the 16-row chunk (zero-padded rows, the clamped partial weight chunk), kernel size 2 (an odd
+    # number of GEMM1 chunks), three blocks of output channels
+    "cin20_k2_skip256": (dict(out_channels=30, layers=4, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=256, kernel_size=2,
+                              dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=20, upsample_conditional_features=False), 3, 1000),
+    # no conditioning at all, a single partial tile
+    "plain_T100": (dict(out_channels=2, layers=6, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
+                        dropout=0.0, scalar_input=True, output_distribution="Normal"), 2, 100),
+    # speaker embedding + conditioning, kernel size 3, T a multiple of the tile
+    "speakers_T384": (dict(out_channels=256, layers=6, stacks=3, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
+                           dropout=0.0, cin_channels=36, gin_channels=8, n_speakers=5, use_speaker_embedding=True,
+                           upsample_conditional_features=False), 2, 384),
+}
+
+
+@pytest.mark.parametrize("name", list(ODD))
+def test_forward_odd_shapes_vs_the_torch_graph(name):
+    """Shapes that exercise the edges of the tile kernel, against the same module evaluated with torch ops on the GPU (the reference
+    graph: grad mode keeps the module off the MFMA path)."""
+    import wavenet_vocoder_amd as wnv
+    kw, B, T = ODD[name]
+    torch.manual_seed(5)
+    m = wnv.WaveNet(**kw).eval().to("cuda")
+    g = torch.Generator().manual_seed(3)
+    scalar = kw.get("scalar_input", False)
+    x = torch.tanh(torch.randn(B, 1, T, generator=g)) if scalar else torch.nn.functional.one_hot(
+        torch.randint(0, kw["out_channels"], (B, T), generator=g), kw["out_channels"]).transpose(1, 2).float()
+    c = torch.randn(B, kw["cin_channels"], T, generator=g).cuda() if kw.get("cin_channels", -1) > 0 else None
+    gid = torch.randint(0, kw["n_speakers"], (B, 1), generator=g).cuda() if kw.get("gin_channels", -1) > 0 else None
+    x = x.cuda()
+    with torch.no_grad():
+        got = m(x, c=c, g=gid)
+        assert m._mfma_forward_covers(x, c, gid), "this shape must be served by the MFMA kernels"
+    with torch.enable_grad():
+        ref = m(x, c=c, g=gid).detach()
+    err = (got - ref).abs().max().item()
+    assert err < TOL, f"{name}: {err}"
+    with torch.no_grad():
+        sm = m(x, c=c, g=gid, softmax=True)
+    assert (sm - torch.softmax(ref, dim=1)).abs().max().item() < TOL
