@@ -110,3 +110,24 @@ def test_forward_odd_shapes_vs_the_torch_graph(name):
     with torch.no_grad():
         sm = m(x, c=c, g=gid, softmax=True)
     assert (sm - torch.softmax(ref, dim=1)).abs().max().item() < TOL
+
+
+def test_raw_forward_arguments_are_validated_before_the_launch():
+    """Pointers cross the C boundary raw: the engine wrapper checks shape, dtype, layout and device first (no out-of-bounds device reads)."""
+    name = "cfg2_mol"
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    B, T = 2, 256
+    x = teacher(CONFIGS[name], B, T).cuda()
+    c_up = torch.randn(B, T, 80, device="cuda")
+    eng.forward(x, c_up=c_up)
+    with pytest.raises(ValueError, match="c_up"):
+        eng.forward(x, c_up=c_up[:, : T - 1].contiguous())                # too short
+    with pytest.raises(ValueError, match="c_up"):
+        eng.forward(x, c_up=c_up.double())
+    with pytest.raises(ValueError, match="c_up"):
+        eng.forward(x, c_up=c_up.transpose(1, 2))                         # (B, cin, T) view: wrong layout
+    with pytest.raises(RuntimeError, match="HIP device"):
+        eng.forward(x, c_up=c_up.cpu())
+    with pytest.raises(ValueError, match="channels"):
+        eng.forward(torch.cat([x, x], dim=1), c_up=c_up)

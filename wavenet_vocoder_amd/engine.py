@@ -172,7 +172,22 @@ class Engine:
         Raises NotImplementedError for shapes the MFMA path does not cover."""
         require_gpu_tensor(x, "x")
         x = x.detach().float().contiguous()
-        B, _, T = x.shape
+        B, Cx, T = x.shape
+        cfg = self.cfg
+        if Cx != (1 if cfg.scalar_input else cfg.out_channels):
+            raise ValueError(f"x has {Cx} channels, the model takes {1 if cfg.scalar_input else cfg.out_channels}")
+        if c_up is not None:            # raw pointers cross the boundary: shape, dtype, device and layout are checked here
+            require_gpu_tensor(c_up, "c_up")
+            if c_up.dtype != torch.float32 or not c_up.is_contiguous() or tuple(c_up.shape) != (B, T, cfg.cin_channels):
+                raise ValueError(f"c_up must be a contiguous float32 (B, T, cin) = {(B, T, cfg.cin_channels)} tensor, got {c_up.dtype} {tuple(c_up.shape)}")
+        if g is not None:
+            require_gpu_tensor(g, "g")
+            if g.dtype != torch.float32 or not g.is_contiguous() or tuple(g.shape) != (B, cfg.gin_channels):
+                raise ValueError(f"g must be a contiguous float32 (B, gin) = {(B, cfg.gin_channels)} tensor")
+        if g_ids is not None:
+            require_gpu_tensor(g_ids, "g_ids")
+            if g_ids.dtype != torch.int64 or not g_ids.is_contiguous() or g_ids.numel() != B:
+                raise ValueError("g_ids must be a contiguous int64 (B,) tensor")
         out = torch.empty(B, self.cfg.out_channels, T, device=self.device, dtype=torch.float32)
         a = _lib.ForwardArgs(B=B, T=T, x=_ptr(x), c_up=_ptr(c_up), g=_ptr(g), g_ids=_ptr(g_ids), out=out.data_ptr(),
                              softmax=int(bool(softmax)), stream=_stream(self.device))
