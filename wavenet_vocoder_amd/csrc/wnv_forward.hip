@@ -254,8 +254,17 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
     float xa[8], xb[8];
     dma_chunk(a, ln, 0, n1, Kin, wc0, tid, wave);
     load_b(xa, a, ln, b, t0, 0, wave, lane);
-    bz[tid] = a.zbias[(size_t)b * a.zb_bstride + tid];
-    for (int i = tid; i < ntot; i += FT) bz[256 + i] = a.b_os[i];
+    // biases in ACCUMULATOR order: [tile][lane / 32][v / 4][v % 4], so that one ds_read_b128 fills four consecutive accumulator registers
+    // (channel of (tile i, row r): 128 (i / 4) + 4 r + i % 4 in GEMM1, 4 r + i in a GEMM2 block; row = 8 (v / 4) + 4 (lane / 32) + v % 4)
+    {
+        const int i = tid >> 5, r = tid & 31;                       // tid = 32 i + r  ->  slot [i][(r >> 2) & 1][r >> 3][r & 3]
+        const int slot = i * 32 + ((r >> 2) & 1) * 16 + (r >> 3) * 4 + (r & 3);
+        bz[slot] = a.zbias[(size_t)b * a.zb_bstride + 128 * (i >> 2) + 4 * r + (i & 3)];
+        for (int j = tid; j < ntot; j += FT) {
+            const int blk = j >> 7, ii = (j >> 5) & 3, rr = j & 31;
+            bz[256 + blk * 128 + ii * 32 + ((rr >> 2) & 1) * 16 + (rr >> 3) * 4 + (rr & 3)] = a.b_os[128 * blk + 4 * rr + ii];
+        }
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
     // the gate bias (+ global conditioning) is the accumulators' initial value (LDS reads, no vector ALU work); tile i, row r = gate
@@ -264,7 +273,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[i][v] = bz[128 * (i >> 2) + 4 * acc_row(v, lane) + (i & 3)];
+        for (int v = 0; v < 16; ++v) acc[i][v] = bz[i * 32 + kl * 16 + v];
     FWD_STAMP(0);                                                 // 0: prologue
     // ---- GEMM1: Z^T = W_in^T [taps | c]^T, two steps per iteration (the B register sets swap roles) ------------------------------
     // (ONE inlined copy of the step: alternatives that merge -- role-swapped register sets, a last step without prefetch -- make the
@@ -300,7 +309,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) o[i][v] = bias[4 * acc_row(v, lane) + i];
+            for (int v = 0; v < 16; ++v) o[i][v] = bias[i * 32 + kl * 16 + v];
         const int g2 = n1 + 4 * blk;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
