@@ -310,14 +310,8 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int v = 0; v < 16; ++v) o[i][v] = bias[i * 32 + kl * 16 + v];
-        const int g2 = n1 + 4 * blk;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int par = (g2 + c) & 1;
-            gemm2_step(o, u[c], wc0 + par * WCHL, wc0 + (par ^ 1) * WCHL, a, ln, g2 + c, gtot, n1, Kin, tid, lane, wave);
-        }
-        FWD_STAMP(7);                                             // 7: GEMM2 steps
-        // all 64 addends requested, then 64 stores: one memory round trip per block.  Channel 32 (v / 4) + 4 (v % 4) + i of the block =
+        // what the block's result is added to (the layer input | the running skip sum) is requested BEFORE the block's four GEMM2 steps and
+        // consumed after them: the read of the read-modify-write costs no waiting.  Channel 32 (v / 4) + 4 (v % 4) + i of the block =
         // buffer descriptor of the 32-channel group v / 4 + wave-uniform row offset + the lane's offset (16 (lane / 32) rows + time)
         float prev[4][16];
 #pragma unroll
@@ -328,6 +322,13 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) prev[i][4 * q + e] = buf_load(rs, eoff, (unsigned)((4 * e + i) * a.T * 4));
         }
+        const int g2 = n1 + 4 * blk;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int par = (g2 + c) & 1;
+            gemm2_step(o, u[c], wc0 + par * WCHL, wc0 + (par ^ 1) * WCHL, a, ln, g2 + c, gtot, n1, Kin, tid, lane, wave);
+        }
+        FWD_STAMP(7);                                             // 7: GEMM2 steps
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const __amdgpu_buffer_rsrc_t rd = make_rsrc(dst + (size_t)32 * q * a.T);
