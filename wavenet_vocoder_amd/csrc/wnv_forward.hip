@@ -228,6 +228,7 @@ __device__ __forceinline__ void gemm2_step(f16v (&acc)[4], const f16v& u, const 
     __syncthreads();
 }
 
+template <bool ODD>                                  // ODD: the number of GEMM1 chunks, 8 kw + cp / 16, is odd
 __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const wc0 = smem;                                       // [2][WCHL] weight chunks
@@ -276,13 +277,16 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
         for (int v = 0; v < 16; ++v) acc[i][v] = bz[i * 32 + kl * 16 + v];
     FWD_STAMP(0);                                                 // 0: prologue
     // ---- GEMM1: Z^T = W_in^T [taps | c]^T, two steps per iteration (the B register sets swap roles) ------------------------------
-    // (ONE inlined copy of the step: alternatives that merge -- role-swapped register sets, a last step without prefetch -- make the
-    // register allocator copy or spill the 128 accumulator registers at the merge; the B registers are moved instead: 8 v_mov per step)
-    for (int g = 0; g < n1; ++g) {
-        const int par = g & 1;
-        gemm1_step(acc, xa, xb, wc0 + par * WCHL, wc0 + (par ^ 1) * WCHL, a, ln, b, t0, g, n1, Kin, tid, lane, wave);
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) xa[ks] = xb[ks];
+    // Two steps per iteration, the B register sets swapping roles; an odd chunk count ends in one more step -- a compile-time property
+    // of the instantiation (ODD), because alternatives that MERGE at run time (a last step without prefetch, role-swapped sets) make the
+    // register allocator copy or spill the 128 accumulator registers at the merge.
+    {
+        int g = 0;
+        for (; g + 1 < n1; g += 2) {
+            gemm1_step(acc, xa, xb, wc0, wc0 + WCHL, a, ln, b, t0, g, n1, Kin, tid, lane, wave);
+            gemm1_step(acc, xb, xa, wc0 + WCHL, wc0, a, ln, b, t0, g + 1, n1, Kin, tid, lane, wave);
+        }
+        if constexpr (ODD) gemm1_step(acc, xa, xb, wc0, wc0 + WCHL, a, ln, b, t0, g, n1, Kin, tid, lane, wave);
     }
     FWD_STAMP(5);                                                 // 5: GEMM1 steps
     // ---- tanh . sigmoid, in registers: u[i][v] = gate channel 4 row + i of this lane's time step (modules.py:152-154) ---------------
@@ -521,7 +525,9 @@ hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_ho
         hipLaunchKernelGGL(wnv_fwd_ctrans_kernel, dim3((unsigned)((T + 63) / 64), (unsigned)B), dim3(256), 0, s, a.c_up, c_cm, m.cin, cp, T);
     const size_t lds_l = ((size_t)2 * WCHL + 256 + HC + m.K) * sizeof(float);
     const size_t lds_h = ((size_t)2 * KT * XT + 2 * WCH) * sizeof(float);
-    e = hipFuncSetAttribute((const void*)wnv_fwd_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
+    const bool odd = ((8 * m.kw + cp / KT) & 1) != 0;
+    e = odd ? hipFuncSetAttribute((const void*)wnv_fwd_layer_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l)
+            : hipFuncSetAttribute((const void*)wnv_fwd_layer_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l);
     if (e != hipSuccess) return e;
     float *in = H0, *out = H1;
     for (int l = 0; l < m.L; ++l) {
@@ -531,7 +537,8 @@ hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_ho
         la.zbias = a.zbias + (size_t)l * m.Gp; la.zb_bstride = a.zbias_bstride;
         la.w_in = d_W + Ld.w_in; la.w_os = d_W + Ld.w_os; la.b_os = d_W + Ld.b_os;
         la.T = T; la.tiles_per_utt = tiles; la.d = Ld.dilation; la.kw = m.kw; la.cin = m.cin; la.K = m.K; la.nosp = m.NOSp;
-        hipLaunchKernelGGL(wnv_fwd_layer_kernel, dim3((unsigned)(B * tiles)), dim3(FT), lds_l, s, la);
+        if (odd) hipLaunchKernelGGL(wnv_fwd_layer_kernel<true>, dim3((unsigned)(B * tiles)), dim3(FT), lds_l, s, la);
+        else hipLaunchKernelGGL(wnv_fwd_layer_kernel<false>, dim3((unsigned)(B * tiles)), dim3(FT), lds_l, s, la);
         std::swap(in, out);
     }
 #ifdef WNV_FWD_TRACE
