@@ -78,6 +78,11 @@ ODD = {
     # no conditioning at all, a single partial tile
     "plain_T100": (dict(out_channels=2, layers=6, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
                         dropout=0.0, scalar_input=True, output_distribution="Normal"), 2, 100),
+    # fewer time steps than a wave owns, and a single one
+    "tiny_T31": (dict(out_channels=30, layers=4, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
+                      dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=80, upsample_conditional_features=False), 2, 31),
+    "tiny_T1": (dict(out_channels=30, layers=4, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
+                     dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=80, upsample_conditional_features=False), 3, 1),
     # speaker embedding + conditioning, kernel size 3, T a multiple of the tile
     "speakers_T384": (dict(out_channels=256, layers=6, stacks=3, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
                            dropout=0.0, cin_channels=36, gin_channels=8, n_speakers=5, use_speaker_embedding=True,

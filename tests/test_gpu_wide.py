@@ -191,3 +191,25 @@ def test_wide_onehot_model_through_batch_wavegen():
     want = P.post_chain(y_hat.cpu().numpy(), "mulaw-quantize", quantize_channels=256, postprocess=h.postprocess,
                         coef=h.preemphasis_coef, global_gain_scale=h.global_gain_scale)
     assert np.abs(wav - want).max() < 1e-4 * max(1.0, np.abs(want).max())
+
+
+def test_wide_onehot_eleven_utterances_vs_the_generic_kernel():
+    """More than 8 utterances on the one-hot head pair (the tap stream takes two passes, the history copies run two utterances behind):
+    teacher-forced head outputs against the generic kernel on the same inputs, sampled classes equal wherever the choice is not a near tie."""
+    kw = dict(ONEHOT_WIDE, layers=4, stacks=2)
+    torch.manual_seed(41)
+    m = tame_head_(wnv.WaveNet(**kw).eval()).to("cuda")
+    eng = m._get_engine()
+    B, T = 11, 96
+    g = torch.Generator().manual_seed(6)
+    cu = torch.randn(B, T, 80, generator=g).cuda()
+    idx = torch.randint(0, 256, (B, T), generator=g)
+    tin = torch.zeros(B, T, 256).scatter_(2, idx.unsqueeze(2), 1.0).cuda()
+    tape = make_noise_tape(T, B, scalar_input=False, output_distribution="Logistic", out_channels=256, generator=torch.Generator().manual_seed(2)).cuda()
+    out3, p3, c3 = eng.generate(B=B, T=T, c_up=cu, teacher=tin, noise=tape, want_params=True, want_index=True, kernel=3)
+    assert eng.last_kernel() == 3
+    out1, p1, c1 = eng.generate(B=B, T=T, c_up=cu, teacher=tin, noise=tape, want_params=True, want_index=True, kernel=1)
+    assert float((p3 - p1).abs().max()) < 5e-5
+    assert_match_or_near_tie(c3.cpu(), c1.cpu(), p1.cpu(), tape.cpu(), kw)
+    lone, _, cl = eng.generate(B=1, T=T, c_up=cu[9:10].contiguous(), teacher=tin[9:10].contiguous(), noise=tape[:, 9:10].contiguous(), want_index=True, kernel=3)
+    assert torch.equal(cl[0], c3[9]), "utterance 9 of 11 must not depend on its neighbours"
