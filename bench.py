@@ -349,6 +349,53 @@ def main():
                                     "ms_per_call": round(dt * 1e3, 2)}
             except Exception as e:
                 line["api_path"] = {"error": str(e)[:120]}
+        if world == 1 and args.batch == B_PER_GPU and args.workload == WORKLOAD and not args.no_extras:
+            # informative only: the two other device paths of SURVEY.md section 8 at their own bench shapes, so that a driver-run line
+            # carries them too -- f3 (teacher-forced batch `forward` on the f32 matrix cores, same model and batch) and the group-ring
+            # kernel on the published wide geometry (24 layers 512 / 512 / 256), one and eight utterances
+            try:
+                gx = torch.Generator().manual_seed(3)             # a seeded teacher input (the bench model takes a scalar waveform)
+                if kw.get("scalar_input", False):
+                    xt = torch.tanh(torch.randn(B, 1, T, generator=gx) * 0.5).to(dev)
+                else:
+                    xi = torch.randint(0, kw["out_channels"], (B, T), generator=gx)
+                    xt = torch.zeros(B, kw["out_channels"], T).scatter_(1, xi.unsqueeze(1), 1.0).to(dev)
+                c_up_f = eng.upsample(c_dev, T_expected=T)
+                gi = None if gids is None else gids[:, 0].to(dev)
+                for _ in range(2):
+                    eng.forward(xt, c_up=c_up_f, g_ids=gi)
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+                for _ in range(3):
+                    eng.forward(xt, c_up=c_up_f, g_ids=gi)
+                ev1.record()
+                torch.cuda.synchronize()
+                ms = ev0.elapsed_time(ev1) / 3
+                tf = 2.0 * eng.macs_per_sample() * B * T / ms / 1e9
+                line["f3_forward"] = {"entry": "wnv_forward (WaveNet.forward, teacher-forced, f32 MFMA)", "ms_per_call": round(ms, 3),
+                                      "TFLOP_per_s": round(tf, 1), "frac_of_f32_mfma_peak_157.3": round(tf / 157.3, 4)}
+                del xt, c_up_f
+            except Exception as e:
+                line["f3_forward"] = {"error": str(e)[:120]}
+            try:
+                wname, Tw = "wide_mol_512", 4096
+                mw = build(wname).to(dev)
+                ew = mw._get_engine()
+                wide = {"model": "24 layers 512/512/256, 80-mel MoL (group-ring kernel)", "T": Tw}
+                for Bw in (1, 8):
+                    cw, _ = inputs(wname, Bw, Tw)
+                    cuw = ew.upsample(cw.to(dev), T_expected=Tw)
+                    ew.generate(B=Bw, T=Tw, c_up=cuw, seed=1, kernel=0)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    ew.generate(B=Bw, T=Tw, c_up=cuw, seed=2, kernel=0)
+                    torch.cuda.synchronize()
+                    wide[f"kSamples_per_s_B{Bw}"] = round(Bw * Tw / (time.perf_counter() - t1) / 1e3, 1)
+                wide["kernel"] = {1: "generic", 2: "ring", 3: "group ring"}.get(ew.last_kernel(), "?")
+                line["wide_model"] = wide
+                del mw, ew
+            except Exception as e:
+                line["wide_model"] = {"error": str(e)[:120]}
         if world == 1 and args.cpu_steps > 0 and not args.no_extras:
             line["cpu_baseline"] = cpu_baseline(model_cpu, kw, c, args.cpu_steps)
             line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
