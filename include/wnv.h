@@ -217,7 +217,7 @@ wnv_status wnv_glu_destroy(wnv_glu_handle g);
  * skip_out_channels % 128 == 0, out_channels <= 256 (else WNV_ERR_UNSUPPORTED: the Python host then uses torch ops). */
 typedef struct wnv_forward_args {
     int32_t B;
-    int64_t T;                 /* <= 2^24 samples per utterance (WNV_ERR_INVALID_ARG beyond)                */
+    int64_t T;                 /* <= 2^23 samples per utterance (WNV_ERR_INVALID_ARG beyond)                */
     const float* x;            /* device (B, Cin, T): Cin = 1 (scalar input) or out_channels (one-hot)      */
     const float* c_up;         /* device (B, T, cin) time-major (wnv_upsample's output), or NULL            */
     const float* g;            /* device (B, gin) or NULL                                                   */

@@ -244,7 +244,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
     Lane ln;
     ln.w1 = 16u * (unsigned)tid;
     ln.w2 = 4u * (4u * (unsigned)(tid >> 5) * (unsigned)a.nosp + 4u * (unsigned)(tid & 31));
-    ln.xo = 4u * ((unsigned)kl * (unsigned)a.T + 32u * (unsigned)wave + (unsigned)jl);          // (T <= 2^24: the host checks)
+    ln.xo = 4u * ((unsigned)kl * (unsigned)a.T + 32u * (unsigned)wave + (unsigned)jl);          // (T <= 2^23: the host checks)
     ln.a1 = kl * 256 + 4 * jl;
     ln.a2 = 4 * kl * 128 + 4 * jl;
 #ifdef WNV_FWD_TRACE
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
     FWD_STAMP(6);                                                 // 6: gate
     // ---- GEMM2: [out | skip]^T = [W_out | W_skip]^T U^T in blocks of 128 output channels; epilogue per block --------------------------
     const long long tl = t0 + 32 * wave + jl;                       // this lane's time step
-    const unsigned eoff = 4u * (unsigned)(16 * kl * a.T + min(tl, a.T - 1));      // (the host checks T <= 2^24)
+    const unsigned eoff = 4u * (unsigned)(16 * kl * a.T + min(tl, a.T - 1));      // (the host checks T <= 2^23: offset + scalar offset < 2^31)
     const bool live = tl < a.T;
     for (int blk = 0; blk < nblk; ++blk) {
         // block 0 is the residual output (modules.py:157-162: (out + x) sqrt(.5)), the others accumulate into the skip sum

@@ -439,7 +439,7 @@ extern "C" wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* a) {
     if (h->device < 0) return fail(WNV_ERR_INVALID_ARG, "host-only handle (created with device = -1): there is no CPU path");
     if (!h->packed) return fail(WNV_ERR_NOT_LOADED, "weights are not loaded");
     const WnvModelDev& m = h->m;
-    if (a->B <= 0 || a->T <= 0 || a->T > (1LL << 24)) return fail(WNV_ERR_INVALID_ARG, "B and T must be positive (T <= 2^24: 32-bit in-tile byte offsets)");
+    if (a->B <= 0 || a->T <= 0 || a->T > (1LL << 23)) return fail(WNV_ERR_INVALID_ARG, "B and T must be positive (T <= 2^23: buffer offsets of the tile kernels stay below 2^31 bytes)");
     if (!a->x || !a->out) return fail(WNV_ERR_INVALID_ARG, "x / out is NULL");
     if (m.cin > 0 && !a->c_up) return fail(WNV_ERR_INVALID_ARG, "model has local conditioning but c_up is NULL");
     if (m.cin == 0 && a->c_up) return fail(WNV_ERR_INVALID_ARG, "c_up given but the model has no local conditioning");

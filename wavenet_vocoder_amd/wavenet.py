@@ -168,7 +168,7 @@ class WaveNet(EngineHost, nn.Module):
         cin = max(self.cin_channels, 0)
         if cin > 128 or (cin > 0) != (c is not None) or (self.gin_channels > 0) != (g is not None):
             return False
-        if x.size(2) > (1 << 24):                # 32-bit in-tile byte offsets (wnv_forward: WNV_ERR_INVALID_ARG beyond)
+        if x.size(2) > (1 << 23):                # 31-bit buffer offsets (wnv_forward: WNV_ERR_INVALID_ARG beyond)
             return False
         return x.size(1) == (1 if self.scalar_input else self.out_channels)
 
