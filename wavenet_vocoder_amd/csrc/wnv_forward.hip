@@ -17,8 +17,9 @@
 //     read from LDS in that order);
 //   * one workgroup = 4 waves = 128 time steps of one utterance for one layer (half the weight bytes per time step of the 64-row
 //     tile of v1-v10), two workgroups per CU;
-//   * staging is software-pipelined under the MFMAs (as v10): double LDS chunk buffers, the commit of chunk g + 1 and the global
-//     loads of chunk g + 2 are issued between the MFMAs of chunk g, ONE barrier per 64 MFMAs.
+//   * a step is 64 MFMAs + LDS reads + loads and nothing else (see "v13" below): the weights of chunk g + 1 are DMA-ed into the
+//     other LDS buffer and the B operands of chunk g + 1 are loaded from global memory during the MFMAs of chunk g, ONE barrier per
+//     64 MFMAs.
 // History, each step measured (profiles/r01_forward_*, r02_forward_*): v1 59.9 TFLOP/s -> v8 93.8 (prefetch in registers, LDS bank
 // conflicts, scheduling barriers, straight-line epilogue) -> v9 104.1 (epilogue addressing, no spills) -> v10 109.2 (software
 // pipelining, time-major 64-row tile) -> v11 109.3 (this layout) -> v13 115.1 (steps without VALU work, DMA) -> v14 121.8 (buffer
