@@ -85,7 +85,8 @@ typedef struct wnv_config {
     int32_t cin_pad;
     int32_t upsample_activation;    /* wnv_upsample_act: nn module applied after every upsampling stage (upsample.py:47-49) */
     float   upsample_activation_param; /* LeakyReLU negative_slope / ELU alpha                             */
-    int32_t reserved[6];
+    int32_t upsample_mode;          /* Stretch2d mode (upsample.py:19-21): 0 "nearest" (every preset), 1 "bilinear"        */
+    int32_t reserved[5];
 } wnv_config;
 
 /* One named tensor of a reference state_dict.  `name` is the state_dict key, e.g.

@@ -58,6 +58,7 @@ class OracleConfig:
     freq_axis_kernel_size: int = 1
     upsample_activation: str = "none"                      # upsample.py:30,47-49: getattr(nn, name)(**params) after every stage
     upsample_activation_params: Dict[str, float] = field(default_factory=dict)
+    upsample_mode: str = "nearest"                         # upsample.py:20: the mode of Stretch2d's F.interpolate
     cin_pad: int = 0
     scalar_input: bool = False
     use_speaker_embedding: bool = False
@@ -286,7 +287,7 @@ class Oracle:
         act = None if cfg.upsample_activation == "none" else getattr(torch.nn, cfg.upsample_activation)(**cfg.upsample_activation_params)
         stride = 2 if act is None else 3                                     # up_layers = [stretch, conv(, activation)] per scale
         for i, s in enumerate(cfg.upsample_scales):
-            c = F.interpolate(c, scale_factor=(1, s), mode="nearest")        # upsample.py:19-21
+            c = F.interpolate(c, scale_factor=(1, s), mode=cfg.upsample_mode)   # upsample.py:19-21
             w = self.st[f"{pre}{stride * i + 1}.weight"]
             c = F.conv2d(c, w, padding=((fk - 1) // 2, s))                   # upsample.py:39-42
             if act is not None:

@@ -46,6 +46,7 @@ def oracle_config(kwargs):
         freq_axis_kernel_size=up.get("freq_axis_kernel_size", 1),
         upsample_activation=up.get("upsample_activation", "none"),
         upsample_activation_params=dict(up.get("upsample_activation_params", {})),
+        upsample_mode=up.get("mode", "nearest"),
         cin_pad=kwargs.get("cin_pad", 0), scalar_input=kwargs.get("scalar_input", False),
         use_speaker_embedding=kwargs.get("use_speaker_embedding", False),
         output_distribution=kwargs.get("output_distribution", "Logistic"))

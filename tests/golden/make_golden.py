@@ -98,6 +98,11 @@ CASES = {
                                          upsample_params=dict(upsample_scales=[4, 2], cin_pad=1, freq_axis_kernel_size=5,
                                                               upsample_activation="ELU", upsample_activation_params={"alpha": 0.7}),
                                          **COMPACT), 2, 40, 40, {}),
+    # Stretch2d with mode="bilinear" (upsample.py:20; every preset uses "nearest")
+    "mol_upsample_bilinear": (dict(out_channels=30, cin_channels=6, cin_pad=1, scalar_input=True,
+                                   upsample_conditional_features=True,
+                                   upsample_params=dict(upsample_scales=[4, 2], cin_channels=6, cin_pad=1, mode="bilinear"),
+                                   **COMPACT), 2, 40, 40, {}),
 }
 
 

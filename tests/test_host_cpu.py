@@ -306,3 +306,22 @@ def test_bulk_noise_tape_equals_the_per_step_replay(scalar, dist, C):
         b = make_noise_tape(37, B, scalar_input=scalar, output_distribution=dist, out_channels=C, generator=g2, per_step=True)
         assert a.shape == (37, B, noise_width(scalar, dist, C)) and torch.equal(a, b), (scalar, dist, C, B)
         assert torch.equal(torch.empty(5).uniform_(generator=g1), torch.empty(5).uniform_(generator=g2))
+
+
+def test_upsample_stretch_modes():
+    """Stretch2d: "nearest" and "bilinear" (upsample.py:19-21) are implemented -- on the device too (wnv_config.upsample_mode, pinned by the
+    reference-made fixture mol_upsample_bilinear); anything else is refused by the host module and by make_config."""
+    import torch.nn.functional as F
+    from wavenet_vocoder_amd.upsample import Stretch2d
+    from wavenet_vocoder_amd.engine import make_config
+    x = torch.randn(2, 1, 5, 7)
+    assert torch.equal(Stretch2d(3, 1, "nearest")(x), F.interpolate(x, scale_factor=(1, 3), mode="nearest"))
+    assert torch.equal(Stretch2d(4, 1, "bilinear")(x), F.interpolate(x, scale_factor=(1, 4), mode="bilinear"))
+    with pytest.raises(NotImplementedError):
+        Stretch2d(2, 1, "bicubic")
+    kw = dict(out_channels=30, layers=2, stacks=1, residual_channels=8, gate_channels=16, skip_out_channels=8, kernel_size=2, cin_channels=4,
+              gin_channels=-1, n_speakers=None, use_speaker_embedding=False, scalar_input=True, output_distribution="Logistic",
+              upsample_net="ConvInUpsampleNetwork", upsample_scales=[2, 2], freq_axis_kernel_size=1, cin_pad=0)
+    assert make_config(**kw, upsample_mode="bilinear").upsample_mode == 1 and make_config(**kw).upsample_mode == 0
+    with pytest.raises(NotImplementedError):
+        make_config(**kw, upsample_mode="area")

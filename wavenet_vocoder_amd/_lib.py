@@ -24,6 +24,8 @@ UPSAMPLE = {None: 0, "none": 0, "ConvInUpsampleNetwork": 1, "UpsampleNetwork": 2
 # upsample_activation (upsample.py:30,47-49: getattr(nn, name)(**params)) -> (wnv_upsample_act, the keyword of its one parameter)
 UPSAMPLE_ACT = {"none": (0, None), "ReLU": (1, None), "LeakyReLU": (2, "negative_slope"), "Tanh": (3, None), "Sigmoid": (4, None), "ELU": (5, "alpha")}
 UPSAMPLE_ACT_DEFAULT = {"negative_slope": 0.01, "alpha": 1.0}
+# Stretch2d mode (upsample.py:19-21: F.interpolate(x, scale_factor=(1, s), mode=mode)) -> wnv_config.upsample_mode
+UPSAMPLE_MODE = {"nearest": 0, "bilinear": 1}
 
 # status codes -> Python exceptions (include/wnv.h "Conventions")
 _STATUS_EXC = {
@@ -50,7 +52,7 @@ class Config(C.Structure):
         ("output_distribution", C.c_int32), ("upsample_kind", C.c_int32), ("n_upsample_scales", C.c_int32),
         ("upsample_scales", C.c_int32 * WNV_MAX_UPSAMPLE_STAGES), ("freq_axis_kernel_size", C.c_int32),
         ("cin_pad", C.c_int32), ("upsample_activation", C.c_int32), ("upsample_activation_param", C.c_float),
-        ("reserved", C.c_int32 * 6),
+        ("upsample_mode", C.c_int32), ("reserved", C.c_int32 * 5),
     ]
 
 

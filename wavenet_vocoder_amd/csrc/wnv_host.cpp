@@ -120,6 +120,7 @@ static wnv_status validate_config(const wnv_config* c) {
         if (c->freq_axis_kernel_size < 1 || c->freq_axis_kernel_size > 15 || c->freq_axis_kernel_size % 2 == 0)
             return fail(WNV_ERR_UNSUPPORTED, "freq_axis_kernel_size %d: an odd size <= 15 is implemented", c->freq_axis_kernel_size);
         if (c->upsample_activation < 0 || c->upsample_activation > WNV_UPACT_ELU) return fail(WNV_ERR_INVALID_ARG, "unknown upsample_activation %d", c->upsample_activation);
+        if (c->upsample_mode < 0 || c->upsample_mode > 1) return fail(WNV_ERR_UNSUPPORTED, "upsample_mode %d: 0 (nearest) and 1 (bilinear) are implemented", c->upsample_mode);
         for (int i = 0; i < c->n_upsample_scales; ++i)
             if (c->upsample_scales[i] < 1) return fail(WNV_ERR_INVALID_ARG, "upsample scale < 1");
     }
@@ -424,7 +425,7 @@ extern "C" wnv_status wnv_upsample(wnv_handle h, const float* c_in, int32_t B, i
         const long long indent = (last && c.upsample_kind == WNV_UPSAMPLE_PLAIN) ? (long long)c.cin_pad * total : 0;
         float* dst = last ? c_up : bufs[which];
         HIP_TRY(wnv_launch_stretch_fir(cur, h->d_up + h->up_off[1 + i], dst, B, cin, Tcur, sc, last ? 1 : 0, indent, c.freq_axis_kernel_size,
-                                       c.upsample_activation, c.upsample_activation_param, s));
+                                       c.upsample_activation, c.upsample_activation_param, c.upsample_mode, s));
         cur = dst; which ^= 1;
         Tcur *= sc;
     }

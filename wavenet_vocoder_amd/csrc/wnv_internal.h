@@ -37,8 +37,9 @@ hipError_t wnv_launch_conv_in(const float* c, const float* w, float* out, int B,
                               hipStream_t s);
 // one [nearest-stretch x s, FIR 2s+1, zero pad s] stage on (rows, Tin) -> (rows, Tin*s); when
 // transpose_out != 0 writes (B, Tout_trim, cin) time-major, dropping `indent` samples at both ends.
-// fk: taps along the channel (mel-bin) axis (zero padded); act / act_p: the stage's activation (wnv_upsample_act) and its parameter
+// fk: taps along the channel (mel-bin) axis (zero padded); act / act_p: the stage's activation (wnv_upsample_act) and its parameter;
+// mode: 0 nearest stretch, 1 bilinear stretch (F.interpolate, align_corners = False)
 hipError_t wnv_launch_stretch_fir(const float* in, const float* w, float* out, int B, int cin, long long Tin,
-                                  int scale, int transpose_out, long long indent, int fk, int act, float act_p, hipStream_t s);
+                                  int scale, int transpose_out, long long indent, int fk, int act, float act_p, int mode, hipStream_t s);
 // plain (B, cin, T) -> (B, T, cin) transpose for the no-upsampling case
 hipError_t wnv_launch_transpose_bct(const float* in, float* out, int B, int cin, long long T, hipStream_t s);

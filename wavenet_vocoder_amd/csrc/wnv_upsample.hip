@@ -48,9 +48,25 @@ __device__ __forceinline__ float up_act(float x, int act, float a) {
 // out[row][j] = act( sum_f sum_{m=0..2s} w[f][m] * rep[row + f - fk/2][j + m - s] ),  rep[r][q] = in[r][q / s] for 0 <= q < Tin*s and
 // 0 <= r < cin, else 0: Conv2d(1, 1, (fk, 2s+1), padding=((fk-1)/2, s)) over the nearest-stretched map (upsample.py:38-45); fk = 1 in
 // every reference preset
+// sample q of the stretched row (upsample.py:19-21, F.interpolate(x, scale_factor=(1, s), mode=...)): nearest = in[q / s]; bilinear with
+// align_corners = False (torch's default): source position ratio (q + 0.5) - 0.5 with ratio = 1 / s, clamped at 0, the right neighbour
+// clamped at the last sample (ATen UpSample.h: area_pixel_compute_source_index / compute_source_index_and_lambda); the mel-bin axis has
+// scale 1, i.e. is copied
+__device__ __forceinline__ float stretched(const float* row, long long q, int scale, long long Tin, int mode) {
+    if (mode == 0) return row[q / scale];
+    const float ratio = (float)(1.0 / (double)scale);
+    float src = ratio * ((float)q + 0.5f) - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    const long long i0 = (long long)src;
+    const long long i1 = i0 + (i0 < Tin - 1 ? 1 : 0);
+    float l1 = src - (float)i0;
+    l1 = fminf(fmaxf(l1, 0.f), 1.f);
+    return (1.0f - l1) * row[i0] + l1 * row[i1];
+}
+
 __global__ void wnv_stretch_fir_kernel(const float* __restrict__ in, const float* __restrict__ w,
                                        float* __restrict__ out, int B, int cin, long long Tin, int scale,
-                                       int transpose_out, long long indent, int fk, int act, float act_p) {
+                                       int transpose_out, long long indent, int fk, int act, float act_p, int mode) {
     const long long Tfull = Tin * scale;
     const long long Tout = Tfull - 2 * indent;
     const long long total = (long long)B * cin * Tout;
@@ -76,7 +92,7 @@ __global__ void wnv_stretch_fir_kernel(const float* __restrict__ in, const float
             const float* wf = w + (size_t)f * (2 * scale + 1);
             for (int mtap = 0; mtap <= 2 * scale; ++mtap) {
                 const long long q = jj + mtap - scale;
-                if (q >= 0 && q < Tfull) acc = fmaf(wf[mtap], row[q / scale], acc);
+                if (q >= 0 && q < Tfull) acc = fmaf(wf[mtap], stretched(row, q, scale, Tin, mode), acc);
             }
         }
         acc = up_act(acc, act, act_p);
@@ -153,9 +169,9 @@ hipError_t wnv_launch_conv_in(const float* c, const float* w, float* out, int B,
 }
 
 hipError_t wnv_launch_stretch_fir(const float* in, const float* w, float* out, int B, int cin, long long Tin,
-                                  int scale, int transpose_out, long long indent, int fk, int act, float act_p, hipStream_t s) {
+                                  int scale, int transpose_out, long long indent, int fk, int act, float act_p, int mode, hipStream_t s) {
     const long long total = (long long)B * cin * (Tin * scale - 2 * indent);
-    if (transpose_out && fk == 1 && scale <= 16 && indent % scale == 0 && cin <= 2048) {
+    if (mode == 0 && transpose_out && fk == 1 && scale <= 16 && indent % scale == 0 && cin <= 2048) {
         // LDS-tiled last stage: ni input samples per tile such that the window fits 48 KiB
         int ni = 64;
         while (ni > 1 && (size_t)cin * ((ni + 2) | 1) * sizeof(float) > 48 * 1024) ni >>= 1;
@@ -169,7 +185,7 @@ hipError_t wnv_launch_stretch_fir(const float* in, const float* w, float* out, i
         }
     }
     hipLaunchKernelGGL(wnv_stretch_fir_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, w, out, B, cin, Tin,
-                       scale, transpose_out, indent, fk, act, act_p);
+                       scale, transpose_out, indent, fk, act, act_p, mode);
     return hipGetLastError();
 }
 

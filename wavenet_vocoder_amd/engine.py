@@ -28,7 +28,7 @@ def make_config(*, out_channels, layers, stacks, residual_channels, gate_channel
                 kernel_size, cin_channels, gin_channels, n_speakers, use_speaker_embedding, scalar_input,
                 output_distribution, upsample_net: Optional[str], upsample_scales: Sequence[int],
                 freq_axis_kernel_size: int, cin_pad: int, upsample_activation: str = "none",
-                upsample_activation_params: Optional[dict] = None) -> Config:
+                upsample_activation_params: Optional[dict] = None, upsample_mode: str = "nearest") -> Config:
     cfg = Config()
     cfg.abi_version = _lib.WNV_ABI_VERSION
     cfg.out_channels = out_channels
@@ -67,6 +67,9 @@ def make_config(*, out_channels, layers, stacks, residual_channels, gate_channel
     if set(params) - ({pname} if pname else set()):
         raise NotImplementedError(f"upsample_activation_params {sorted(params)} of {upsample_activation}")
     cfg.upsample_activation = kind
+    if upsample_mode not in _lib.UPSAMPLE_MODE:
+        raise NotImplementedError(f"upsampling mode {upsample_mode!r} (implemented: {sorted(_lib.UPSAMPLE_MODE)})")
+    cfg.upsample_mode = _lib.UPSAMPLE_MODE[upsample_mode]
     cfg.upsample_activation_param = float(params.get(pname, _lib.UPSAMPLE_ACT_DEFAULT.get(pname, 0.0))) if pname else 0.0
     cfg.cin_pad = int(cin_pad)
     return cfg

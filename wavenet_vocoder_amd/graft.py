@@ -44,18 +44,19 @@ def infer_config_kwargs(m) -> dict:
               n_speakers=None if emb is None else int(emb.num_embeddings), use_speaker_embedding=emb is not None,
               scalar_input=bool(m.scalar_input), output_distribution=m.output_distribution,
               upsample_net=None, upsample_scales=[], freq_axis_kernel_size=1, cin_pad=0, upsample_activation="none",
-              upsample_activation_params={})
+              upsample_activation_params={}, upsample_mode="nearest")
     up = getattr(m, "upsample_net", None)
     if up is not None:
         kind = type(up).__name__
         inner = up.upsample if kind == "ConvInUpsampleNetwork" else up
         from ._lib import UPSAMPLE_ACT
-        scales, freq, act, act_params = [], 1, "none", {}
+        scales, freq, act, act_params, mode = [], 1, "none", {}, "nearest"
         for layer in inner.up_layers:
             name = type(layer).__name__
             if name == "Stretch2d":
-                if getattr(layer, "mode", "nearest") != "nearest" or int(getattr(layer, "y_scale", 1)) != 1:
-                    raise NotImplementedError("only nearest-neighbour stretching along time is implemented (upsample.py:20)")
+                if getattr(layer, "mode", "nearest") not in ("nearest", "bilinear") or int(getattr(layer, "y_scale", 1)) != 1:
+                    raise NotImplementedError("nearest and bilinear stretching along time are implemented (upsample.py:20)")
+                mode = getattr(layer, "mode", "nearest")
                 scales.append(int(layer.x_scale))
             elif hasattr(layer, "kernel_size"):
                 freq = int(layer.kernel_size[0])
@@ -69,7 +70,7 @@ def infer_config_kwargs(m) -> dict:
             total *= s
         cin_pad = (int(up.conv_in.kernel_size[0]) - 1) // 2 if kind == "ConvInUpsampleNetwork" else int(up.indent) // total
         kw.update(upsample_net=kind, upsample_scales=scales, freq_axis_kernel_size=freq, cin_pad=cin_pad, upsample_activation=act,
-                  upsample_activation_params=act_params)
+                  upsample_activation_params=act_params, upsample_mode=mode)
     return kw
 
 

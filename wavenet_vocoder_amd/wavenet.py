@@ -89,10 +89,11 @@ class WaveNet(EngineHost, nn.Module):
             self._freq_k = int(upsample_params.get("freq_axis_kernel_size", 1))
             self._up_act = upsample_params.get("upsample_activation", "none")
             self._up_act_params = dict(upsample_params.get("upsample_activation_params", {}))
+            self._up_mode = upsample_params.get("mode", "nearest")
         else:
             self.upsample_net = None
             self._upsample_kind, self._upsample_scales, self._upsample_cin_pad, self._freq_k = None, [], 0, 1
-            self._up_act, self._up_act_params = "none", {}
+            self._up_act, self._up_act_params, self._up_mode = "none", {}, "nearest"
         self.receptive_field = receptive_field_size(layers, stacks, kernel_size)
         self._cfg_kwargs = dict(
             out_channels=out_channels, layers=layers, stacks=stacks, residual_channels=residual_channels,
@@ -101,7 +102,8 @@ class WaveNet(EngineHost, nn.Module):
             use_speaker_embedding=self.embed_speakers is not None, scalar_input=scalar_input,
             output_distribution=output_distribution, upsample_net=self._upsample_kind,
             upsample_scales=self._upsample_scales, freq_axis_kernel_size=self._freq_k,
-            cin_pad=self._upsample_cin_pad, upsample_activation=self._up_act, upsample_activation_params=self._up_act_params)
+            cin_pad=self._upsample_cin_pad, upsample_activation=self._up_act, upsample_activation_params=self._up_act_params,
+            upsample_mode=self._up_mode)
         # engine state (rng, kernel, capture_params, last_params, the packed-weight cache): EngineHost, not module state
 
     # ---- reference API ---------------------------------------------------------------------------
