@@ -213,3 +213,31 @@ def test_wide_onehot_eleven_utterances_vs_the_generic_kernel():
     assert_match_or_near_tie(c3.cpu(), c1.cpu(), p1.cpu(), tape.cpu(), kw)
     lone, _, cl = eng.generate(B=1, T=T, c_up=cu[9:10].contiguous(), teacher=tin[9:10].contiguous(), noise=tape[:, 9:10].contiguous(), want_index=True, kernel=3)
     assert torch.equal(cl[0], c3[9]), "utterance 9 of 11 must not depend on its neighbours"
+
+
+def test_wide_more_than_sixteen_utterances_run_in_slices():
+    """A batch beyond what the groups pipeline at once is served in slices of 16 (one launch each), noise addressed by the utterance's
+    index in the whole call: same numbers as the generic kernel on the whole batch (tape mode), and -- Philox mode -- an utterance
+    alone with its own stream position equals its row in the batch."""
+    kw, _, _, _ = CASES["mol_512_384_256_thirteen_utterances"]
+    torch.manual_seed(23)
+    m = tame_head_(wnv.WaveNet(**kw).eval()).to("cuda")
+    eng = m._get_engine()
+    B, Tt, T = 37, 24, 48
+    g = torch.Generator().manual_seed(12)
+    cu = torch.randn(B, T, kw["cin_channels"], generator=g).cuda()
+    x = torch.tanh(torch.randn(B, Tt, 1, generator=g) * 0.5).cuda()
+    tape = tape_for(kw, T, B, 3).cuda()
+    out3, p3, _ = eng.generate(B=B, T=T, c_up=cu, teacher=x, noise=tape, want_params=True, kernel=3)
+    assert eng.last_kernel() == 3
+    out1, p1, _ = eng.generate(B=B, T=T, c_up=cu, teacher=x, noise=tape, want_params=True, kernel=1)
+    assert float((p3[:, :, :Tt] - p1[:, :, :Tt]).abs().max()) < 5e-5
+    assert_match_or_near_tie(out3.cpu()[:, :, :Tt - 1], out1.cpu()[:, :, :Tt - 1], p1.cpu()[:, :, :Tt - 1], tape.cpu()[:Tt - 1], kw, tol=TOL)
+    auto, _, _ = eng.generate(B=B, T=T, c_up=cu, teacher=x, noise=tape, kernel=0)
+    assert eng.last_kernel() == 3 and torch.equal(auto, out3), "auto serves a wide model with the group ring at any batch size"
+    # Philox: the slices continue one stream (utterance b draws from position b), so slicing does not change a sample
+    ph, _, _ = eng.generate(B=B, T=T, c_up=cu, seed=77, kernel=3)
+    ph16, _, _ = eng.generate(B=16, T=T, c_up=cu[:16].contiguous(), seed=77, kernel=3)
+    assert torch.equal(ph[:16], ph16)
+    lone, _, _ = eng.generate(B=1, T=T, c_up=cu[:1].contiguous(), seed=77, kernel=3)                 # utterance 0 draws from stream position 0
+    assert torch.equal(lone[0], ph[0])

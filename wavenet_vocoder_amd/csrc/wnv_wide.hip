@@ -59,6 +59,7 @@ typedef unsigned u4v __attribute__((ext_vector_type(4)));
 
 struct WideParams {
     int L, nL, B, T, Tt, O, cin, cinp, kw, nz, dist, kpre, nkb;
+    int b0, noise_B;                                      // this launch is utterances [b0, b0 + B) of a call of noise_B (noise addressing)
     int head_x, head_li, fast;
     int cin1, softmax, quantize;                          // first_conv input channels (1 = scalar input); categorical switches (wavenet.py:332-335)
     int* index_out;
@@ -523,7 +524,7 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
             // ---- everything that does not depend on the network, while the groups work: the noise terms of the sampler ----------
             if (tid < p.nz) {
                 const int kind = (p.dist == 2 && tid == p.nz - 1) ? 1 : 0;
-                const float r = p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, b, tid, kind);
+                const float r = p.noise ? p.noise[((size_t)t * p.noise_B + p.b0 + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, p.b0 + b, tid, kind);
                 if (tid < nmix) s.nz[tid] = -logf(-logf(r));                                         // Gumbel noise (mixture.py:138-140)
                 else s.nz[tid] = p.dist == 1 ? logf(r) - logf(1.0f - r) : r;                         // mixture.py:151-152 / :265-267
             }
@@ -669,7 +670,7 @@ __device__ void run_wide_head_b(const WideParams& p, bool fast_first, float* sme
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
         for (int b = 0; b < p.B; ++b) {
-            if (tid < O) s.nz[tid] = p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, b, tid, 2);   // e ~ Exp(1)
+            if (tid < O) s.nz[tid] = p.noise ? p.noise[((size_t)t * p.noise_B + p.b0 + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, p.b0 + b, tid, 2);   // e ~ Exp(1)
             if (wave < 2) {
                 if (!recv128(p.hidmail + (size_t)b * KWD + 128 * wave, tag, s.hid + 128 * wave, p.status, 0x480u, lane)) s.ints[0] = 1;
             }
@@ -764,7 +765,7 @@ static const char* wide_why_not(const wnv_config& c, int B) {
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 128) return "needs cin_channels <= 128";
     if (c.layers > 30) return "needs layers <= 30 (8 workgroups per layer and 8 for the tail, 32 CUs per XCD, one or two more for the head)";
-    if (B > BMAX) return "more than 16 utterances per call";
+    (void)B;                                           // any batch: the host runs it in slices of 16 utterances
     return nullptr;
 }
 bool wnv_wide_supported(const wnv_config& c, int B) { return wide_why_not(c, B) == nullptr; }
@@ -977,6 +978,26 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
         if (st0 != WNV_OK) { wnv_wide_destroy(*pst); *pst = nullptr; return st0; }
     }
     WnvWideState* st = *pst;
+    if (ga.B > BMAX) {
+        // more utterances than the groups pipeline at once: slices of BMAX, one launch each (utterances are independent; the noise tape
+        // and the Philox stream are addressed with the utterance's index in the whole call, so the samples do not depend on the slicing)
+        const int cin1 = st->cin1, cin = st->cin, O = st->O;
+        for (int b0 = 0; b0 < ga.B; b0 += BMAX) {
+            WnvGenArgs g = ga;
+            g.B = std::min(BMAX, ga.B - b0);
+            g.b0 = ga.b0 + b0; g.noise_B = ga.noise_B > 0 ? ga.noise_B : ga.B;
+            if (ga.c_up) g.c_up = ga.c_up + (size_t)b0 * ga.T * cin;
+            if (ga.initial) g.initial = ga.initial + (size_t)b0 * cin1;
+            if (ga.teacher) g.teacher = ga.teacher + (size_t)b0 * ga.Tt * cin1;
+            if (ga.zbias_bstride != 0) g.zbias = ga.zbias + (size_t)b0 * ga.zbias_bstride;
+            g.out = ga.out + (size_t)b0 * cin1 * ga.T;
+            if (ga.params_out) g.params_out = ga.params_out + (size_t)b0 * O * ga.T;
+            if (ga.index_out) g.index_out = ga.index_out + (size_t)b0 * ga.T;
+            const wnv_status s0 = wnv_wide_generate(pst, device, c, store, g, stream, err);
+            if (s0 != WNV_OK) return s0;
+        }
+        return WNV_OK;
+    }
     const int B = ga.B, L = st->L;
     if (!st->map_ok || st->n_xcd != 8) {
         char buf[160];
@@ -1001,6 +1022,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     WideParams p{};
     p.L = L; p.nL = nL; p.B = B; p.T = (int)ga.T; p.Tt = (int)ga.Tt; p.O = st->O; p.cin = st->cin; p.cinp = st->cinp; p.kw = st->kw; p.nz = ga.nz;
     p.dist = c.output_distribution; p.kpre = st->kpre; p.nkb = st->nkb;
+    p.b0 = ga.b0; p.noise_B = ga.noise_B > 0 ? ga.noise_B : B;
     p.head_x = head_x; p.head_li = head_li;
     p.cin1 = st->cin1; p.softmax = ga.softmax; p.quantize = ga.quantize; p.index_out = ga.index_out;
     { const char* e = getenv("WNV_RING_FAST"); p.fast = !(e && e[0] == '0'); }
