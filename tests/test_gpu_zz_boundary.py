@@ -23,7 +23,7 @@ CHILD = r"""
 import json, sys, time, torch
 sys.path.insert(0, %(root)r)
 from tests._configs import build, inputs
-name, B, T = "cfg2_mol", 8, 256
+name, B, T, FORCED = %(name)r, %(B)d, %(T)d, %(forced)d
 m = build(name).to("cuda")
 eng = m._get_engine()
 c, _ = inputs(name, B, T)
@@ -44,7 +44,7 @@ res["second_auto_kernel"] = eng.last_kernel()
 res["second_equal"] = bool(torch.equal(again, auto))
 try:
     eng2 = build(name).to("cuda")._get_engine()
-    forced, _, _ = eng2.generate(B=B, T=T, c_up=c_up, seed=11, kernel=2)
+    forced, _, _ = eng2.generate(B=B, T=T, c_up=c_up, seed=11, kernel=FORCED)
     res["forced"] = "ran"
     res["forced_vs_generic"] = float((forced - ref).abs().max())
 except (TimeoutError, NotImplementedError) as e:
@@ -53,10 +53,11 @@ print("RESULT " + json.dumps(res), flush=True)
 """
 
 
-def run_child(env_extra, timeout=240):
+def run_child(env_extra, timeout=240, name="cfg2_mol", B=8, T=256, forced=2):
     env = dict(os.environ)
     env.update(env_extra)
-    p = subprocess.Popen([sys.executable, "-c", CHILD % {"root": ROOT}], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    p = subprocess.Popen([sys.executable, "-c", CHILD % {"root": ROOT, "name": name, "B": B, "T": T, "forced": forced}], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
         out, err = p.communicate(timeout=timeout)
     except subprocess.TimeoutExpired:
@@ -91,6 +92,22 @@ def test_cu_mask_clean_timeout_then_fallback():
         assert res["forced"] == "ran" or res["forced"].startswith(("TimeoutError", "NotImplementedError")), res
     else:
         # the mask left enough CUs co-resident after all (or is not honoured on this box): the ring result must be right
+        assert res["forced"] == "ran" and res["forced_vs_generic"] < 1e-3, res
+
+
+def test_cu_mask_group_ring_clean_fallback():
+    """The same for the group-ring kernel of wide models (201 co-resident workgroups, 32 per XCD): under the mask `auto` must come back
+    with the generic kernel's result, an explicit kernel = 3 with TimeoutError / NotImplementedError -- and unmasked it must run."""
+    kw = dict(name="wide_mol_512", B=2, T=256, forced=3)
+    res, err = run_child({}, **kw)
+    assert res["auto_kernel"] == 3 and res["forced"] == "ran" and res["auto_vs_generic"] < 1e-3 and res["forced_vs_generic"] < 1e-3, res
+    res, err = run_child({"HSA_CU_MASK": "0:0-63"}, **kw)
+    print(res, err[-600:])
+    assert res["auto_vs_generic"] < 1e-3, res
+    if res["auto_kernel"] == 1:
+        assert res["second_auto_kernel"] == 1 and res["second_equal"]
+        assert res["forced"] == "ran" or res["forced"].startswith(("TimeoutError", "NotImplementedError")), res
+    else:
         assert res["forced"] == "ran" and res["forced_vs_generic"] < 1e-3, res
 
 
