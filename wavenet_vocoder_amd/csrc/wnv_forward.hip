@@ -58,6 +58,18 @@ __device__ __forceinline__ float fwd_gate(float a, float g) {
     return copysignf((1.0f - e) * r, a);
 }
 
+// two elements at a time: the multiplies and adds as packed f32 operations (every VALU instruction between MFMAs costs matrix-pipe time)
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2v fwd_gate2(f2v a, f2v g) {
+    const f2v ea = f2v{fabsf(a.x), fabsf(a.y)} * f2v{-2.8853900817779268f, -2.8853900817779268f};
+    const f2v eg = g * f2v{-1.4426950408889634f, -1.4426950408889634f};
+    const f2v e = f2v{__builtin_amdgcn_exp2f(ea.x), __builtin_amdgcn_exp2f(ea.y)}, f = f2v{__builtin_amdgcn_exp2f(eg.x), __builtin_amdgcn_exp2f(eg.y)};
+    const f2v one = f2v{1.0f, 1.0f};
+    const f2v den = (one + e) * (one + f);
+    const f2v t = (one - e) * f2v{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    return f2v{copysignf(t.x, a.x), copysignf(t.y, a.y)};
+}
+
 #ifdef WNV_FWD_TRACE
 // debug build: per-phase cycles of wave 0 of every workgroup, summed (s_memtime), read back by the host after the last layer
 __device__ unsigned long long g_fwd_phase[16];
@@ -296,7 +308,10 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_layer_kernel(const LayerArgs a)
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[i][v] = fwd_gate(acc[i][v], acc[4 + i][v]);
+        for (int v = 0; v < 16; v += 2) {
+            const f2v r = fwd_gate2(f2v{acc[i][v], acc[i][v + 1]}, f2v{acc[4 + i][v], acc[4 + i][v + 1]});
+            acc[i][v] = r.x; acc[i][v + 1] = r.y;
+        }
     f16v (&u)[4] = *reinterpret_cast<f16v(*)[4]>(&acc[0]);
     f16v (&o)[4] = *reinterpret_cast<f16v(*)[4]>(&acc[4]);
     FWD_STAMP(6);                                                 // 6: gate
