@@ -23,7 +23,7 @@
 // History, each step measured (profiles/r01_forward_*, r02_forward_*): v1 59.9 TFLOP/s -> v8 93.8 (prefetch in registers, LDS bank
 // conflicts, scheduling barriers, straight-line epilogue) -> v9 104.1 (epilogue addressing, no spills) -> v10 109.2 (software
 // pipelining, time-major 64-row tile) -> v11 109.3 (this layout) -> v13 115.1 (steps without VALU work, DMA) -> v14 121.8 (buffer
-// addressing) -> v17 124.5 (biases in accumulator order, parity template).
+// addressing) -> v17 124.5 (biases in accumulator order, parity template) -> v18 125.6 (packed gate math).
 // Lane layout of the 32x32x2 MFMA (checked on the device by scripts/ubench_mfma.hip): A[i = lane % 32][k = lane / 32],
 // B[k = lane / 32][j = lane % 32], D[8 (v / 4) + 4 (lane / 32) + v % 4][lane % 32] for accumulator register v.
 #include <hip/hip_runtime.h>
