@@ -20,6 +20,10 @@
  *     mode') (reference conv.py:19-20), WNV_ERR_SHAPE -> AssertionError (wavenet.py:276), and so on.
  *   - not re-entrant per handle (the reference's modules are not either: per-module mutable buffers,
  *     SURVEY.md section 8b "Threading"); different handles may be used from different threads.
+ *     The persistent kernels (ring, group ring) need all their workgroups resident at once, so inside one
+ *     process the library lets them take turns per device: launches of different handles are ordered on the
+ *     device (an event behind the previous one) and their host side runs under a per-device mutex.  Other
+ *     processes on the same GPU are what the WNV_ERR_TIMEOUT fallback of kernel = 0 is for.
  */
 #ifndef WNV_H_
 #define WNV_H_

@@ -143,3 +143,52 @@ def test_config_read_off_the_module_tree_runs_the_same_launch():
     assert torch.equal(outs[0], outs[1])
     with pytest.raises(IndexError):                                   # nn.Embedding's error for an unknown speaker (wavenet.py:264-268)
         a.incremental_forward(c=c.cuda(), g=torch.full((B, 1), 7), T=T)
+
+
+def test_persistent_launches_of_two_handles_take_turns():
+    """Two ring launches in flight on one device would each hold part of the CUs and starve the other until the bounded spins give
+    up (WNV_ERR_TIMEOUT; in auto mode the handle would stay on the generic kernel).  Inside one process the library orders them
+    (wnv_host.cpp, TurnGuard): (i) two asynchronous launches of two handles on two streams, issued back to back -- both kernels
+    are queued before either has finished; (ii) two threads calling the synchronous auto mode at the same time."""
+    import threading
+    name, B, T = "cfg2_mol", 8, 94 * 256                             # 0.44 s per launch: longer than the kernel's bounded spins
+    engines = [build(name).to("cuda")._get_engine() for _ in range(2)]
+    c, _ = inputs(name, B, T)
+    c_up = engines[0].upsample(c.cuda(), T_expected=T)
+    serial = [eng.generate(B=B, T=T, c_up=c_up, seed=3 + i, kernel=2)[0].clone() for i, eng in enumerate(engines)]
+    assert not torch.equal(serial[0], serial[1])
+    torch.cuda.synchronize()
+    # (i) overlapping asynchronous launches
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    outs = []
+    for i, eng in enumerate(engines):
+        with torch.cuda.stream(streams[i]):
+            outs.append(eng.generate(B=B, T=T, c_up=c_up, seed=3 + i, kernel=2, asynchronous=True)[0])
+    for eng in engines:
+        eng.wait()                                                    # raises TimeoutError if a launch gave up
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(outs[i], serial[i]), i
+    # (ii) two host threads, auto mode
+    results, errors = [[], []], []
+    gate = threading.Barrier(2)
+
+    def work(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                gate.wait()
+                for _ in range(2):
+                    results[i].append(engines[i].generate(B=B, T=T, c_up=c_up, seed=3 + i, kernel=0)[0].clone())
+                streams[i].synchronize()
+        except Exception as e:                                        # noqa: BLE001 -- reported below
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(120)
+    assert not errors, errors
+    for i in range(2):
+        assert len(results[i]) == 2 and all(torch.equal(r, serial[i]) for r in results[i]), i
+        assert engines[i].last_kernel() == 2, "a handle fell back to the generic kernel"

@@ -7,8 +7,10 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -465,6 +467,41 @@ extern "C" wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* a) {
 // ------------------------------------------------------------------------------------------------
 // the hot loop
 // ------------------------------------------------------------------------------------------------
+// ---- one persistent launch at a time per device ---------------------------------------------------------------------------
+// The ring and group-ring kernels make progress only with ALL their workgroups resident.  Two of them in flight on one device
+// (two handles on two streams or threads) can each hold part of the CUs and starve the other until the bounded spins give up
+// -- WNV_ERR_TIMEOUT, and in auto mode a handle that stays on the generic kernel for no better reason than bad timing.  Inside
+// one process they therefore take turns: the host side of a persistent launch runs under a per-device mutex, and the launch is
+// ordered on the device behind an event recorded after the previous one (which matters for WNV_GEN_ASYNC launches, whose
+// kernels are still running when the call returns).  Other processes on the same GPU are what the time-out fallback is for.
+namespace {
+struct PersistentTurn {
+    std::mutex m;
+    hipEvent_t done = nullptr;      // recorded behind the last persistent launch on this device
+};
+PersistentTurn g_turns[64];
+class TurnGuard {                   // construct with the device current (DeviceGuard)
+  public:
+    TurnGuard(int device, hipStream_t s) : t_(g_turns[device & 63]), s_(s), on_(!std::getenv("WNV_NO_TURN")) {   // (diagnostic knob:
+        if (!on_) return;                                                // tests/test_gpu_zz_boundary.py shows what the turn prevents)
+        t_.m.lock();
+        if (t_.done) (void)hipStreamWaitEvent(s_, t_.done, 0);
+    }
+    ~TurnGuard() {
+        if (!on_) return;
+        if (!t_.done && hipEventCreateWithFlags(&t_.done, hipEventDisableTiming) != hipSuccess) t_.done = nullptr;
+        if (t_.done) (void)hipEventRecord(t_.done, s_);
+        t_.m.unlock();
+    }
+    TurnGuard(const TurnGuard&) = delete;
+    TurnGuard& operator=(const TurnGuard&) = delete;
+  private:
+    PersistentTurn& t_;
+    hipStream_t s_;
+    bool on_;
+};
+}  // namespace
+
 extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     if (!h || !a) return fail(WNV_ERR_INVALID_ARG, "NULL handle or args");
     if (h->device < 0) return fail(WNV_ERR_INVALID_ARG, "host-only handle (created with device = -1): there is no CPU path");
@@ -517,7 +554,11 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         if (!wnv_wide_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the group-ring kernel does not cover this configuration: %s", wnv_wide_why_not(c, a->B));
         HIP_TRY(zero_onehot_out());
         std::string err;
-        wnv_status st = wnv_wide_generate(&h->wide_state, h->device, c, h->store, ga, s, err);
+        wnv_status st;
+        {
+            TurnGuard turn(h->device, s);
+            st = wnv_wide_generate(&h->wide_state, h->device, c, h->store, ga, s, err);
+        }
         if (st == WNV_OK) { h->last_kernel = 3; return WNV_OK; }
         const bool recoverable = st == WNV_ERR_UNSUPPORTED || st == WNV_ERR_TIMEOUT;
         if (!(a->kernel == 0 && recoverable)) return fail(st, "%s", err.c_str());
@@ -529,7 +570,11 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         if (!wnv_ring_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the pipelined ring kernel does not cover this configuration: %s", wnv_ring_why_not(c, a->B));
         HIP_TRY(zero_onehot_out());
         std::string err;
-        wnv_status st = wnv_ring_generate(&h->ring_state, h->device, c, h->store, ga, s, err);
+        wnv_status st;
+        {
+            TurnGuard turn(h->device, s);
+            st = wnv_ring_generate(&h->ring_state, h->device, c, h->store, ga, s, err);
+        }
         if (st == WNV_OK) { h->last_kernel = 2; return WNV_OK; }
         // auto mode: a device that cannot host the persistent pipeline (fewer CUs than one ring + its tap workgroups per XCD, a
         // partitioned GPU: WNV_ERR_UNSUPPORTED from the occupancy / placement checks) or did not keep it co-resident (CUs masked
