@@ -83,6 +83,12 @@ ODD = {
                       dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=80, upsample_conditional_features=False), 2, 31),
     "tiny_T1": (dict(out_channels=30, layers=4, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
                      dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=80, upsample_conditional_features=False), 3, 1),
+    # first_conv on the matrix pipe (one-hot models): a class count that is odd and no multiple of the 8-row trip, a DENSE input
+    # (every row of the 251 x T operand matters, unlike a one-hot one), T one more than a wave's 32 steps
+    "soft251_T33": (dict(out_channels=251, layers=4, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
+                         dropout=0.0, cin_channels=80, upsample_conditional_features=False), 2, 33),
+    "soft6_T300": (dict(out_channels=6, layers=4, stacks=2, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=2,
+                        dropout=0.0), 3, 300),
     # speaker embedding + conditioning, kernel size 3, T a multiple of the tile
     "speakers_T384": (dict(out_channels=256, layers=6, stacks=3, residual_channels=128, gate_channels=256, skip_out_channels=128, kernel_size=3,
                            dropout=0.0, cin_channels=36, gin_channels=8, n_speakers=5, use_speaker_embedding=True,
@@ -102,6 +108,8 @@ def test_forward_odd_shapes_vs_the_torch_graph(name):
     scalar = kw.get("scalar_input", False)
     x = torch.tanh(torch.randn(B, 1, T, generator=g)) if scalar else torch.nn.functional.one_hot(
         torch.randint(0, kw["out_channels"], (B, T), generator=g), kw["out_channels"]).transpose(1, 2).float()
+    if name.startswith("soft"):
+        x = torch.softmax(2.0 * torch.randn(B, kw["out_channels"], T, generator=g), dim=1)
     c = torch.randn(B, kw["cin_channels"], T, generator=g).cuda() if kw.get("cin_channels", -1) > 0 else None
     gid = torch.randint(0, kw["n_speakers"], (B, 1), generator=g).cuda() if kw.get("gin_channels", -1) > 0 else None
     x = x.cuda()

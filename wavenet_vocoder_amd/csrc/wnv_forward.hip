@@ -491,6 +491,52 @@ __global__ void wnv_fwd_first_kernel(const float* __restrict__ x, const float* _
     H[idx] = acc;
 }
 
+// first_conv of one-hot / soft-input models (cin1 = out_channels > 1): the same product on the matrix pipe, D[channel][time] =
+// W (128 x cin1) . x (cin1 x 32) per wave.  A workgroup of four waves takes 128 consecutive time steps of one utterance; both operands
+// come straight from memory (w_first is k-major, so a half wave's A load is one 128-byte row piece; x is channel-major, so a half
+// wave's B load is 32 consecutive time steps); the 128-KB matrix stays in the L2 / L1.  (The scalar loop above spent 4 ms on the
+// 256-class models at the benchmark shape -- 22 % of the whole forward -- re-reading x 128 times through the caches.)
+__global__ void __launch_bounds__(256) wnv_fwd_first_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wf, const float* __restrict__ bf,
+                                                                 float* __restrict__ H, int cin1, long long T) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const long long t0 = (long long)blockIdx.x * TN + 32 * wave;
+    if (t0 >= T) return;
+    const long long t = t0 + (lane & 31), tc = t < T ? t : T - 1;
+    const int kh = lane >> 5;
+    const float* xb = x + (size_t)b * cin1 * T + tc;
+    const float* wa = wf + (lane & 31);
+    f16v acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[i][v] = bf[32 * i + acc_row(v, lane)];
+    for (int k0 = 0; k0 < cin1; k0 += 8) {                         // four k pairs per trip: 20 loads in flight, then 16 MFMAs
+        float xv[4], wv[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 2 * j + kh;
+            const bool in = k < cin1;                              // cin1 not a multiple of 8: the empty k contribute zeros
+            const int kc = in ? k : cin1 - 1;
+            const float xl = xb[(size_t)kc * T];                   // (unconditional load of a clamped row, then a select: no branch)
+            xv[j] = in ? xl : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wv[j][i] = wa[(size_t)kc * HC + 32 * i];
+        }
+        __builtin_amdgcn_sched_barrier(0);                         // all 20 loads issued before the first MFMA waits for its operands
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[j][i], xv[j], acc[i], 0, 0, 0);
+    }
+    if (t < T) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) H[((size_t)b * HC + 32 * i + acc_row(v, lane)) * T + t] = acc[i][v];
+    }
+}
+
 // F.softmax(x, dim=1) in place on (B, O, T) (wavenet.py:211)
 __global__ void wnv_fwd_softmax_kernel(float* __restrict__ out, int O, long long T, long long n) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -532,8 +578,12 @@ hipError_t wnv_launch_forward(const WnvModelDev& m, const WnvLayerDev* layers_ho
     if (e != hipSuccess) return e;
     {
         const long long n = (long long)B * T * HC;
-        hipLaunchKernelGGL(wnv_fwd_first_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.x, d_W + m.w_first, d_W + m.b_first,
-                           H0, m.cin1, T, n);
+        if (m.cin1 > 1)
+            hipLaunchKernelGGL(wnv_fwd_first_mfma_kernel, dim3((unsigned)((T + TN - 1) / TN), (unsigned)B), dim3(256), 0, s, a.x, d_W + m.w_first,
+                               d_W + m.b_first, H0, m.cin1, T);
+        else
+            hipLaunchKernelGGL(wnv_fwd_first_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a.x, d_W + m.w_first, d_W + m.b_first,
+                               H0, m.cin1, T, n);
     }
     const int tiles = (int)((T + TN - 1) / TN);
     const int cp = (m.cin + KT - 1) / KT * KT;
