@@ -412,37 +412,60 @@ __global__ void __launch_bounds__(FT, 2) wnv_fwd_head_kernel(const HeadArgs a) {
     for (int i = 0; i < NOT; ++i)
 #pragma unroll
         for (int v = 0; v < 16; ++v) oacc[i][v] = 0.f;
+    // staging registers of one GEMM1 chunk: thread (r = tid / 16, m8 = 8 (tid % 16)) carries 8 time steps of skip row r; threads tid and
+    // FT + tid carry one float4 each of the [16 k][128 hidden] weight chunk
+    const int sr = tid >> 4, m8 = 8 * (tid & 15);
+    const bool whole = t0 + TN <= a.T && (a.T & 3) == 0;          // the tile lies inside the utterance and its rows are 16-byte aligned
+    float4 sv0, sv1, wv0, wv1;
+    auto load_chunk = [&](int hb, int kc) {
+        const float* row = a.Skip + ((size_t)b * a.K + kc * KT + sr) * a.T + t0 + m8;
+        if (whole) {
+            sv0 = *reinterpret_cast<const float4*>(row);
+            sv1 = *reinterpret_cast<const float4*>(row + 4);
+        } else {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = t0 + m8 + e < a.T ? row[e] : 0.f;
+            sv0 = make_float4(v[0], v[1], v[2], v[3]);
+            sv1 = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        const float* w = a.w_h1 + (size_t)(kc * KT + (tid >> 5)) * a.kp + HC * hb + 4 * (tid & 31);
+        wv0 = *reinterpret_cast<const float4*>(w);
+        wv1 = *reinterpret_cast<const float4*>(w + (size_t)8 * a.kp);
+    };
+    auto store_chunk = [&](int buf) {
+        float* x = xt + buf * (KT * XT) + sr * XT + m8;
+        *reinterpret_cast<float4*>(x) = make_float4(fmaxf(sv0.x * a.scale, 0.f), fmaxf(sv0.y * a.scale, 0.f), fmaxf(sv0.z * a.scale, 0.f), fmaxf(sv0.w * a.scale, 0.f));
+        *reinterpret_cast<float4*>(x + 4) = make_float4(fmaxf(sv1.x * a.scale, 0.f), fmaxf(sv1.y * a.scale, 0.f), fmaxf(sv1.z * a.scale, 0.f), fmaxf(sv1.w * a.scale, 0.f));
+        float4* w = reinterpret_cast<float4*>(wc + buf * (KT * HC));
+        w[tid] = wv0;
+        w[FT + tid] = wv1;
+    };
     for (int hb = 0; hb < a.K / HC; ++hb) {                      // hidden channels [128 hb, 128 hb + 128)
         f16v hacc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int v = 0; v < 16; ++v) hacc[i][v] = 0.f;
-        for (int kc = 0; kc < a.K / KT; ++kc) {
-            {   // relu(skips * sqrt(1/L)) chunk (wavenet.py:200-203): 16 skip channels x 128 time steps
-                const int r = tid >> 4, m8 = 8 * (tid & 15);
-                const float* row = a.Skip + ((size_t)b * a.K + kc * KT + r) * a.T;
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const long long t = t0 + m8 + e;
-                    v[e] = t < a.T ? fmaxf(row[t] * a.scale, 0.f) : 0.f;
-                }
-                *reinterpret_cast<float4*>(xt + r * XT + m8) = make_float4(v[0], v[1], v[2], v[3]);
-                *reinterpret_cast<float4*>(xt + r * XT + m8 + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {                        // W_h1 rows [16 kc, +16) x hidden columns [128 hb, +128): 512 float4
-                const int f = q * FT + tid, k = kc * KT + (f >> 5), col = HC * hb + 4 * (f & 31);
-                reinterpret_cast<float4*>(wc)[f] = *reinterpret_cast<const float4*>(a.w_h1 + (size_t)k * a.kp + col);
-            }
-            __syncthreads();
+        // GEMM1 of this hidden block, software-pipelined: chunk kc + 1 (16 skip channels x 128 time steps, ReLU and scale applied on the
+        // way -- wavenet.py:200-203 -- and W_h1 rows [16 kc, +16) x hidden columns [128 hb, +128)) travels global -> registers -> the
+        // other LDS buffer while the MFMAs of chunk kc run: one barrier per chunk
+        const int n1 = a.K / KT;
+        load_chunk(hb, 0);
+        store_chunk(0);
+        __syncthreads();
+        for (int kc = 0; kc < n1; ++kc) {
+            const bool more = kc + 1 < n1;
+            if (more) load_chunk(hb, kc + 1);
+            const float* xc = xt + (kc & 1) * (KT * XT);
+            const float* wk = wc + (kc & 1) * (KT * HC);
 #pragma unroll
             for (int ks = 0; ks < KT / 2; ++ks) {
-                const float bv = xt[(2 * ks + kl) * XT + 32 * wave + jl];
+                const float bv = xc[(2 * ks + kl) * XT + 32 * wave + jl];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) hacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[(2 * ks + kl) * HC + 32 * i + jl], bv, hacc[i], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) hacc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(wk[(2 * ks + kl) * HC + 32 * i + jl], bv, hacc[i], 0, 0, 0);
             }
+            if (more) store_chunk((kc + 1) & 1);
             __syncthreads();
         }
 #pragma unroll
