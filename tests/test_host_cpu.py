@@ -300,12 +300,13 @@ def test_bulk_noise_tape_equals_the_per_step_replay(scalar, dist, C):
     """make_noise_tape draws the whole tape in one call where torch's CPU stream is provably partition-independent (uniform_,
     exponential_; normal_ for batch sizes that are multiples of 16) and step by step otherwise; both must give the numbers the
     reference's per-step calls consume -- and leave the generator in the same state."""
-    for B in (1, 3, 8, 16, 32):
+    for B in (1, 3, 8, 15, 16, 24, 32):
         g1, g2 = torch.Generator().manual_seed(3), torch.Generator().manual_seed(3)
         a = make_noise_tape(37, B, scalar_input=scalar, output_distribution=dist, out_channels=C, generator=g1)
         b = make_noise_tape(37, B, scalar_input=scalar, output_distribution=dist, out_channels=C, generator=g2, per_step=True)
         assert a.shape == (37, B, noise_width(scalar, dist, C)) and torch.equal(a, b), (scalar, dist, C, B)
         assert torch.equal(torch.empty(5).uniform_(generator=g1), torch.empty(5).uniform_(generator=g2))
+        assert torch.equal(torch.empty(3).normal_(generator=g1), torch.empty(3).normal_(generator=g2))     # (the cached Box-Muller half too)
 
 
 def test_upsample_stretch_modes():
