@@ -1,28 +1,54 @@
-"""Fine-grained timeline of ring stages (debug build with -DWNV_FINE_TRACE).  Slots: 0 X received (after LDS + barrier) | 1 u sent
-(wave 0) | 2 H sent | 3 skip sent | 4 deferred done | 5 gate value ready (wave 0) | 6 zin ready | 7 barrier after u | 8 poll that
-carried every tag returned (wave 0) | 9..15 u sent by waves 1..7."""
+"""Fine-grained timeline of ring stages (trace build, -DWNV_FINE_TRACE: stamps are noted in registers and written once per step,
+behind everything that is timed).  Slots per (step, stage): 0 X and zin in LDS (barrier passed) | 1 u sent (wave 0) | 2 H sent |
+3 skip sent | 4 step done | 5 h_{l-1} received (wave 0) | 6 zin ready (N waves) | 7 barrier behind u passed | 8 poll that carried
+every tag of the chain input returned (wave 0) | 9..11 u sent by chain waves 1..3.  Head: 0 input of the step sent | 1 skip sum in
+LDS | 2 step done.
+
+    python scripts/fine_trace.py <raw trace written by WNV_RING_TRACE>"""
 import sys
 rows = [l.split() for l in open(sys.argv[1]) if not l.startswith("#")]
 steps = sorted({int(r[0]) for r in rows})
 S = max(int(r[1]) for r in rows)
-W = len(rows[0]) - 2
 acc = {}
+def get(t, pos):
+    r = [x for x in rows if int(x[0]) == t and int(x[1]) == pos][0]
+    return [int(x) for x in r[2:]]
 for t in steps[1:-1]:
-    base = [int(x) for x in [r for r in rows if int(r[0]) == t and int(r[1]) == S][0][2:]][0]
-    prev = None
-    for pos in range(1, S):
-        r = [x for x in rows if int(x[0]) == t and int(x[1]) == pos][0]
-        v = [int(x) - base for x in r[2:]]
-        sends = [v[1]] + ([v[k] for k in range(9, 16)] if W >= 16 else [])
-        cur = dict(v=v, first=min(sends), last=max(sends))
-        if prev is not None and W >= 16:
-            d = dict(transport=v[8] - prev["last"], lds_barrier=v[0] - v[8], matvec_gate=v[5] - v[0], store_issue=v[1] - v[5],
-                     wave_skew=cur["last"] - cur["first"], layer=v[1] - prev["v"][1])
-            for k, x in d.items():
-                acc.setdefault(k, []).append(x)
-            if t == steps[2]:
-                print(f"stage {pos:2d}: last u of stage {pos-1} sent {prev['last']:6d} -> poll hit {v[8]:6d} (+{d['transport']:4d}) -> in LDS {v[0]:6d} (+{d['lds_barrier']:3d}) "
-                      f"-> gate ready {v[5]:6d} (+{d['matvec_gate']:3d}) -> u sent wave0 {v[1]:6d}, waves: first {cur['first']:6d} last {cur['last']:6d} (skew {d['wave_skew']:3d}) | zin ready {v[6]:6d}")
-        prev = cur
+    base = get(t, S)[0]
+    st = {}
+    for pos in range(0, S):
+        raw = get(t, pos)
+        v = [x - base if x >= 0 else None for x in raw]
+        sends = [x for x in [v[1], v[9], v[10], v[11]] if x is not None]
+        st[pos] = dict(v=v, first=min(sends), last=max(sends))
+    for pos in range(2, S):
+        c, pr, pp = st[pos], st[pos - 1], st[pos - 2]
+        v = c["v"]
+        d = dict(transport=v[8] - pr["last"], zin_ahead_of_hit=v[8] - v[6], lds_barrier=v[0] - max(v[8], v[6]), chain_phase=c["first"] - v[0],
+                 wave_skew=c["last"] - c["first"], layer=c["last"] - pr["last"],
+                 h_transport=v[5] - pp["v"][2], n_phase=v[6] - v[5], barrier_behind_u=v[7] - c["last"], o_phase=v[2] - v[7], skip_after_h=v[3] - v[2],
+                 rest=v[4] - max(v[3], v[2]))
+        if len(v) >= 32 and v[12] is not None and v[13] is not None:
+            d.update(n_barrier=v[12] - v[5], n_matvec_w4=v[6] - v[12], n_matvec_w5=v[13] - v[12])
+        if len(v) >= 32 and v[30] is not None:
+            d.update(o_dot_w0=v[14] - v[7], o_recv_w0=v[15] - v[14], o_store_w0=v[2] - v[15],
+                     o_dot_w4=v[30] - v[7], o_recv_w4=v[31] - v[30], o_store_w4=v[18] - v[31], h_arrival_vs_bar=(pr["v"][18] if pr["v"][18] is not None else pr["v"][2]) - v[7])
+        for k, x in d.items():
+            acc.setdefault(k, []).append(x)
+        if t == steps[2]:
+            print(f"stage {pos:2d}: u[{pos-1}] sent {pr['last']:6d} -> hit {v[8]:6d} (+{d['transport']:4d}) | h recv {v[5]:6d} zin {v[6]:6d} -> in LDS {v[0]:6d} "
+                  f"-> u sent {c['first']:6d}..{c['last']:6d} (+{d['chain_phase']:3d}, skew {d['wave_skew']:3d}) -> bar {v[7]:6d} H {v[2]:6d} skip {v[3]:6d} done {v[4]:6d}")
+    hd = get(t, S)
+    nxt = get(t + 1, S) if t + 1 in steps else None
+    last = st[S - 1]
+    if nxt and hd[3] >= 0 and hd[4] >= 0:
+        for k, x in dict(head_hidden=hd[3] - hd[1], head_out=hd[4] - hd[3], head_sample_send=nxt[0] - hd[4]).items():
+            acc.setdefault(k, []).append(x)
+    e = dict(head_skip_hop=hd[1] - base - last["v"][3], head_mlp_sample=(nxt[0] - hd[1]) if nxt else None, first_hop=st[0]["v"][8], step=(nxt[0] - hd[0]) if nxt else None)
+    for k, x in e.items():
+        if x is not None:
+            acc.setdefault(k, []).append(x)
 if acc:
-    print("means over stages 2..S-1 and", len(steps) - 2, "steps (ns):", {k: round(sum(x) / len(x), 1) for k, x in acc.items()})
+    print("means (ns) over stages 2..S-1 and", len(steps) - 2, "steps:")
+    for k, x in acc.items():
+        print(f"  {k:18s} {sum(x) / len(x):8.1f}   (min {min(x)}, max {max(x)})")

@@ -74,7 +74,8 @@ struct RingParams {
     long long zbias_bstride;
     int zb_ld, gh;                     // its row stride (G padded to 4) and the model's G / 2: padded output n -> row (n >> 7) * gh + (n & 127)
     const int *lay_dil, *lay_histoff;
-    unsigned long long *xmail, *hmail, *smail;   // chain inputs X[b][S+1][128]; layer inputs H[b][2 (t parity)][S+1][128]; skip sums
+    unsigned long long *xmail, *hmail, *smail;   // chain inputs X[b][S+1][128]; residual increments Q[b][2 (t parity)][S+1][128] (slot l+1 = conv1x1_out(u_l) + b_o,l); skip sums
+    unsigned long long *gmail;                   // layer inputs handed on: G[b][2 (t parity)][S+1][128], slot j = h_{j-1}[t] as stage j formed it (read by stage j + 1)
     unsigned long long *omail;                   // head parts j > 0 -> part 0: partial head outputs O[b][NH][Op]
     float *fmail, *pmail;                        // bulk records: stage -> tap workgroup h_l[t]: F[b][L][4 + 128]; tap workgroup -> stage pre_l[t+1]: P[b][L][4 + 256]
     int ring_blocks, tap_parts;                  // blocks [0, ring_blocks) = rings, then tap_parts tap workgroups per layer (part q serves passes q, q + parts, ...)
@@ -102,6 +103,14 @@ __device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v, bool f
     const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
     if (fast) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(x) : "memory");
     else asm volatile("global_store_dwordx2 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+}
+
+// two adjacent granules {tag, v0} {tag, v1} in one 16-byte store (a wave hands on a whole 128-value vector with one instruction)
+__device__ __forceinline__ void st_granule2(u64* p, unsigned tag, float v0, float v1, bool fast) {
+    typedef unsigned u4s __attribute__((ext_vector_type(4)));
+    const u4s x = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
+    if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(x) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
 }
 
 // BULK hand-off for the traffic nobody waits for (stage <-> tap workgroup, any XCD): raw floats in 16-B write-through
@@ -320,13 +329,35 @@ __device__ __forceinline__ bool same_xcd_as(const RingParams& p, int reader_a, i
     return *flag != 0;
 }
 
-// debug timeline: stamp slot k of (step t, position pos) with the device-wide 100 MHz wall clock
-constexpr int TRW = 16;            // stamp slots per (step, position)
+// debug timeline (builds with -DWNV_FINE_TRACE only; the product kernel carries no stamp code -- the scalar bookkeeping of a
+// run-time "is this step traced" test sat on the chain of every stage): a role notes the device-wide 100 MHz wall clock in
+// REGISTERS where something happens (WNV_TS: one s_memrealtime, no wait, no store) and lane 0 of a wave writes the slots it owns
+// once per step, behind everything that is timed (WNV_TS_FLUSH).
+constexpr int TRW = 32;            // stamp slots per (step, position)
+#ifdef WNV_FINE_TRACE
 // (every utterance of ring 0 is stamped: utterance b = j n_rings is the j-th of that ring)
-__device__ __forceinline__ void stamp(const RingParams& p, int b, int t, int pos, int k, int who = 0) {
-    if (p.trace && b % p.n_rings == 0 && (int)threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
-        p.trace[(((size_t)(t - p.trace_t0) * p.upr + b / p.n_rings) * (p.S + 1) + pos) * TRW + k] = wall_clock64();
+__device__ __forceinline__ bool ts_traced(const RingParams& p, int b, int t) {
+    return p.trace && b % p.n_rings == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n;
 }
+__device__ __forceinline__ unsigned long long* ts_row(const RingParams& p, int b, int t, int pos) {
+    return p.trace + (((size_t)(t - p.trace_t0) * p.upr + b / p.n_rings) * (p.S + 1) + pos) * TRW;
+}
+// slots [k of tsv] -> [k + shift] of the row, for the bits set in mask
+__device__ __forceinline__ void ts_flush(const RingParams& p, int b, int t, int pos, const unsigned long long (&tsv)[TRW], unsigned mask, int shift = 0) {
+    if ((threadIdx.x & 63) != 0 || !ts_traced(p, b, t)) return;
+    unsigned long long* row = ts_row(p, b, t, pos);
+#pragma unroll
+    for (int k = 0; k < TRW; ++k)
+        if ((mask >> k) & 1u) row[k + shift] = tsv[k];
+}
+#define WNV_TS_DECL unsigned long long tsv[TRW] = {0}
+#define WNV_TS(k) (tsv[k] = __builtin_amdgcn_s_memrealtime())
+#define WNV_TS_FLUSH(b, t, pos, mask, shift) ts_flush(p, b, t, pos, tsv, mask, shift)
+#else
+#define WNV_TS_DECL
+#define WNV_TS(k) ((void)0)
+#define WNV_TS_FLUSH(b, t, pos, mask, shift) ((void)0)
+#endif
 
 // sum over the four adjacent lanes of a quad (the four K-quarters of one output channel): two DPP quad_perm adds
 template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
@@ -421,6 +452,7 @@ struct StageLds {
     float* us;       // gate output u_l[t]
     float* hh;       // h_l[t], collected for the tap workgroup
     float* pre;      // [256] pre_l[t] from the layer's tap workgroup
+    float* zin;      // [128][2] {tanh, sigmoid} rows of N_l h_{l-1}[t] + pre_l[t]: handed from the N waves to the chain waves
     int* flags;
     float* bsk;      // [512] conv1x1_skip bias
     float4* wsk;     // [passes in LDS][2 rows][4 chunks][512 threads] image of conv1x1_skip (64 KiB per 128 skip channels; off the chain)
@@ -438,12 +470,13 @@ __device__ __forceinline__ StageLds carve_stage(float* smem) {
     s.us = smem + 16 * ES;
     s.hh = smem + 24 * ES;
     s.pre = smem + 32 * ES;
-    s.flags = reinterpret_cast<int*>(s.pre + GC);
+    s.zin = s.pre + GC;
+    s.flags = reinterpret_cast<int*>(s.zin + GC);
     s.bsk = reinterpret_cast<float*>(s.flags + 16);
     s.wsk = reinterpret_cast<float4*>(s.bsk + 512);
     return s;
 }
-__host__ __device__ constexpr size_t stage_lds_floats(int NK) { return (size_t)32 * ES + GC + 16 + 512 + (size_t)lds_passes(NK) * 8 * RT * 4; }
+__host__ __device__ constexpr size_t stage_lds_floats(int NK) { return (size_t)32 * ES + 2 * GC + 16 + 512 + (size_t)lds_passes(NK) * 8 * RT * 4; }
 
 // ---- tap workgroup (one per layer, shared by all rings) -----------------------------------------------------------------
 // Everything of a layer that is known a step ahead -- the dilated conv's older taps and the local-conditioning 1x1,
@@ -503,8 +536,12 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
         const int tp = t + 1;
         for (int b0 = part * TB; b0 < p.B; b0 += p.tap_parts * TB) {
             const int nb = min(TB, p.B - b0);
+#ifdef WNV_FINE_TRACE
 #define TAP_STAMP(k) do { if (p.trace_tap && l == 0 && part == 0 && b0 == 0 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
                               p.trace_tap[(size_t)(t - p.trace_t0) * TRW + (k)] = wall_clock64(); } while (0)
+#else
+#define TAP_STAMP(k) ((void)0)
+#endif
             TAP_STAMP(0);
             // ---- h_l[t] of utterances b0 .. b0+nb-1, forwarded by their stages: wave w takes utterance b0 + w, two granules
             //      per lane (one 16-B load), and files the row in the history ring ------------------------------------------
@@ -651,22 +688,68 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
     }
 }
 
+// ---- the 256-row mat-vec of a WAVE GROUP (four waves = one wave per SIMD) -------------------------------------------------
+// A stage's eight waves form two groups: waves 0-3 hold M_l and are the only ones that work while the chain waits (nothing shares
+// their SIMDs), waves 4-7 hold N_l and prepare zin = N_l h_{l-1} + pre_l ahead of it.  (Until round 3 every wave held half of M and
+// half of N: the two waves of a SIMD then finished the chain mat-vec one after the other -- the second wave's store left ~0.14 us
+// after the first's, profiles/r02_ring_v12_fine_timeline.txt -- and every wave repeated the reduce and the gate.)
+// Group thread gtid = (og = gtid >> 3, ks = gtid & 7): eight adjacent lanes split K = 128 (16 floats each) for the EIGHT rows
+// {tanh, sigmoid} x channels 4og .. 4og + 3.  The reduce-scatter needs no selects because the register SLOT of a row depends on
+// the lane (the host lays the image out that way, put_row8g): with b2 = ks >> 2, b1 = (ks >> 1) & 1 a lane's slot pairs hold
+// channels 4og + {2b2 + b1, 2b2 + 1-b1, 2(1-b2) + 1-b1, 2(1-b2) + b1}; step 1 (row_half_mirror, lane j <-> 7 - j) adds the partner's
+// slots 4-7 to slots 0-3, step 2 (lane j <-> j ^ 2) the partner's 2-3 to 0-1, step 3 (j <-> j ^ 1) completes both rows of
+// channel 4og + (ks >> 1) in lanes ks and ks ^ 1: 8 DPP adds for 8 rows.
+constexpr int GT = 256;            // threads of a wave group
+__device__ __forceinline__ void load_image8g(const float* img, int gtid, f2 (&w)[8]) {
+    const float4* src = reinterpret_cast<const float4*>(img);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 v = src[(size_t)c * GT + gtid];
+        w[2 * c] = f2{v.x, v.y}; w[2 * c + 1] = f2{v.z, v.w};
+    }
+}
+template <int CTRL> __device__ __forceinline__ float dpp_fold(float keep, float send) {
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, true));
+}
+// (za, zb: two addends read from LDS ahead of the x slice -- their latency hides under the FMAs -- and added to a and g)
+__device__ __forceinline__ void group_matvec8(const f2 (&w)[8][8], const float* xslice, const float* za, const float* zb, float& a, float& g) {
+    float2 z = make_float2(*za, *zb);
+    float x[16];
+    lds_read16(xslice, x);
+    f2 acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = f2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[s] = __builtin_elementwise_fma(w[s][k], f2{x[2 * k], x[2 * k + 1]}, acc[s]);
+    asm volatile("" : "+v"(z.x), "+v"(z.y));                     // the reads were issued up there, not behind the reduce
+    float q[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) q[s] = acc[s].x + acc[s].y;
+    const float n0 = dpp_fold<0x141>(q[0], q[4]), n1 = dpp_fold<0x141>(q[1], q[5]);
+    const float n2 = dpp_fold<0x141>(q[2], q[6]), n3 = dpp_fold<0x141>(q[3], q[7]);
+    const float m0 = dpp_fold<0x4E>(n0, n2), m1 = dpp_fold<0x4E>(n1, n3);
+    a = dpp_fold<0xB1>(m0, m0) + z.x;
+    g = dpp_fold<0xB1>(m1, m1) + z.y;
+}
+
 // One stage = one gated layer on one CU, weights resident in VGPRs.
 //
 // GATE-TO-GATE CHAIN.  The reference's layer is  z_l = W_cur,l h_l + pre_l ;  u_l = tanh . sigmoid (z_l) ;
 // h_{l+1} = sqrt(.5) (W_o,l u_l + b_o,l + h_l)   (modules.py:127-163).  Substituting h_l into z_l,
 //     z_l = M_l u_{l-1} + N_l h_{l-1} + c_l + pre_l ,   M_l = sqrt(.5) W_cur,l W_o,l-1 ,  N_l = sqrt(.5) W_cur,l ,  c_l = N_l b_o,l-1
 // (M, N, c folded once on the host, in double).  h_{l-1} is known a whole layer earlier than u_{l-1}, so only
-// M_l u_{l-1} -> gate -> send u_l  is on the chain; conv1x1_out (the h recurrence itself, bit for bit the reference's),
-// the N_l mat-vec (weights in LDS), the skip 1x1, the history push and the older taps all happen behind the send.
+// M_l u_{l-1} -> gate -> send u_l  is on the chain (waves 0-3); the N_l mat-vec (waves 4-7, ahead of the chain), conv1x1_out
+// (the h recurrence itself, bit for bit the reference's), the skip 1x1, the history push and the older taps all happen off it.
 // The values exchanged:  X[l] = u_{l-1} (X[0] = h_0 from the head) over the chain mailbox;  H[l] = h_l, written by
 // stage l-1 into a mailbox with one slot per step parity and read by stage l (residual, history) and stage l+1 (N);
 // two slots because those reads are off the chain: a slot is rewritten two steps later, which the data flow itself
 // orders behind every reader (the writer's gate of step t+2 needs the sample of step t+1, hence every stage's step t+1).
 //
-// Thread mapping: eight adjacent lanes split the K = 128 contraction (16 floats each), a group of eight lanes owns
-// channels 2og and 2og + 1; reductions are reduce-scatters (first DPP step row_half_mirror, lane j <-> 7 - j, hands
-// lanes 0-3 the sums of channel 2og and lanes 4-7 those of 2og + 1; two quad_perm steps finish).
+// Thread mapping of the work behind the send (all eight waves): eight adjacent lanes split the K = 128 contraction (16 floats
+// each), a group of eight lanes owns channels 2og and 2og + 1; reductions are reduce-scatters (first DPP step row_half_mirror,
+// lane j <-> 7 - j, hands lanes 0-3 the sums of channel 2og and lanes 4-7 those of 2og + 1; two quad_perm steps finish).
 template <int NK>
 __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
     constexpr int NLDS = lds_passes(NK);
@@ -677,24 +760,30 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     const bool hi = ks >= 4;                                    // lanes 4-7 finish channel 2og + 1, lanes 0-3 channel 2og
     const int ch = 2 * og + (hi ? 1 : 0);
     const bool writer = (ks & 3) == 0;                          // lanes 0 and 4 of the group publish
+    // wave groups: grp 0 = waves 0-3 (M_l, the chain), grp 1 = waves 4-7 (N_l); group lane group gog owns channels 4gog .. 4gog + 3
+    const int grp = tid >> 8, gtid = tid & (GT - 1);
+    const int chc = 4 * (gtid >> 3) + (ks >> 1);                // the channel whose (tanh, sigmoid) rows end up in this lane
+    const bool gwriter = (ks & 1) == 0;
     const int l = sidx;
     const bool first_stage = sidx == 0, last_stage = sidx == p.S - 1;
     const int S1 = p.S + 1;
+    WNV_TS_DECL;
 
     // ---- resident weights (registers), pairs along K (every FMA on or near the chain is a v_pk_fma_f32):
-    //      wm / wn rows = {tanh c0, sigmoid c0, tanh c1, sigmoid c1} of M_l and N_l, wo rows = {c0, c1} of conv1x1_out;
+    //      wmn = the eight rows of M_l (waves 0-3) or N_l (waves 4-7) this lane contracts, wo rows = {c0, c1} of conv1x1_out;
     //      conv1x1_skip (nobody waits for it) is read from an LDS image ----------------------------------------------
-    f2 wm[4][8], wn[4][8], wo[2][8];
+    f2 wmn[8][8], wo[2][8];
 #pragma unroll
-    for (int row = 0; row < 4; ++row) {
-        load_image8(p.w2img + ((size_t)l * 4 + row) * 4 * RT * 4, tid, wm[row]);
-        load_image8(p.wnimg + ((size_t)l * 4 + row) * 4 * RT * 4, tid, wn[row]);      // zeros at stage 0
-    }
+    for (int slot = 0; slot < 8; ++slot)       // N_l is all zeros at stage 0
+        load_image8g((grp == 0 ? p.w2img : p.wnimg) + ((size_t)l * 8 + slot) * 4 * GT * 4, gtid, wmn[slot]);
     const float4* wsk_g = reinterpret_cast<const float4*>(p.wsimg) + (size_t)l * NK * 8 * RT;    // this layer's conv1x1_skip image
 #pragma unroll
     for (int row = 0; row < 2; ++row) {
-        if (NK > NLDS && last_stage)     // K = 512: the last layer's conv1x1_out is never used; its registers hold skip pass NLDS
-            load_image8(reinterpret_cast<const float*>(wsk_g + ((size_t)NLDS * 2 + row) * 4 * RT), tid, wo[row]);
+        // the last layer's conv1x1_out is never used (wavenet.py:310-313): its registers hold a skip pass there -- the first one that
+        // does not fit LDS (K = 512), else pass 0: the last stage's skip term is the head's input, and a pass read from the LDS
+        // image is LDS-bandwidth-bound (64 KiB per pass: ~0.2 us)
+        if (last_stage)
+            load_image8(reinterpret_cast<const float*>(wsk_g + ((size_t)(NK > NLDS ? NLDS : 0) * 2 + row) * 4 * RT), tid, wo[row]);
         else
             load_image8(p.woimg + ((size_t)l * 2 + row) * 4 * RT * 4, tid, wo[row]);
     }
@@ -705,8 +794,9 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     if (tid == 0) s.flags[0] = 0;
     // readers of what this stage sends: the next stage (X, H) and the one behind it (H); the head behind the last stage
     // (every head part reads the skip sum)
+    // (the stage before the last: the last stage and, for the skip sum it completes, every head part -- consecutive positions)
     const int rd1 = ring + (sidx + 1) * p.rstride, rd2 = ring + (sidx + 2 <= p.S ? sidx + 2 : sidx + 1) * p.rstride;
-    const bool fast = same_xcd_as(p, rd1, last_stage ? p.NH : 1, rd2, s.flags + 1);
+    const bool fast = same_xcd_as(p, rd1, last_stage ? p.NH : sidx == p.S - 2 ? 1 + p.NH : 1, rd2, s.flags + 1);
 
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
@@ -716,174 +806,158 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             if (b >= p.B) continue;
             // every mailbox address of this step, pinned in registers before the first wait
             const u64* x_in = p.xmail + ((size_t)b * S1 + sidx) * RC + 2 * lane;      // wave 0: two granules per lane
-            u64* x_out = p.xmail + ((size_t)b * S1 + sidx + 1) * RC + ch;
-            const u64* h_in = p.hmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + ch;
-            u64* h_out = p.hmail + (((size_t)b * 2 + par) * S1 + sidx + 1) * RC + ch;
+            u64* x_out = p.xmail + ((size_t)b * S1 + sidx + 1) * RC + chc;            // chain waves
+            u64* q_out = p.hmail + (((size_t)b * 2 + par) * S1 + sidx + 1) * RC + ch;    // conv1x1_out(u_l) + b_o,l, for stage l + 2
             const u64* sm_in = p.smail + ((size_t)b * S1 + sidx) * p.Kp + ch;
             u64* sm_out = p.smail + ((size_t)b * S1 + sidx + 1) * p.Kp + ch;
-            asm volatile("" : "+v"(x_in), "+v"(h_in), "+v"(h_out), "+v"(sm_in), "+v"(sm_out));
-            // ---- ahead of the chain: zin = N_l h_{l-1}[t] + pre_l[t]  (h_{l-1} arrives a layer time before u_{l-1}; pre_l[t]
-            //      comes from the layer's tap workgroup and has been on its way since the previous step) ----------------
-            //      ONE wave waits for it, at a relaxed cadence: the stage is idle here for most of a step, and hundreds of
+            asm volatile("" : "+v"(x_in), "+v"(x_out), "+v"(q_out), "+v"(sm_in), "+v"(sm_out));
+            // ---- ahead of the chain: zin = N_l h_{l-1}[t] + pre_l[t]  (pre_l[t] comes from the layer's tap workgroup and has been on
+            //      its way since the previous step).  THE h RECURRENCE IS CARRIED BY THE POLLERS (round 3): stage l - 2 publishes only
+            //      q = conv1x1_out(u_{l-2}) + b_o -- right after its gate, without waiting for its own layer input -- and this
+            //      stage's wave 0 forms  h_{l-1} = sqrt(.5) (q + h_{l-2})  (modules.py:157-162, the reference's own arithmetic) from
+            //      q and the h_{l-2} stage l - 1 handed on when IT formed its input, hands h_{l-1} on to stage l + 1, and files it for
+            //      layer l - 1's tap workgroup at the end of the step.  (Before, stage l - 2 waited for h_{l-2} to arrive, added and
+            //      sent h_{l-1}: ~0.13 us of every stage's wait sat on the loop  u_l -> h_{l+1} -> N_{l+2} h_{l+1} -> u_{l+2}, which --
+            //      not the chain of the u's -- was what bounded the step: profiles/r03_ring_e1_fine_timeline.txt.)
+            //      ONE wave waits, pre at a relaxed cadence: the stage is idle here for most of a step, and hundreds of
             //      waves polling write-through lines would load the fabric that the chain's hops share.
-            float zin_a = 0.f, zin_g = 0.f;
+            float hv0 = 0.f, hv1 = 0.f;                                         // wave 0: h_{l-1}[t], channels 2 lane, 2 lane + 1
+            bool hand_on = false;
+            auto recv128 = [&](const u64* g2, unsigned code, float& v0, float& v1) {
+                if constexpr (RP) return rpoll_recv2<false>(g2, tag, v0, v1, p.status, code, lane);
+                else return wave_recv2(g2, tag, v0, v1, p.status, code, lane, false, u4v{0, 0, 0, 0});
+            };
             if (wave == 0) {
                 const float* rec = p.pmail + ((size_t)b * p.L + l) * (4 + GC);
                 if (!bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
                 *reinterpret_cast<float4*>(s.pre + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
-            }
-            __syncthreads();
-            zin_a = s.pre[ch]; zin_g = s.pre[RC + ch];
-            if (!first_stage) {
-                if (wave == 0) {
-                    // h_0 is the chain input of stage 0; h_{l-1} for l >= 2 comes from stage l-2's conv1x1_out
-                    const u64* hb_in = sidx == 1 ? p.xmail + ((size_t)b * S1) * RC + 2 * lane
-                                                 : p.hmail + (((size_t)b * 2 + par) * S1 + sidx - 1) * RC + 2 * lane;
-                    float v0 = 0.f, v1 = 0.f;
-                    if (!wave_recv2(hb_in, tag, v0, v1, p.status, 0x400u + (unsigned)sidx, lane, false, u4v{0, 0, 0, 0})) s.flags[0] = 1;
-                    *reinterpret_cast<float2*>(s.hb + eidx(2 * lane)) = make_float2(v0, v1);
-                    if constexpr (RP) rpoll16_issue<0>(x_in);         // the chain input may be there already: fetch it under the N mat-vec
+                if (!first_stage) {
+                    bool ok;
+                    if (sidx == 1) {                                            // h_0 is the chain input of stage 0 (from the head)
+                        ok = recv128(p.xmail + ((size_t)b * S1) * RC + 2 * lane, 0x400u + (unsigned)sidx, hv0, hv1);
+                    } else {
+                        const size_t slot = (((size_t)b * 2 + par) * S1 + sidx - 1) * RC + 2 * lane;
+                        float g0 = 0.f, g1 = 0.f, q0 = 0.f, q1 = 0.f;
+                        ok = recv128(p.gmail + slot, 0x480u + (unsigned)sidx, g0, g1) &&          // h_{l-2}: there long before q
+                             recv128(p.hmail + slot, 0x400u + (unsigned)sidx, q0, q1);
+                        hv0 = (q0 + g0) * 0.70710678118654752440f;
+                        hv1 = (q1 + g1) * 0.70710678118654752440f;
+                    }
+                    if (!ok) s.flags[0] = 1;
+                    WNV_TS(5);
+                    *reinterpret_cast<float2*>(s.hb + eidx(2 * lane)) = make_float2(hv0, hv1);
+                    hand_on = !last_stage && ok;
                 }
-                __syncthreads();
-                float x[16];
-                lds_read16(s.hb + ES * ks, x);
-                f2 acc[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-#pragma unroll
-                    for (int row = 0; row < 4; ++row)
-                        acc[row] = __builtin_elementwise_fma(wn[row][k], f2{x[2 * k], x[2 * k + 1]}, acc[row]);
-                float a0 = acc[0].x + acc[0].y, g0 = acc[1].x + acc[1].y, a1 = acc[2].x + acc[2].y, g1 = acc[3].x + acc[3].y;
-                if (wave == 0) {                    // a second poll for the chain input, one reduction ahead of its use: the
-                    asm volatile("" : "+v"(a0), "+v"(g0), "+v"(a1), "+v"(g1));      // vector tends to land during this mat-vec
-                    if constexpr (RP) rpoll16_issue<1>(x_in);
-                }
-                zin_a += quad_allreduce((hi ? a1 : a0) + dpp_mov<0x141>(hi ? a0 : a1));
-                zin_g += quad_allreduce((hi ? g1 : g0) + dpp_mov<0x141>(hi ? g0 : g1));
             }
-            asm volatile("" : "+v"(x_out), "+v"(zin_a), "+v"(zin_g));
-#ifdef WNV_FINE_TRACE
-            stamp(p, b, t, sidx, 6);
-#endif
-            // ---- the chain: receive X[l][t]  ->  M_l X + zin  ->  gate  ->  send u_l --------------------------------
-            if (wave == 0) {
-                float v0 = 0.f, v1 = 0.f;           // two early polls have been outstanding since before / during the N mat-vec
+            __syncthreads();                                                    // pre_l and h_{l-1} in LDS
+            if (wave == 0 && hand_on)                                           // (behind the barrier: the N waves start first)
+                st_granule2(p.gmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + 2 * lane, tag, hv0, hv1, fast);
+            if (grp == 1) {                                                     // the N waves; the chain waves go on to the chain input
+                WNV_TS(12);
+                __builtin_amdgcn_s_setprio(3);                                  // wave 4 shares its SIMD with the polling wave 0
+                float a, g;
+                if (!first_stage) group_matvec8(wmn, s.hb + ES * ks, s.pre + chc, s.pre + RC + chc, a, g);
+                else { a = s.pre[chc]; g = s.pre[RC + chc]; }
+                if (gwriter) *reinterpret_cast<float2*>(s.zin + 2 * chc) = make_float2(a, g);
+                __builtin_amdgcn_s_setprio(0);
+                WNV_TS(6);                                                      // zin ready
+            } else if (wave == 0) {
+                // ---- the chain: receive X[l][t]  ->  M_l X + zin  ->  gate  ->  send u_l --------------------------------
+                float v0 = 0.f, v1 = 0.f;
                 bool got;
-                if constexpr (RP)
-                    got = first_stage ? rpoll_recv2<false>(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane)
-                                      : rpoll_recv2<true>(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane);
-                else
-                    got = wave_recv2(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane, false, u4v{0, 0, 0, 0});
+                if constexpr (RP) got = rpoll_recv2<false>(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane);
+                else got = wave_recv2(x_in, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane, false, u4v{0, 0, 0, 0});
                 if (!got) s.flags[0] = 1;
-#ifdef WNV_FINE_TRACE
-                stamp(p, b, t, sidx, 8);            // the poll that carried every tag has returned
-#endif
+                WNV_TS(8);                                                      // the poll that carried every tag has returned
                 *reinterpret_cast<float2*>(s.hx + eidx(2 * lane)) = make_float2(v0, v1);
             }
-            __syncthreads();
-            stamp(p, b, t, sidx, 0);
-            {
-                float x[16];
-                lds_read16(s.hx + ES * ks, x);
-                f2 acc[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
-#pragma unroll
-                for (int k = 0; k < 8; ++k)
-#pragma unroll
-                    for (int row = 0; row < 4; ++row)
-                        acc[row] = __builtin_elementwise_fma(wm[row][k], f2{x[2 * k], x[2 * k + 1]}, acc[row]);
-                const float a0 = acc[0].x + acc[0].y, g0 = acc[1].x + acc[1].y, a1 = acc[2].x + acc[2].y, g1 = acc[3].x + acc[3].y;
-                // reduce-scatter: lanes 0-3 collect channel c0, lanes 4-7 channel c1 (the partner is lane 7 - j)
-                const float a = quad_allreduce((hi ? a1 : a0) + dpp_mov<0x141>(hi ? a0 : a1)) + zin_a;
-                const float g = quad_allreduce((hi ? g1 : g0) + dpp_mov<0x141>(hi ? g0 : g1)) + zin_g;
+            __syncthreads();                                                    // X[l][t] and zin in LDS
+            if (grp == 1) WNV_TS(0);                                            // (noted by the waves that are idle here)
+            if (grp == 0) {
+                float a, g;
+                group_matvec8(wmn, s.hx + ES * ks, s.zin + 2 * chc, s.zin + 2 * chc + 1, a, g);
                 const float u = fast_gate(a, g);                                // modules.py:154
-#ifdef WNV_FINE_TRACE
-                stamp(p, b, t, sidx, 5);            // gate value ready (wave 0)
-#endif
-                if (writer) {
+                if (gwriter) {
                     if (!last_stage) st_granule(x_out, tag, u, fast);           // send on: nothing else is on the chain
-                    s.us[eidx(ch)] = u;
+                    s.us[eidx(chc)] = u;
                 }
-#ifdef WNV_FINE_TRACE
-                if (wave > 0) stamp(p, b, t, sidx, 8 + wave, 64 * wave);        // when each of the other waves issued its share of u
-#endif
+                WNV_TS(1);                                                      // this chain wave has issued its share of u
             }
-            stamp(p, b, t, sidx, 1);
             // ---- behind the send -----------------------------------------------------------------------------------
-            // h_l[t] (from stage l-1, normally a hop behind its u) is awaited by the very lanes that own the channel and
-            // added in registers: the h recurrence costs one hop + one add per layer.  Its first poll is issued here, under
-            // the barrier and the conv1x1_out mat-vec.
-            if constexpr (RP) { if (!first_stage && writer) rpoll8_issue<0>(h_in); }
             __syncthreads();                                                    // u_l complete in LDS
-            if constexpr (RP) { if (!first_stage && !last_stage && writer) rpoll8_issue<1>(h_in); }
-#ifdef WNV_FINE_TRACE
-            stamp(p, b, t, sidx, 7);
-#endif
+            if (grp == 1) WNV_TS(7);
             float xu[16];
             lds_read16(s.us + ES * ks, xu);
-            // conv1x1_out -> residual -> publish h_{l+1}[t]  (modules.py:157-162: the reference's own recurrence)
+            // conv1x1_out + bias, published for stage l + 2's poller, which adds the residual (see above)
             auto h_phase = [&]() {
-                float o = 0.f;
                 if (!last_stage) {                  // the last layer's residual output is never used (wavenet.py:310-313)
                     const float o0 = dot16p(wo[0], xu), o1 = dot16p(wo[1], xu);
-                    if constexpr (RP) { if (!first_stage && writer) rpoll8_issue<2>(h_in); }
-                    o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1)) + bo_r;
+                    const float o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1)) + bo_r;
+                    if (writer) st_granule(q_out, tag, o, fast);
                 }
-                float h = 0.f;
-                bool ok = true;
-                if (first_stage) {
-                    h = s.hx[eidx(ch)];                                          // h_0 is the chain input itself
-                } else {
-                    if constexpr (RP)
-                        ok = last_stage ? rpoll_recv<1>(h_in, writer, tag, h, p.status, 0x500u + (unsigned)sidx, lane)
-                                        : rpoll_recv<3>(h_in, writer, tag, h, p.status, 0x500u + (unsigned)sidx, lane);
-                    else
-                        ok = wave_recv<false>(h_in, writer, tag, h, p.status, 0x500u + (unsigned)sidx, lane);
-                }
-                if (writer) {
-                    if (!last_stage && ok)
-                        st_granule(h_out, tag, (o + h) * 0.70710678118654752440f, fast);
-                    s.hh[eidx(ch)] = h;                 // forwarded to the layer's tap workgroup at the end of the step
-                }
-                if (!ok) s.flags[0] = 1;
             };
-            // skip 1x1, accumulated stage to stage in the reference's layer order (wavenet.py:312)
+            // skip 1x1, accumulated stage to stage in the reference's layer order (wavenet.py:312).  The LAST stage publishes its own
+            // term alone and the head adds it to the sum through stage S - 2 (same order of additions): the accumulated sum travels
+            // as a chain of its own, one hop + one poll per stage, and runs ~0.6 us behind the u's -- the last stage used to wait
+            // for it with the whole ring idle.
             auto skip_phase = [&]() {
                 bool ok = true;
 #pragma unroll
                 for (int pp = 0; pp < NK; ++pp) {                               // skip channels 128 pp + ch
                     float m0, m1;
-                    if (pp < NLDS) {
-                        m0 = dot16l(s.wsk + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(s.wsk + (size_t)(8 * pp + 4) * RT + tid, xu);
-                    } else if (last_stage && pp == NLDS) {
+                    if (last_stage && pp == (NK > NLDS ? NLDS : 0)) {
                         m0 = dot16p(wo[0], xu); m1 = dot16p(wo[1], xu);
+                    } else if (pp < NLDS) {
+                        m0 = dot16l(s.wsk + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(s.wsk + (size_t)(8 * pp + 4) * RT + tid, xu);
                     } else {                                                    // streams from the L2 (image layout: coalesced 16-B loads)
                         m0 = dot16l(wsk_g + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(wsk_g + (size_t)(8 * pp + 4) * RT + tid, xu);
                     }
                     const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + (pp == 0 ? bs_r : s.bsk[RC * pp + ch]);
                     float acc = 0.f;
-                    if (sidx > 0 && ok)
+                    if (sidx > 0 && !last_stage && ok)
                         ok = wave_recv<false>(sm_in + RC * pp, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
                     if (writer && ok) st_granule(sm_out + RC * pp, tag, acc + mine, fast);
                 }
                 if (!ok) s.flags[0] = 1;
             };
-            // the h recurrence is what the next-but-one stage waits for; at the last stage the skip sum (the head's input) is the
-            // urgent one -- and at the stage before it too: what it adds to the skip chain is what the last stage waits for,
-            // while its h output only feeds off-chain consumers (the last stage's history push)
-            if (last_stage || sidx == p.S - 2) { skip_phase(); stamp(p, b, t, sidx, 3); h_phase(); stamp(p, b, t, sidx, 2); }
-            else { h_phase(); stamp(p, b, t, sidx, 2); skip_phase(); stamp(p, b, t, sidx, 3); }
+            // the residual increment is what the next-but-one stage waits for; at the last stage the skip term (the head's input) is
+            // the urgent one -- and at the stage before it too: the sum it completes is the other half of the head's input, while its
+            // q only feeds the last stage's history push
+            if (last_stage || sidx == p.S - 2) { skip_phase(); WNV_TS(3); h_phase(); WNV_TS(2); }
+            else { h_phase(); WNV_TS(2); skip_phase(); WNV_TS(3); }
             // ---- history push + next step's pre-activations (its barriers fence the LDS vectors for the next step) -------
             __syncthreads();                        // fences the LDS vectors against the next step; makes flags[0] uniform
             if (s.flags[0]) return;                 // a bounded wait gave up somewhere: drain (status holds the code)
-            if (wave == 0) {                        // h_l[t] to the layer's tap workgroup (history ring, older taps): bulk record
-                float* rec = p.fmail + ((size_t)b * p.L + l) * (4 + RC);
-                if (lane < RC / 4) {
-                    const float* src = s.hh + ES * (lane >> 2) + 4 * (lane & 3);     // channels 4 lane .. 4 lane + 3
-                    bulk_store16(rec + 4 + 4 * lane, *reinterpret_cast<const float4*>(src));
+            if (wave == 0) {
+                // layer inputs to their tap workgroups (history ring, older taps of the next step): bulk records.  This stage knows
+                // h_{l-1}[t] (its N input); the last stage also forms h_l[t] of its own layer, which nobody else needs
+                auto file = [&](int layer, const float* vec) {
+                    float* rec = p.fmail + ((size_t)b * p.L + layer) * (4 + RC);
+                    if (lane < RC / 4) {
+                        const float* src = vec + ES * (lane >> 2) + 4 * (lane & 3);  // channels 4 lane .. 4 lane + 3
+                        bulk_store16(rec + 4 + 4 * lane, *reinterpret_cast<const float4*>(src));
+                    }
+                    bulk_publish(reinterpret_cast<u64*>(rec), tag, lane);
+                };
+                if (!first_stage) file(l - 1, s.hb);
+                if (last_stage) {
+                    if (first_stage) {
+                        file(l, s.hx);                                          // a one-layer model: h_0 is the chain input
+                    } else {
+                        float q0 = 0.f, q1 = 0.f;
+                        if (!recv128(p.hmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + 2 * lane, 0x500u + (unsigned)sidx, q0, q1)) return;   // (status holds the code; the others drain at their next wait)
+                        *reinterpret_cast<float2*>(s.hh + eidx(2 * lane)) = make_float2((q0 + hv0) * 0.70710678118654752440f, (q1 + hv1) * 0.70710678118654752440f);
+                        file(l, s.hh);
+                    }
                 }
-                bulk_publish(reinterpret_cast<u64*>(rec), tag, lane);
             }
-            stamp(p, b, t, sidx, 4);
+            WNV_TS(4);
+            // timeline slots: 0 X and zin in LDS | 1 u sent (wave 0) | 2 q sent | 3 skip sent | 4 step done | 5 h_{l-1} formed | 6 zin ready |
+            // 7 barrier behind u | 8 chain input's poll hit | 9-11 u sent by waves 1-3
+            if (wave == 0) WNV_TS_FLUSH(b, t, sidx, 0x013Eu, 0);
+            else if (wave < 4) WNV_TS_FLUSH(b, t, sidx, 0x002u, 7 + wave);
+            else if (wave == 4) { WNV_TS_FLUSH(b, t, sidx, 0x10C1u, 0); WNV_TS_FLUSH(b, t, sidx, 0x000Cu, 16); }   // 12: N waves released; 18, 19: slots 2, 3 as wave 4 saw them
+            else if (wave == 5) WNV_TS_FLUSH(b, t, sidx, 0x0040u, 7);          // 13: zin ready as wave 5 saw it
         }
     }
 }
@@ -929,15 +1003,22 @@ template <int NK, int NW2> struct HeadSlice {
     }
 };
 
-// skip sum of (b, t) -> s.vs (all parts);  returns false on abort
+// skip sum of (b, t) -> s.vs (all parts): the sum through stage S - 2 (slot S - 1) + the last stage's own term (slot S), the
+// reference's order of additions (wavenet.py:312);  returns false on abort
 template <int NK>
 __device__ __forceinline__ bool head_recv_skip(const RingParams& p, int b, unsigned tag, float* vs, int tid, int lane, int wave) {
     bool ok = true;
     if (wave < 2 * NK) {
-        float v = 0.f;
-        if constexpr (NK <= 2) ok = rpoll_recv<0>(p.smail + ((size_t)b * (p.S + 1) + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane);
-        else ok = wave_recv<false>(p.smail + ((size_t)b * (p.S + 1) + p.S) * p.Kp + tid, true, tag, v, p.status, 0x300u, lane);
-        vs[qidx(tid)] = fmaxf(v * p.skip_scale, 0.f);                           // wavenet.py:313-316
+        const u64* own = p.smail + ((size_t)b * (p.S + 1) + p.S) * p.Kp + tid;
+        float acc = 0.f, v = 0.f;
+        if constexpr (NK <= 2) {
+            if (p.S > 1) ok = rpoll_recv<0>(own - p.Kp, true, tag, acc, p.status, 0x300u, lane);
+            ok = ok && rpoll_recv<0>(own, true, tag, v, p.status, 0x300u, lane);
+        } else {
+            if (p.S > 1) ok = wave_recv<false>(own - p.Kp, true, tag, acc, p.status, 0x300u, lane);
+            ok = ok && wave_recv<false>(own, true, tag, v, p.status, 0x300u, lane);
+        }
+        vs[qidx(tid)] = fmaxf((acc + v) * p.skip_scale, 0.f);                   // wavenet.py:313-316
     }
     return ok;
 }
@@ -1000,6 +1081,7 @@ __device__ __forceinline__ bool head_collect(const RingParams& p, int b, unsigne
 
 template <int NK>
 __device__ void run_head(const RingParams& p, int ring, float* smem) {
+    WNV_TS_DECL;
     const HeadLds s = carve_head(smem, NK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, i = wave * 16 + (lane >> 2);
@@ -1024,7 +1106,6 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
         if (b >= p.B || tid >= RC) continue;
         const float xs = p.Tt > 0 ? p.teacher[(size_t)b * p.Tt] : (p.initial ? p.initial[b] : 0.f);
         st_granule(p.xmail + ((size_t)b * S1) * RC + tid, p.tag_base + 1u, fmaf(wf, xs, bf), fast);
-        stamp(p, b, 0, p.S, 0);
     }
 
     for (int t = 0; t < p.T; ++t) {
@@ -1043,9 +1124,10 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             // ---- wait for the accumulated skip vector of (b, t) -----------------------------------------------
             if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.flags[0] = 1;
             __syncthreads();
-            stamp(p, b, t, p.S, 1);
+            WNV_TS(1);
             head_hidden<NK, 1>(w, s.vs, s.hid, q, i);
             __syncthreads();
+            WNV_TS(3);
             float x[32];
             lds_read32(s.hid + QS * q, x);
             float o = quad_allreduce(dot32p(w.wh2[0], x));                        // wavenet.py:319
@@ -1057,6 +1139,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
                 if (p.params_out) p.params_out[((size_t)b * p.O + i) * p.T + t] = o;
             }
             __syncthreads();
+            WNV_TS(4);
             // ---- sample, redundantly in every lane of waves 0-1 (no cross-lane traffic), then first_conv of step t+1 ----
             if (wave < 2) {
                 int bi = 0;
@@ -1076,11 +1159,12 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
                 if (t + 1 < p.T) {
                     const float xs = t + 1 < p.Tt ? forced : xo;                   // wavenet.py:297-305
                     st_granule(p.xmail + ((size_t)b * S1) * RC + tid, tag + 1u, fmaf(wf, xs, bf), fast);
-                    stamp(p, b, t + 1, p.S, 0);
+                    WNV_TS(0);
                 }
                 if (tid == 0) p.out[(size_t)b * p.T + t] = xo;
             }
-            stamp(p, b, t, p.S, 2);
+            WNV_TS(2);
+            if (wave == 0) { WNV_TS_FLUSH(b, t, p.S, 0x1Eu, 0); WNV_TS_FLUSH(b, t + 1, p.S, 0x1u, 0); }   // 0 input of step t+1 sent | 1 skip sum in LDS | 2 step done | 3 hidden layer in LDS | 4 head outputs in LDS
             if (s.flags[0]) return;                 // uniform: written before the barriers above
         }
     }
@@ -1104,6 +1188,7 @@ __host__ __device__ constexpr size_t cat_lds_floats(int NK) { return (size_t)(4 
 
 template <int NK>
 __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
+    WNV_TS_DECL;
     const CatLds s = carve_cat(smem, NK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, i = wave * 16 + (lane >> 2);
@@ -1144,7 +1229,6 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
         if (b >= p.B) continue;
         const float* dense = p.Tt > 0 ? p.teacher + (size_t)b * p.Tt * O : (p.initial ? p.initial + (size_t)b * O : nullptr);
         send_input(b, dense, 127, p.tag_base + 1u);
-        stamp(p, b, 0, p.S, 0);
     }
 
     for (int t = 0; t < p.T; ++t) {
@@ -1156,7 +1240,7 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
             if (tid < O) s.nzb[tid] = head_noise(p, t, b, tid, 2);
             if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.ints[0] = 1;
             __syncthreads();
-            stamp(p, b, t, p.S, 1);
+            WNV_TS(1);
             head_hidden<NK, 2>(w, s.vs, s.hid, q, i);
             __syncthreads();
             float x[32];
@@ -1191,9 +1275,10 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
                 if (t + 1 < p.Tt) dense = p.teacher + ((size_t)b * p.Tt + t + 1) * O;
                 else if (!p.quantize) dense = s.obuf;                               // fed-back probabilities
                 send_input(b, dense, s.ints[1], tag + 1u);
-                stamp(p, b, t + 1, p.S, 0);
+                WNV_TS(0);
             }
-            stamp(p, b, t, p.S, 2);
+            WNV_TS(2);
+            if (wave == 0) { WNV_TS_FLUSH(b, t, p.S, 0x6u, 0); WNV_TS_FLUSH(b, t + 1, p.S, 0x1u, 0); }   // 0 input of step t+1 sent | 1 skip sum in LDS | 2 step done
             if (s.ints[0]) return;
         }
     }
@@ -1341,6 +1426,20 @@ static void put_row8(std::vector<float>& blob, size_t off, const float* M, int r
     }
 }
 
+// wave-group row image (see group_matvec8): group thread gtid (K-slice ks = gtid & 7, lane group og = gtid >> 3) holds in register
+// slot `slot` the K-slice [16ks, 16ks + 16) of row (slot & 1 ? 128 : 0) + 4og + j, j = the lane-dependent channel of slot pair
+// slot >> 1; laid out [chunk 4][256 threads][4]
+static void put_row8g(std::vector<float>& blob, size_t off, const float* M, int slot) {
+    for (int gtid = 0; gtid < GT; ++gtid) {
+        const int ks = gtid & 7, og = gtid >> 3, b2 = ks >> 2, b1 = (ks >> 1) & 1;
+        const int sp = slot >> 1;
+        const int j = sp == 0 ? 2 * b2 + b1 : sp == 1 ? 2 * b2 + (1 - b1) : sp == 2 ? 2 * (1 - b2) + (1 - b1) : 2 * (1 - b2) + b1;
+        const float* src = M + (size_t)(((slot & 1) ? RC : 0) + 4 * og + j) * RC + 16 * ks;
+        for (int c = 0; c < 4; ++c)
+            for (int e = 0; e < 4; ++e) blob[off + ((size_t)c * GT + gtid) * 4 + e] = src[4 * c + e];
+    }
+}
+
 wnv_status wnv_placement_census(int device, int* ncu_out, int* n_xcd_out, bool* map_ok_out, std::string& err) {
     int ncu = 0;
     RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -1433,9 +1532,9 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
             }
         }
         const size_t rowsz = (size_t)4 * RT * 4;                   // one row image: 4 chunks x 512 threads x 4 floats
-        for (int row = 0; row < 4; ++row) {                        // rows: tanh c0, sigmoid c0, tanh c1, sigmoid c1  (c0 = 2og, c1 = 2og + 1)
-            put_row8(blob, st->o_w2 + ((size_t)l * 4 + row) * rowsz, mmat.data(), (row & 1) ? RC : 0, row >> 1);
-            if (l > 0) put_row8(blob, st->o_wn + ((size_t)l * 4 + row) * rowsz, nmat.data(), (row & 1) ? RC : 0, row >> 1);
+        for (int slot = 0; slot < 8; ++slot) {                     // M_l / N_l: eight register slots of the wave-group mapping
+            put_row8g(blob, st->o_w2 + ((size_t)l * 8 + slot) * (rowsz / 2), mmat.data(), slot);
+            if (l > 0) put_row8g(blob, st->o_wn + ((size_t)l * 8 + slot) * (rowsz / 2), nmat.data(), slot);
         }
         const std::vector<float> wo = padded(T(pfx + "conv1x1_out.weight").data.data(), Ra, Gha, RC, RC);          // (R, G/2, 1)
         put_row8(blob, st->o_wo + ((size_t)l * 2 + 0) * rowsz, wo.data(), 0, 0);
@@ -1587,13 +1686,13 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride;
     p.zb_ld = (c.gate_channels + 3) & ~3; p.gh = c.gate_channels / 2;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
-    // state: [status 64 B][placement table 4 KiB][xmail B*(S+1)*128 u64][hmail B*2*(S+1)*128 u64][smail B*(S+1)*Kp u64][omail B*NK*256 u64]
+    // state: [status 64 B][placement table 4 KiB][xmail B*(S+1)*128 u64][hmail B*2*(S+1)*128 u64][gmail, the same][smail B*(S+1)*Kp u64][omail B*NK*256 u64]
     //        [hist B*hist_floats f32]
     const size_t head_bytes = 64 + 4096;                           // status word, placement table
     const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
     const size_t n_f = (size_t)B * st->L * (4 + RC), n_p = (size_t)B * st->L * (4 + GC);   // stage <-> tap-workgroup bulk records (floats)
     const size_t n_o = (size_t)B * NK * p.Op;                      // partial head outputs of parts 1 .. NK-1
-    const size_t mail_bytes = (3 * n_h + n_s + n_o) * sizeof(u64) + (n_f + n_p) * sizeof(float);
+    const size_t mail_bytes = (5 * n_h + n_s + n_o) * sizeof(u64) + (n_f + n_p) * sizeof(float);
     const size_t hist_bytes = (size_t)B * st->hist_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -1621,7 +1720,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.xcc = (unsigned int*)(base + 64);
     p.xmail = (u64*)(base + head_bytes);
     p.hmail = p.xmail + n_h;
-    p.smail = p.hmail + 2 * n_h;
+    p.gmail = p.hmail + 2 * n_h;
+    p.smail = p.gmail + 2 * n_h;
     p.omail = p.smail + n_s;
     p.fmail = (float*)(p.omail + n_o);
     p.pmail = p.fmail + n_f;
@@ -1663,6 +1763,14 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     unsigned long long* d_trace = nullptr;
     const int trace_n = 8;
     size_t trace_words = 0;
+#ifndef WNV_FINE_TRACE
+    if (trace_path && *trace_path) {
+        static bool told = false;
+        if (!told) fprintf(stderr, "[wnv] WNV_RING_TRACE needs a trace build of the library (python -m wavenet_vocoder_amd.build --out <lib> --flags -DWNV_FINE_TRACE, then WNV_LIB=<lib>); ignored\n");
+        told = true;
+        trace_path = nullptr;
+    }
+#endif
     if (trace_path && *trace_path && p.T > 64) {
         trace_words = (size_t)trace_n * upr * (st->S + 1) * TRW + (size_t)trace_n * TRW;
         RING_HIP(hipMalloc((void**)&d_trace, trace_words * sizeof(unsigned long long)));
