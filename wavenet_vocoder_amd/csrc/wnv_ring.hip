@@ -1140,10 +1140,30 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             }
             __syncthreads();
             WNV_TS(4);
-            // ---- sample, redundantly in every lane of waves 0-1 (no cross-lane traffic), then first_conv of step t+1 ----
+            // ---- sample in waves 0-1 (each on its own), then first_conv of step t+1.  Up to 16 mixture components: lane c evaluates
+            //      component c -- its three LDS reads are independent, ONE round trip --, the Gumbel-max is a 16-lane DPP butterfly
+            //      + ballot (first index wins ties) and the winner's sample comes back through v_readlane.  (Round 2 walked the keys
+            //      in a loop of dependent LDS reads and then fetched mean / log-scale: ~0.49 us from barrier to send.) ----
             if (wave < 2) {
-                int bi = 0;
-                if (nmix > 0) {                                                     // Gumbel-max, first index wins ties
+                float xo;
+                if (nmix <= 16) {
+                    float key = -INFINITY, mean = 0.f, ls = 0.f;
+                    if (nmix == 0) { mean = s.obuf[o_mean]; ls = s.obuf[o_ls]; }   // mixture.py:258-261
+                    else if (lane < nmix) { key = s.vbuf[lane]; mean = s.obuf[o_mean + lane]; ls = s.obuf[o_ls + lane]; }   // mixture.py:143-146
+                    float xc = p.dist == 1 ? mean + __expf(ls) * lr : lr * __expf(ls) + mean;
+                    xc = fminf(fmaxf(xc, -1.0f), 1.0f);                           // mixture.py:154 / :269
+                    if (nmix > 0) {                                                 // Gumbel-max (mixture.py:138-140), first index wins ties
+                        float m = key;
+                        m = fmaxf(m, dpp_mov<0xB1>(m)); m = fmaxf(m, dpp_mov<0x4E>(m));
+                        m = fmaxf(m, dpp_mov<0x141>(m)); m = fmaxf(m, dpp_mov<0x140>(m));      // row_half_mirror, row_mirror: lanes 0-15
+                        const unsigned long long win = __ballot(lane < nmix && key == m);
+                        const int wl = win ? __ffsll((long long)win) - 1 : 0;
+                        xo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), wl));
+                    } else {
+                        xo = xc;
+                    }
+                } else {
+                    int bi = 0;
                     float best = -INFINITY;
                     for (int c = 0; c < nchunk; ++c) {
                         const float4 v = reinterpret_cast<const float4*>(s.vbuf)[c];
@@ -1152,10 +1172,10 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
                         if (v.z > best) { best = v.z; bi = 4 * c + 2; }
                         if (v.w > best) { best = v.w; bi = 4 * c + 3; }
                     }
+                    const float mean = s.obuf[o_mean + bi], ls = s.obuf[o_ls + bi];
+                    xo = p.dist == 1 ? mean + expf(ls) * lr : lr * expf(ls) + mean;
+                    xo = fminf(fmaxf(xo, -1.0f), 1.0f);
                 }
-                const float mean = s.obuf[o_mean + bi], ls = s.obuf[o_ls + bi];   // mixture.py:143-146 / :258-261
-                float xo = p.dist == 1 ? mean + expf(ls) * lr : lr * expf(ls) + mean;
-                xo = fminf(fmaxf(xo, -1.0f), 1.0f);                               // mixture.py:154 / :269
                 if (t + 1 < p.T) {
                     const float xs = t + 1 < p.Tt ? forced : xo;                   // wavenet.py:297-305
                     st_granule(p.xmail + ((size_t)b * S1) * RC + tid, tag + 1u, fmaf(wf, xs, bf), fast);
