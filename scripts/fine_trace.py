@@ -20,8 +20,11 @@ for t in steps[1:-1]:
         raw = get(t, pos)
         v = [x - base if x >= 0 else None for x in raw]
         sends = [x for x in [v[1], v[9], v[10], v[11]] if x is not None]
-        st[pos] = dict(v=v, first=min(sends), last=max(sends))
+        if sends:                                   # (position 0 is empty when the head evaluates layer 0)
+            st[pos] = dict(v=v, first=min(sends), last=max(sends))
     for pos in range(2, S):
+        if pos - 2 not in st:
+            continue
         c, pr, pp = st[pos], st[pos - 1], st[pos - 2]
         v = c["v"]
         d = dict(transport=v[8] - pr["last"], zin_ahead_of_hit=v[8] - v[6], lds_barrier=v[0] - max(v[8], v[6]), chain_phase=c["first"] - v[0],
@@ -44,7 +47,8 @@ for t in steps[1:-1]:
     if nxt and hd[3] >= 0 and hd[4] >= 0:
         for k, x in dict(head_hidden=hd[3] - hd[1], head_out=hd[4] - hd[3], head_sample_send=nxt[0] - hd[4]).items():
             acc.setdefault(k, []).append(x)
-    e = dict(head_skip_hop=hd[1] - base - last["v"][3], head_mlp_sample=(nxt[0] - hd[1]) if nxt else None, first_hop=st[0]["v"][8], step=(nxt[0] - hd[0]) if nxt else None)
+    first = st[min(st)]
+    e = dict(head_skip_hop=hd[1] - base - last["v"][3], head_mlp_sample=(nxt[0] - hd[1]) if nxt else None, first_hop=first["v"][8], step=(nxt[0] - hd[0]) if nxt else None)
     for k, x in e.items():
         if x is not None:
             acc.setdefault(k, []).append(x)

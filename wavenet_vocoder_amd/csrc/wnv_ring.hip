@@ -69,12 +69,15 @@ struct RingParams {
     const float *w2img, *wnimg, *woimg, *wsimg, *bo, *wpre, *bskip, *cvec;
     const float *wh1img, *bh1, *wh2img, *bh2, *wfirst, *bfirst;   // one-hot models: wh2img holds two row images (rows i, 128 + i), wfirst is K-major [cin1][128]
     int cin1, softmax, quantize;       // first_conv input channels (1 = scalar input); categorical head switches (wavenet.py:332-335)
+    int head_l0;                       // the head evaluates layer 0 itself (scalar-input models, K = 128): position 0 of a ring stays empty
+    const float* l0vec;                // [4][256]: W_cur,0 w_first, W_cur,0 b_first (layer 0's pre-activation is affine in the sample); N_1 w_first, N_1 b_first (so is N_1 h_0)
     int* index_out;
     const float* zbias;                // effective conv bias of the generic pack: [B or 1][L][zb_ld], rows = the model's own G gate rows
     long long zbias_bstride;
     int zb_ld, gh;                     // its row stride (G padded to 4) and the model's G / 2: padded output n -> row (n >> 7) * gh + (n & 127)
     const int *lay_dil, *lay_histoff;
     unsigned long long *xmail, *hmail, *smail;   // chain inputs X[b][S+1][128]; residual increments Q[b][2 (t parity)][S+1][128] (slot l+1 = conv1x1_out(u_l) + b_o,l); skip sums
+    unsigned long long *zmail;                   // head_l0: Z[b][256] = N_1 h_0[t] (affine in the sample: made by the head), read by stage 1
     unsigned long long *gmail;                   // layer inputs handed on: G[b][2 (t parity)][S+1][128], slot j = h_{j-1}[t] as stage j formed it (read by stage j + 1)
     unsigned long long *omail;                   // head parts j > 0 -> part 0: partial head outputs O[b][NH][Op]
     float *fmail, *pmail;                        // bulk records: stage -> tap workgroup h_l[t]: F[b][L][4 + 128]; tap workgroup -> stage pre_l[t+1]: P[b][L][4 + 256]
@@ -302,6 +305,25 @@ __device__ __forceinline__ bool rpoll_recv(const u64* g, bool active, unsigned t
         }
     }
 #undef WNV_RPOLL8
+}
+
+// ONE wave receives three 2-granule groups at once (stage 1 behind a head that evaluates layer 0: four rows of N_1 h_0 and two
+// values of u_0 per lane): the three loads travel together, one L2 round trip per attempt instead of three polls in a row.
+__device__ __forceinline__ bool rpoll_recv3(const u64* ga, const u64* gb, const u64* gc, unsigned tag, float (&v)[6], unsigned int* status, unsigned code, int lane) {
+    unsigned spins = 0;
+    for (;;) {
+        rpoll16_issue<0>(ga); rpoll16_issue<1>(gb); rpoll16_issue<2>(gc);
+        const u4v a = rpoll16_take<0, 2>(), b = rpoll16_take<1, 1>(), c = rpoll16_take<2, 0>();
+        if (__all(a.y == tag && a.w == tag && b.y == tag && b.w == tag && c.y == tag && c.w == tag)) {
+            v[0] = __uint_as_float(a.x); v[1] = __uint_as_float(a.z); v[2] = __uint_as_float(b.x); v[3] = __uint_as_float(b.z);
+            v[4] = __uint_as_float(c.x); v[5] = __uint_as_float(c.z);
+            return true;
+        }
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+    }
 }
 
 // Placement handshake: publish this workgroup's XCC id, read those of the (up to two) workgroups that read what this one
@@ -750,7 +772,9 @@ __device__ __forceinline__ void group_matvec8(const f2 (&w)[8][8], const float* 
 // Thread mapping of the work behind the send (all eight waves): eight adjacent lanes split the K = 128 contraction (16 floats
 // each), a group of eight lanes owns channels 2og and 2og + 1; reductions are reduce-scatters (first DPP step row_half_mirror,
 // lane j <-> 7 - j, hands lanes 0-3 the sums of channel 2og and lanes 4-7 those of 2og + 1; two quad_perm steps finish).
-template <int NK>
+// (L0: the ring's head evaluates layer 0 -- run_head; ZMSG: this instantiation is stage 1 of such a ring.  Compile-time switches:
+//  the stage loop is codegen-sensitive, a run-time flag in it costs every stage 3 %.)
+template <int NK, bool L0, bool ZMSG>
 __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
     constexpr int NLDS = lds_passes(NK);
     constexpr bool RP = NK <= 2;                // pipelined polls in the reserved registers (the K = 512 instantiation needs them itself)
@@ -823,6 +847,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             //      waves polling write-through lines would load the fabric that the chain's hops share.
             float hv0 = 0.f, hv1 = 0.f;                                         // wave 0: h_{l-1}[t], channels 2 lane, 2 lane + 1
             bool hand_on = false;
+            constexpr bool zmsg = ZMSG;                                         // N_1 h_0 comes ready-made from the head (run_head)
             auto recv128 = [&](const u64* g2, unsigned code, float& v0, float& v1) {
                 if constexpr (RP) return rpoll_recv2<false>(g2, tag, v0, v1, p.status, code, lane);
                 else return wave_recv2(g2, tag, v0, v1, p.status, code, lane, false, u4v{0, 0, 0, 0});
@@ -830,15 +855,29 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             if (wave == 0) {
                 const float* rec = p.pmail + ((size_t)b * p.L + l) * (4 + GC);
                 if (!bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
-                *reinterpret_cast<float4*>(s.pre + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
-                if (!first_stage) {
+                const float4 pv = bulk_load16(rec + 4 + 4 * lane);
+                *reinterpret_cast<float4*>(s.pre + 4 * lane) = pv;
+                if constexpr (zmsg) {                                           // rows 4 lane .. 4 lane + 3 of N_1 h_0, plus pre_1: zin is complete;
+                    if constexpr (RP) {                                         // the chain input u_0 comes with it
+                        float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                        if (!rpoll_recv3(p.zmail + (size_t)b * GC + 4 * lane, p.zmail + (size_t)b * GC + 4 * lane + 2, x_in, tag, v, p.status,
+                                         0x100u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                        WNV_TS(5); WNV_TS(8);
+                        const int r = 4 * lane, half = r >> 7, c0 = r & (RC - 1);  // row r = half * 128 + channel; zin is [channel][half]
+                        s.zin[2 * c0 + half] = v[0] + pv.x; s.zin[2 * (c0 + 1) + half] = v[1] + pv.y;
+                        s.zin[2 * (c0 + 2) + half] = v[2] + pv.z; s.zin[2 * (c0 + 3) + half] = v[3] + pv.w;
+                        *reinterpret_cast<float2*>(s.hx + eidx(2 * lane)) = make_float2(v[4], v[5]);
+                    }
+                } else if (!first_stage) {
                     bool ok;
                     if (sidx == 1) {                                            // h_0 is the chain input of stage 0 (from the head)
                         ok = recv128(p.xmail + ((size_t)b * S1) * RC + 2 * lane, 0x400u + (unsigned)sidx, hv0, hv1);
                     } else {
                         const size_t slot = (((size_t)b * 2 + par) * S1 + sidx - 1) * RC + 2 * lane;
                         float g0 = 0.f, g1 = 0.f, q0 = 0.f, q1 = 0.f;
-                        ok = recv128(p.gmail + slot, 0x480u + (unsigned)sidx, g0, g1) &&          // h_{l-2}: there long before q
+                        // h_{l-2}: there long before q (stage 2 of a ring whose head evaluates layer 0 takes h_0 from the head itself)
+                        const u64* gsrc = L0 && sidx == 2 ? p.xmail + ((size_t)b * S1) * RC + 2 * lane : p.gmail + slot;
+                        ok = recv128(gsrc, 0x480u + (unsigned)sidx, g0, g1) &&
                              recv128(p.hmail + slot, 0x400u + (unsigned)sidx, q0, q1);
                         hv0 = (q0 + g0) * 0.70710678118654752440f;
                         hv1 = (q1 + g1) * 0.70710678118654752440f;
@@ -852,7 +891,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             __syncthreads();                                                    // pre_l and h_{l-1} in LDS
             if (wave == 0 && hand_on)                                           // (behind the barrier: the N waves start first)
                 st_granule2(p.gmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + 2 * lane, tag, hv0, hv1, fast);
-            if (grp == 1) {                                                     // the N waves; the chain waves go on to the chain input
+            if (grp == 1 && !zmsg) {                                            // the N waves; the chain waves go on to the chain input
                 WNV_TS(12);
                 __builtin_amdgcn_s_setprio(3);                                  // wave 4 shares its SIMD with the polling wave 0
                 float a, g;
@@ -861,7 +900,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 if (gwriter) *reinterpret_cast<float2*>(s.zin + 2 * chc) = make_float2(a, g);
                 __builtin_amdgcn_s_setprio(0);
                 WNV_TS(6);                                                      // zin ready
-            } else if (wave == 0) {
+            } else if (wave == 0 && !zmsg) {
                 // ---- the chain: receive X[l][t]  ->  M_l X + zin  ->  gate  ->  send u_l --------------------------------
                 float v0 = 0.f, v1 = 0.f;
                 bool got;
@@ -939,7 +978,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                     }
                     bulk_publish(reinterpret_cast<u64*>(rec), tag, lane);
                 };
-                if (!first_stage) file(l - 1, s.hb);
+                if (!first_stage && !zmsg) file(l - 1, s.hb);                   // (zmsg: the head files h_0 itself)
                 if (last_stage) {
                     if (first_stage) {
                         file(l, s.hx);                                          // a one-layer model: h_0 is the chain input
@@ -969,6 +1008,8 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
 // floats per thread) and the partial outputs W2[:, 128 j ..] . hidden_j; parts j > 0 send their partials to part 0, which adds
 // them in part order, samples and feeds the ring.  NK = 1 is the single-workgroup head.
 struct HeadLds {
+    float* pre0;   // [256] pre_0[t+1] from layer 0's tap workgroup (head_l0)
+    float* us0;    // u_0[t+1], eight padded K-slices (head_l0: input of conv1x1_out / conv1x1_skip of layer 0)
     float* vs;     // strided relu(skip * scale), 4 NK K-quarters
     float* hid;    // strided hidden slice
     float* obuf;   // [256] head output
@@ -977,11 +1018,12 @@ struct HeadLds {
 };
 __device__ __forceinline__ HeadLds carve_head(float* smem, int NK) {
     HeadLds s;
-    s.vs = smem; s.hid = smem + 4 * NK * QS; s.obuf = s.hid + 4 * QS; s.vbuf = s.obuf + 256;
+    s.pre0 = smem; s.us0 = smem + GC;
+    s.vs = s.us0 + 8 * ES; s.hid = s.vs + 4 * NK * QS; s.obuf = s.hid + 4 * QS; s.vbuf = s.obuf + 256;
     s.flags = reinterpret_cast<int*>(s.vbuf + 48);
     return s;
 }
-__host__ __device__ constexpr size_t head_lds_floats(int NK) { return (size_t)(4 * NK + 4) * QS + 256 + 48 + 16; }
+__host__ __device__ constexpr size_t head_lds_floats(int NK) { return (size_t)GC + 8 * ES + (size_t)(4 * NK + 4) * QS + 256 + 48 + 16; }
 
 // noise value `idx` of (t, b): from the tape (rng = "replay") or the in-kernel Philox stream
 __device__ __forceinline__ float head_noise(const RingParams& p, int t, int b, int idx, int kind) {
@@ -1079,7 +1121,7 @@ __device__ __forceinline__ bool head_collect(const RingParams& p, int b, unsigne
     return ok;
 }
 
-template <int NK>
+template <int NK, bool L0>
 __device__ void run_head(const RingParams& p, int ring, float* smem) {
     WNV_TS_DECL;
     const HeadLds s = carve_head(smem, NK);
@@ -1098,14 +1140,97 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
     const int nchunk = (nmix + 3) >> 2;
     if (tid < 48) s.vbuf[tid] = -INFINITY;
     if (tid == 0) s.flags[0] = 0;
-    const bool fast = same_xcd_as(p, ring, 1, ring + (p.S > 1 ? p.rstride : 0), s.flags + 1);   // h_0 is read by stages 0 and 1
+    // ---- LAYER 0 IN THE HEAD (p.head_l0; scalar-input models with 128 skip channels).  h_0 = w_first x + b_first is affine in the
+    //      sample, so layer 0's pre-activation is  z_0 = (W_cur,0 w_first) x + W_cur,0 b_first + pre_0[t+1]: two FMAs per channel,
+    //      no mat-vec.  The head therefore gates u_0 itself and sends it straight to stage 1 -- one hop and one mat-vec phase less
+    //      per step (~0.6 us) -- followed by h_0 (stage 1's N input) and, behind the sends, layer 0's conv1x1_out / conv1x1_skip
+    //      terms (the stage role's thread mapping and row images).  Position 0 of the ring stays empty.  Stage 1's N_1 h_0 is affine in
+    //      the sample too and is sent along (Z mailbox): h_0 is no longer known a layer ahead of u_0.
+    constexpr bool l0 = L0;
+    const int ks = tid & 7, og = tid >> 3;
+    const bool hi = ks >= 4, writer = (ks & 3) == 0;
+    const int ch = 2 * og + (hi ? 1 : 0);
+    f2 wo0[2][8], ws0[2][8];
+    float a_t = 0.f, a_s = 0.f, c_t = 0.f, c_s = 0.f, bo0 = 0.f, bs0 = 0.f, n_t = 0.f, n_s = 0.f, d_t = 0.f, d_s = 0.f;
+    if (l0) {
+#pragma unroll
+        for (int row = 0; row < 2; ++row) {
+            load_image8(p.woimg + (size_t)row * 4 * RT * 4, tid, wo0[row]);
+            load_image8(p.wsimg + (size_t)row * 4 * RT * 4, tid, ws0[row]);
+        }
+        bo0 = p.bo[ch]; bs0 = p.bskip[ch];
+        if (tid < RC) {
+            a_t = p.l0vec[tid]; a_s = p.l0vec[RC + tid]; c_t = p.l0vec[GC + tid]; c_s = p.l0vec[GC + RC + tid];
+            n_t = p.l0vec[2 * GC + tid]; n_s = p.l0vec[2 * GC + RC + tid]; d_t = p.l0vec[3 * GC + tid]; d_s = p.l0vec[3 * GC + RC + tid];
+        }
+    }
+    // readers of what the head sends: h_0 -> stages 0 and 1; with layer 0 here: u_0, h_0 -> stage 1, layer 0's residual term -> stage 2
+    const bool fast = l0 ? same_xcd_as(p, ring + p.rstride, 1, ring + (p.S > 2 ? 2 : 1) * p.rstride, s.flags + 1)
+                         : same_xcd_as(p, ring, 1, ring + (p.S > 1 ? p.rstride : 0), s.flags + 1);
+    // wave 2 fetches pre_0 of the step whose input is about to be made (tag tg) into LDS; a barrier follows at the call sites
+    auto fetch_pre0 = [&](int b, unsigned tg) {
+        if (l0 && wave == 2) {
+            const float* rec = p.pmail + ((size_t)b * p.L) * (4 + GC);
+            if (!bulk_wait(reinterpret_cast<const u64*>(rec), tg, p.status, 0x700u, lane)) s.flags[0] = 1;
+            *reinterpret_cast<float4*>(s.pre0 + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
+        }
+    };
+    // the input of step (tag tg, parity parn) from the sample xs (waves 0-1): u_0 first -- it is what the chain waits for
+    // (pt, ps: c + pre_0 of the lane's two rows, read from LDS ahead of time; every address comes pinned in registers: between the
+    //  sample and the sends there is no address arithmetic and no reload of a spilled kernel argument)
+    struct FeedAddr { u64 *x0, *x1, *z; float* f; u64 *q, *sk; };
+    auto feed_addr = [&](int b, int parn) {
+        FeedAddr a;
+        a.x0 = p.xmail + ((size_t)b * S1) * RC + tid;
+        a.x1 = a.x0 + RC;
+        a.z = p.zmail + (size_t)b * GC + tid;
+        a.f = p.fmail + ((size_t)b * p.L) * (4 + RC) + 4 + tid;
+        a.q = p.hmail + (((size_t)b * 2 + parn) * S1 + 1) * RC + ch;
+        a.sk = p.smail + ((size_t)b * S1 + 1) * p.Kp + ch;
+        asm volatile("" : "+v"(a.x0), "+v"(a.x1), "+v"(a.z), "+v"(a.f), "+v"(a.q), "+v"(a.sk));
+        return a;
+    };
+    auto feed = [&](int b, unsigned tg, const FeedAddr& ad, float xs, float pt, float ps) {
+        if (wave < 2) {
+            const float h0 = fmaf(wf, xs, bf);
+            if (l0) {
+                const float u = fast_gate(fmaf(a_t, xs, pt), fmaf(a_s, xs, ps));
+                st_granule(ad.x1, tg, u, fast);
+                // N_1 h_0 for stage 1 (it would otherwise run its N mat-vec ON the chain: h_0 is not known a layer early any more)
+                st_granule(ad.z, tg, fmaf(n_t, xs, d_t), fast);
+                st_granule(ad.z + RC, tg, fmaf(n_s, xs, d_s), fast);
+                s.us0[eidx(tid)] = u;
+            }
+            st_granule(ad.x0, tg, h0, fast);
+            WNV_TS(0);
+            // h_0 for layer 0's tap workgroup (history, older taps of the next step): filed HERE, at the start of the step -- the
+            // tap workgroups serve all rings in one pass, and the ring that runs ahead of the others waits for pre_0 first
+            if (l0) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(ad.f), "v"(h0) : "memory");
+        }
+        if (l0) {                                                               // behind the sends: layer 0's residual and skip terms
+            __syncthreads();
+            float xu[16];
+            lds_read16(s.us0 + ES * ks, xu);
+            const float o0 = dot16p(wo0[0], xu), o1 = dot16p(wo0[1], xu);
+            const float o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1)) + bo0;
+            if (writer) st_granule(ad.q, tg, o, fast);                          // (stage 2 is waiting for this one)
+            const float m0 = dot16p(ws0[0], xu), m1 = dot16p(ws0[1], xu);
+            const float m = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + bs0;
+            if (writer) st_granule(ad.sk, tg, m, fast);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the h_0 payload of waves 0-1 has left the CU ...
+            __syncthreads();
+            if (tid == 0) st_granule(reinterpret_cast<u64*>(p.fmail + ((size_t)b * p.L) * (4 + RC)), tg, 0.f, false);   // ... publish the record
+        }
+    };
 
     // ---- prologue: the input of step 0 (wavenet.py:283-289, :297-308) ----------------------------------------
     for (int j = 0; j < p.upr; ++j) {
         const int b = ring + j * p.n_rings;
-        if (b >= p.B || tid >= RC) continue;
+        if (b >= p.B) continue;
+        fetch_pre0(b, p.tag_base + 1u);
+        __syncthreads();
         const float xs = p.Tt > 0 ? p.teacher[(size_t)b * p.Tt] : (p.initial ? p.initial[b] : 0.f);
-        st_granule(p.xmail + ((size_t)b * S1) * RC + tid, p.tag_base + 1u, fmaf(wf, xs, bf), fast);
+        feed(b, p.tag_base + 1u, feed_addr(b, 0), xs, l0 && tid < RC ? c_t + s.pre0[tid] : 0.f, l0 && tid < RC ? c_s + s.pre0[RC + tid] : 0.f);
     }
 
     for (int t = 0; t < p.T; ++t) {
@@ -1121,10 +1246,17 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
                 lr = p.dist == 1 ? logf(r) - logf(1.0f - r) : r;                     // mixture.py:151-152 / :265-267
                 if (t + 1 < p.Tt) forced = p.teacher[(size_t)b * p.Tt + t + 1];
             }
+            const FeedAddr ad = feed_addr(b, (t + 1) & 1);
+            if (t + 1 < p.T) fetch_pre0(b, tag + 1u);
             // ---- wait for the accumulated skip vector of (b, t) -----------------------------------------------
             if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.flags[0] = 1;
             __syncthreads();
             WNV_TS(1);
+            float pt = 0.f, ps = 0.f;
+            if (l0 && tid < RC) { pt = c_t + s.pre0[tid]; ps = c_s + s.pre0[RC + tid]; }
+            // (the teacher sample has long arrived: consume it here, or the compiler waits for "every outstanding memory operation" --
+            //  the chain store just issued included -- when it re-uses the register behind the sample)
+            asm volatile("" : "+v"(forced), "+v"(pt), "+v"(ps));
             head_hidden<NK, 1>(w, s.vs, s.hid, q, i);
             __syncthreads();
             WNV_TS(3);
@@ -1144,6 +1276,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             //      component c -- its three LDS reads are independent, ONE round trip --, the Gumbel-max is a 16-lane DPP butterfly
             //      + ballot (first index wins ties) and the winner's sample comes back through v_readlane.  (Round 2 walked the keys
             //      in a loop of dependent LDS reads and then fetched mean / log-scale: ~0.49 us from barrier to send.) ----
+            float xs = 0.f, xout = 0.f;
             if (wave < 2) {
                 float xo;
                 if (nmix <= 16) {
@@ -1176,13 +1309,11 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
                     xo = p.dist == 1 ? mean + expf(ls) * lr : lr * expf(ls) + mean;
                     xo = fminf(fmaxf(xo, -1.0f), 1.0f);
                 }
-                if (t + 1 < p.T) {
-                    const float xs = t + 1 < p.Tt ? forced : xo;                   // wavenet.py:297-305
-                    st_granule(p.xmail + ((size_t)b * S1) * RC + tid, tag + 1u, fmaf(wf, xs, bf), fast);
-                    WNV_TS(0);
-                }
-                if (tid == 0) p.out[(size_t)b * p.T + t] = xo;
+                xs = t + 1 < p.Tt ? forced : xo;                                    // wavenet.py:297-305
+                xout = xo;
             }
+            if (t + 1 < p.T) feed(b, tag + 1u, ad, xs, pt, ps);
+            if (tid == 0) p.out[(size_t)b * p.T + t] = xout;
             WNV_TS(2);
             if (wave == 0) { WNV_TS_FLUSH(b, t, p.S, 0x1Eu, 0); WNV_TS_FLUSH(b, t + 1, p.S, 0x1u, 0); }   // 0 input of step t+1 sent | 1 skip sum in LDS | 2 step done | 3 hidden layer in LDS | 4 head outputs in LDS
             if (s.flags[0]) return;                 // uniform: written before the barriers above
@@ -1304,7 +1435,7 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
     }
 }
 
-template <int NK>
+template <int NK, bool L0>
 __device__ __forceinline__ void ring_body(const RingParams& p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int P = p.S + p.NH;                   // workgroups of one ring: S stages + NH head parts
@@ -1324,23 +1455,25 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
         if (k < p.tap_parts * p.L) run_tap(p, k % p.L, k / p.L, smem);
         return;
     }
-    if (pos < p.S) run_stage<NK>(p, ring, pos, smem);
+    if (L0 && pos == 0) return;                   // layer 0 is evaluated by the head (run_head)
+    if (L0 && pos == 1) run_stage<NK, L0, L0>(p, ring, pos, smem);
+    else if (pos < p.S) run_stage<NK, L0, false>(p, ring, pos, smem);
     else if (p.cin1 > 1) {
         if constexpr (NK <= 2) {                // one-hot models with 512 skip channels stay on the generic kernel (why_not)
             if (pos == p.S) run_head_cat<NK>(p, ring, smem);
             else run_head_part<NK, 2>(p, ring, pos - p.S, smem);
         }
     } else {
-        if (pos == p.S) run_head<NK>(p, ring, smem);
+        if (pos == p.S) run_head<NK, L0>(p, ring, smem);
         else run_head_part<NK, 1>(p, ring, pos - p.S, smem);
     }
 }
 
 // NK <= 2: capped at 244 VGPRs -- v244 .. v255 are the poll slots (see "POLLS IN RESERVED REGISTERS")
-template <int NK>
-__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK>(p); }
+template <int NK, bool L0>
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK, L0>(p); }
 // K = 512: needs the whole register file; polls one load at a time in compiler-allocated registers
-__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4>(p); }
+__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4, false>(p); }
 
 // Placement census (once per handle): every workgroup of a one-block-per-CU grid reports the XCC it runs on.  The host derives
 // the number of XCDs and checks the block -> XCD mapping the ring layout relies on (block b on XCD b % n_xcd, observed; HIP
@@ -1363,7 +1496,7 @@ struct WnvRingState {
     int L = 0, S = 0, K = 0, Kp = 0, O = 0, cin = 0, kw = 0, kpre = 0, cin1 = 1;
     float* d_w = nullptr;          // one blob, offsets below (floats)
     size_t o_wn = 0, o_cvec = 0, o_w2 = 0, o_wo = 0, o_bo = 0, o_wpre = 0, o_ws = 0, o_bskip = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0,
-           o_bh2 = 0, o_wf = 0, o_bf = 0;
+           o_bh2 = 0, o_wf = 0, o_bf = 0, o_l0 = 0;
     int* d_dil = nullptr;
     int* d_histoff = nullptr;
     int hist_floats = 0;
@@ -1615,6 +1748,37 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     }
     st->o_bf = alloc(RC);
     std::copy(T("first_conv.bias").data.begin(), T("first_conv.bias").data.end(), blob.begin() + st->o_bf);
+    // layer 0 evaluated by the head of scalar-input models (run_head): z_0 = (W_cur,0 w_first) x + W_cur,0 b_first + pre_0, folded in
+    // double: [256] slopes then [256] offsets, rows = tanh channels 0..127 then sigmoid channels 0..127 of the padded geometry
+    st->o_l0 = alloc(4 * GC);
+    if (c.scalar_input) {
+        const HostTensor& wc0 = T("conv_layers.0.conv.weight");          // (G, R, kw)
+        const HostTensor& wf = T("first_conv.weight");                   // (R, 1, 1)
+        const HostTensor& bf = T("first_conv.bias");
+        for (int o = 0; o < GC; ++o) {
+            const int go = gate_row(o);
+            if (go < 0) continue;
+            double a = 0.0, cc = 0.0;
+            for (int ii = 0; ii < Ra; ++ii) {
+                const double wv = (double)wc0.data[((size_t)go * Ra + ii) * kw + (kw - 1)];
+                a += wv * (double)wf.data[ii];
+                cc += wv * (double)bf.data[ii];
+            }
+            blob[st->o_l0 + o] = (float)a;
+            blob[st->o_l0 + GC + o] = (float)cc;
+            if (L >= 2) {                                                // N_1 = sqrt(.5) W_cur,1 (the tap workgroup adds c_1 = N_1 b_o,0)
+                const HostTensor& wc1 = T("conv_layers.1.conv.weight");
+                double a1 = 0.0, c1 = 0.0;
+                for (int ii = 0; ii < Ra; ++ii) {
+                    const double wv = rs * (double)wc1.data[((size_t)go * Ra + ii) * kw + (kw - 1)];
+                    a1 += wv * (double)wf.data[ii];
+                    c1 += wv * (double)bf.data[ii];
+                }
+                blob[st->o_l0 + 2 * GC + o] = (float)a1;
+                blob[st->o_l0 + 3 * GC + o] = (float)c1;
+            }
+        }
+    }
     *out = st;
     RING_HIP(hipMalloc((void**)&st->d_w, blob.size() * sizeof(float)));
     RING_HIP(hipMemcpy(st->d_w, blob.data(), blob.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1668,12 +1832,16 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     // pass (~4-5 us), so a second one per layer joins when there are more utterances and it fits.
     const int cus_per_xcd = ncu / 8;
     const int NK = st->K / RC;                                     // skip passes per stage = head parts per ring
-    const int P = st->S + NK;                                      // workgroups of one ring
+    const int P = st->S + NK;                                      // workgroups (grid positions) of one ring
+    // scalar-input models with 128 skip channels: the head evaluates layer 0 (run_head), position 0 of every ring exits at once
+    bool head_l0 = st->cin1 == 1 && NK == 1 && st->S >= 2;
+    { const char* e = getenv("WNV_RING_L0"); if (e && e[0] == '0') head_l0 = false; }
+    const int Plive = P - (head_l0 ? 1 : 0);
     auto rings_that_fit = [&](int parts) {
         for (int n = std::min(B, 8); n >= 1; --n) {
             const int free_slots = (8 - n) * P;
             const int extra = std::max(0, parts * st->L - free_slots);
-            if (P + (extra + 7) / 8 <= cus_per_xcd) return n;
+            if (Plive + (extra + 7) / 8 <= cus_per_xcd) return n;
         }
         return 0;
     };
@@ -1695,6 +1863,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.K = st->K; p.Kp = st->Kp; p.O = st->O; p.cin = st->cin; p.kw = st->kw; p.kpre = st->kpre; p.nz = ga.nz;
     p.dist = c.output_distribution;
     p.cin1 = st->cin1; p.softmax = ga.softmax; p.quantize = ga.quantize; p.index_out = ga.index_out;
+    p.head_l0 = head_l0 ? 1 : 0;
     p.pstride = std::max(GC, st->Kp);
     p.hist_floats = st->hist_floats;
     p.skip_scale = (float)std::sqrt(1.0 / st->L);
@@ -1702,7 +1871,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const float* w = st->d_w;
     p.w2img = w + st->o_w2; p.wnimg = w + st->o_wn; p.cvec = w + st->o_cvec; p.woimg = w + st->o_wo; p.bo = w + st->o_bo; p.wpre = w + st->o_wpre;
     p.wsimg = w + st->o_ws; p.bskip = w + st->o_bskip; p.wh1img = w + st->o_wh1; p.bh1 = w + st->o_bh1;
-    p.wh2img = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf;
+    p.wh2img = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf; p.l0vec = w + st->o_l0;
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride;
     p.zb_ld = (c.gate_channels + 3) & ~3; p.gh = c.gate_channels / 2;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
@@ -1712,7 +1881,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
     const size_t n_f = (size_t)B * st->L * (4 + RC), n_p = (size_t)B * st->L * (4 + GC);   // stage <-> tap-workgroup bulk records (floats)
     const size_t n_o = (size_t)B * NK * p.Op;                      // partial head outputs of parts 1 .. NK-1
-    const size_t mail_bytes = (5 * n_h + n_s + n_o) * sizeof(u64) + (n_f + n_p) * sizeof(float);
+    const size_t n_z = (size_t)B * GC;                             // N_1 h_0 from the head (head_l0)
+    const size_t mail_bytes = (5 * n_h + n_s + n_o + n_z) * sizeof(u64) + (n_f + n_p) * sizeof(float);
     const size_t hist_bytes = (size_t)B * st->hist_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -1743,7 +1913,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.gmail = p.hmail + 2 * n_h;
     p.smail = p.gmail + 2 * n_h;
     p.omail = p.smail + n_s;
-    p.fmail = (float*)(p.omail + n_o);
+    p.zmail = p.omail + n_o;
+    p.fmail = (float*)(p.zmail + n_z);
     p.pmail = p.fmail + n_f;
     p.hist = p.pmail + n_p;
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
@@ -1758,7 +1929,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
                                 st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
-    const void* kfn = NK == 1 ? (const void*)wnv_ring_kernel<1> : NK == 2 ? (const void*)wnv_ring_kernel<2> : (const void*)wnv_ring_kernel_k512;
+    const void* kfn = NK == 1 ? (head_l0 ? (const void*)wnv_ring_kernel<1, true> : (const void*)wnv_ring_kernel<1, false>)
+                              : NK == 2 ? (const void*)wnv_ring_kernel<2, false> : (const void*)wnv_ring_kernel_k512;
     RING_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.tap_parts = tap_parts;
     const int grid = p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);
@@ -1769,7 +1941,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     {
         int per_cu = 0;
         RING_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, RT, lds));
-        const int live = n_rings * P + tap_parts * st->L;
+        const int live = n_rings * Plive + tap_parts * st->L;
         if (per_cu < 1 || live > ncu * per_cu) {
             char buf[160];
             snprintf(buf, sizeof buf, "ring kernel: %d workgroups must be co-resident but the device holds %d (%d CUs x %d per CU)", live,
@@ -1798,8 +1970,9 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
         p.trace_tap = d_trace + (size_t)trace_n * upr * (st->S + 1) * TRW;
     }
-    if (NK == 1) hipLaunchKernelGGL(wnv_ring_kernel<1>, dim3(grid), dim3(RT), lds, stream, p);
-    else if (NK == 2) hipLaunchKernelGGL(wnv_ring_kernel<2>, dim3(grid), dim3(RT), lds, stream, p);
+    if (NK == 1 && head_l0) hipLaunchKernelGGL((wnv_ring_kernel<1, true>), dim3(grid), dim3(RT), lds, stream, p);
+    else if (NK == 1) hipLaunchKernelGGL((wnv_ring_kernel<1, false>), dim3(grid), dim3(RT), lds, stream, p);
+    else if (NK == 2) hipLaunchKernelGGL((wnv_ring_kernel<2, false>), dim3(grid), dim3(RT), lds, stream, p);
     else hipLaunchKernelGGL(wnv_ring_kernel_k512, dim3(grid), dim3(RT), lds, stream, p);
     RING_HIP(hipGetLastError());
     // a bounded spin that gave up must reach the caller: the status word follows the kernel into pinned host memory; the call
