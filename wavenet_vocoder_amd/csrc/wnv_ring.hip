@@ -984,6 +984,9 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                         file(l, s.hx);                                          // a one-layer model: h_0 is the chain input
                     } else {
                         float q0 = 0.f, q1 = 0.f;
+                        if constexpr (zmsg) {                                   // (a two-layer model: this stage never fetched its own input h_0)
+                            if (!recv128(p.xmail + ((size_t)b * S1) * RC + 2 * lane, 0x500u + (unsigned)sidx, hv0, hv1)) return;
+                        }
                         if (!recv128(p.hmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + 2 * lane, 0x500u + (unsigned)sidx, q0, q1)) return;   // (status holds the code; the others drain at their next wait)
                         *reinterpret_cast<float2*>(s.hh + eidx(2 * lane)) = make_float2((q0 + hv0) * 0.70710678118654752440f, (q1 + hv1) * 0.70710678118654752440f);
                         file(l, s.hh);
