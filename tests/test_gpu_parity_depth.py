@@ -19,7 +19,7 @@ import pytest
 import torch
 
 import wavenet_vocoder_amd as wnv
-from oracle.wavenet_oracle import Oracle
+from oracle.wavenet_oracle import Oracle, sample_mol
 from tests._configs import CONFIGS, build, inputs, tame_head_
 from tests._golden import oracle_config
 from tests._margins import assert_free_run_agrees_until_near_tie, assert_match_or_near_tie
@@ -35,6 +35,14 @@ GAUSS30 = dict(out_channels=2, layers=30, stacks=3, residual_channels=128, gate_
 def tape_for(kw, T, B, seed):
     return make_noise_tape(T, B, scalar_input=kw.get("scalar_input", False), output_distribution=kw.get("output_distribution", "Logistic"),
                            out_channels=kw["out_channels"], generator=torch.Generator().manual_seed(seed))
+
+
+def sample_from_params(params, tape, kw):
+    """The oracle's mixture-of-logistics sampler applied to head outputs of every step at once: params (B, O, T), tape (T, B, NZ) -> (B, 1, T)."""
+    B, O, T = params.shape
+    y = params.permute(0, 2, 1).reshape(B * T, O)
+    nz = tape.permute(1, 0, 2).reshape(B * T, -1)
+    return sample_mol(y, nz).reshape(B, 1, T)
 
 
 def teacher(kw, B, T, seed=3):
@@ -128,6 +136,32 @@ def test_ring_at_the_benchmark_shape_vs_oracle():
     hz = assert_free_run_agrees_until_near_tie(out, want, params, wparams, tape, kw, t0=Tt - 1)
     print(f"benchmark shape: forced head outputs max err {err:.2e}, {n_bad} near-tie flips among {B * (Tt - 1)} forced samples; "
           f"free-run agreement horizon per utterance (of {T}): {hz}")
+
+
+def test_ring_at_the_benchmark_length_online_equals_offline():
+    """The benchmark's own size -- egs/mol, B = 8 x T = 24 064 -- teacher-forced on the ring kernel against the batch `forward` kernels on
+    the same inputs (online == offline, the reference's own test pattern, tests/test_model.py:361-366): head outputs <= 1e-4 at every
+    one of the 192 512 steps.  The oracle cannot reach this length; `wnv_forward` is itself oracle-checked (tests/test_gpu_forward.py,
+    T = 2304 deep taps in this file).  Then the samples under a shared tape: a forced step's sample may differ from what the offline
+    head outputs imply only at a near tie of the Gumbel pick."""
+    name, B, T = "cfg2_mol", 8, 24064
+    kw = CONFIGS[name]
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    c, _ = inputs(name, B, T)
+    x = teacher(kw, B, T).cuda()
+    tape = tape_for(kw, T, B, 5)
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    out, params, _ = eng.generate(B=B, T=T, c_up=c_up, teacher=x.transpose(1, 2).contiguous(), noise=tape.cuda(), want_params=True, kernel=0)
+    assert eng.last_kernel() == 2, "auto must choose the ring kernel for the benchmark configuration"
+    off = eng.forward(x, c_up=c_up)
+    err = (params - off).abs()
+    worst = float(err.max())
+    assert worst < TOL, (worst, int(err.flatten().argmax()))
+    tail = float(err[:, :, T - 4096:].max())                                      # no drift with depth into the utterance
+    # every step is forced: sample t follows from the head outputs of step t alone -> compare with the sampler applied to the OFFLINE outputs
+    n_bad = assert_match_or_near_tie(out.cpu(), sample_from_params(off.cpu(), tape, kw), off.cpu(), tape, kw, what="benchmark length, forced")
+    print(f"benchmark length: online vs offline head outputs max err {worst:.2e} (last 4096 steps {tail:.2e}); {n_bad} near-tie flips among {B * T} samples")
 
 
 def test_ring_multispeaker_16_per_gpu_vs_oracle():
