@@ -67,6 +67,35 @@ def test_ring_equals_generic_kernel(B):
     assert torch.equal(o2, o3)
 
 
+@pytest.mark.parametrize("name,B", [("cfg2_mol", 8), ("cfg2_mol", 3), ("cfg3_gaussian", 5)])
+def test_split_rings_vs_oracle_and_generic(name, B, monkeypatch):
+    """WNV_RING_SPLIT=1: two CUs per layer (run_stage_split; measured and not the default -- profiles/r03_ring_split_fine_timeline.txt).
+    Teacher-forced head outputs against the oracle, then a free run against the generic kernel, and the layer-0-in-the-head switch
+    (WNV_RING_L0=0: position 0 of every ring is a stage again) bit-compatible in the same sense."""
+    kw = CONFIGS[name]
+    T, Tt = 512, 256
+    m = build(name)
+    o = Oracle(oracle_config(kw), m.state_dict())
+    c, _ = inputs(name, B, T)
+    x = torch.tanh(torch.randn(B, 1, Tt, generator=torch.Generator().manual_seed(3)) * 0.5)
+    tape = tape_for(kw, T, B, 2)
+    torch.set_num_threads(8)
+    _, wparams = o.incremental_forward(test_inputs=x, c=c, T=T, noise=tape, return_params=True)
+    eng = m.to("cuda")._get_engine()
+    c_up = eng.upsample(c.cuda(), T_expected=T)
+    xt = x.transpose(1, 2).contiguous().cuda()
+    ref, pref, _ = run(eng, 1, B, T, c_up, xt, tape.cuda())
+    for env in ({"WNV_RING_SPLIT": "1"}, {"WNV_RING_L0": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out, params, _ = run(eng, 2, B, T, c_up, xt, tape.cuda())
+        for k in env:
+            monkeypatch.delenv(k)
+        err = (params.cpu()[:, :, :Tt] - wparams[:, :, :Tt]).abs().max().item()
+        assert err < TOL, (env, err)
+        assert_free_run_agrees_until_near_tie(out.cpu(), ref.cpu(), params.cpu(), pref.cpu(), tape, kw, t0=Tt - 1, what=str(env))
+
+
 def test_ring_30_layers_seven_rings_vs_oracle():
     """egs/gaussian as BASELINE.json words it (30 layers, 3 stacks: dilations up to 512): 8 x 31 ring workgroups + 30 tap
     workgroups do not fit 256 CUs, so 7 rings carry the 8 utterances (one ring pipelines two)."""

@@ -173,8 +173,9 @@ def test_ring_kernel_keeps_its_poll_registers_out_of_the_compilers_hands(tmp_pat
     label = re.compile(r"^(\.LBB\w+):")
     branch = re.compile(r"\bs_c?branch\w*\s+(\.LBB\w+)")
     checked = 0
-    for nk, l0 in ((1, 0), (1, 1), (2, 0)):                 # <NK, head evaluates layer 0>
-        m = re.search(rf"^_ZN\S*wnv_ring_kernelILi{nk}ELb{l0}E\S*:[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
+    for nk, l0 in ((1, 0), (1, 1), (2, 0), (1, "split")):  # <NK, head evaluates layer 0>, and the split-ring kernel
+        kname = "wnv_ring_kernel_splitE" if l0 == "split" else f"wnv_ring_kernelILi{nk}ELb{l0}E"
+        m = re.search(rf"^_ZN\S*{kname}\S*:[^\n]*\n(.*?)s_endpgm", text, re.S | re.M)
         assert m, f"kernel <{nk}, {l0}> not found"
         lines = [ln.split(";")[0] for ln in m.group(1).splitlines()]
         helpers = [i for i, c in enumerate(lines) if uses.search(c) and helper.match(c)]
@@ -203,9 +204,9 @@ def test_ring_kernel_keeps_its_poll_registers_out_of_the_compilers_hands(tmp_pat
                     assert not [j for j in helpers if j >= after], \
                         f"wnv_ring_kernel<{nk}, {l0}>: {c.strip()} leaves the tap role's code into code with poll helpers"
         checked += 1
-        meta = re.search(rf"\.name:\s+_ZN\S*wnv_ring_kernelILi{nk}ELb{l0}E\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
+        meta = re.search(rf"\.name:\s+_ZN\S*{kname}\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
         assert meta and int(meta.group(1)) == 0, "the capped kernel spills"
-    assert checked == 3
+    assert checked == 4
 
 
 # ---- host-only handles (wnv_create with device = -1): the native checkpoint path without a GPU ------------------------------

@@ -69,6 +69,8 @@ struct RingParams {
     const float *w2img, *wnimg, *woimg, *wsimg, *bo, *wpre, *bskip, *cvec;
     const float *wh1img, *bh1, *wh2img, *bh2, *wfirst, *bfirst;   // one-hot models: wh2img holds two row images (rows i, 128 + i), wfirst is K-major [cin1][128]
     int cin1, softmax, quantize;       // first_conv input channels (1 = scalar input); categorical head switches (wavenet.py:332-335)
+    int split, sA, qh;                 // split rings (run_stage_split): layers on TWO CUs; stages 1 .. sA share the head's XCD; qh = 2: two partial vectors per Q / skip slot
+    const float *w2s, *wns, *wos, *wss; // split rings: per (layer, half) row images of M, N (wave-group mapping, 4 slots), conv1x1_out / conv1x1_skip K-halves
     int head_l0;                       // the head evaluates layer 0 itself (scalar-input models, K = 128): position 0 of a ring stays empty
     const float* l0vec;                // [4][256]: W_cur,0 w_first, W_cur,0 b_first (layer 0's pre-activation is affine in the sample); N_1 w_first, N_1 b_first (so is N_1 h_0)
     int* index_out;
@@ -326,6 +328,23 @@ __device__ __forceinline__ bool rpoll_recv3(const u64* ga, const u64* gb, const 
     }
 }
 
+// ... and two 2-granule groups (the two partial residual vectors of a split ring)
+__device__ __forceinline__ bool rpoll_recv2x2(const u64* ga, const u64* gb, unsigned tag, float& a0, float& a1, float& b0, float& b1, unsigned int* status, unsigned code, int lane) {
+    unsigned spins = 0;
+    for (;;) {
+        rpoll16_issue<1>(ga); rpoll16_issue<2>(gb);
+        const u4v a = rpoll16_take<1, 1>(), b = rpoll16_take<2, 0>();
+        if (__all(a.y == tag && a.w == tag && b.y == tag && b.w == tag)) {
+            a0 = __uint_as_float(a.x); a1 = __uint_as_float(a.z); b0 = __uint_as_float(b.x); b1 = __uint_as_float(b.z);
+            return true;
+        }
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+    }
+}
+
 // Placement handshake: publish this workgroup's XCC id, read those of the (up to two) workgroups that read what this one
 // sends; true when all share an XCD (and its L2).
 __device__ __forceinline__ bool same_xcd_as(const RingParams& p, int reader_a, int n_a, int reader_b, int* flag) {
@@ -349,6 +368,34 @@ __device__ __forceinline__ bool same_xcd_as(const RingParams& p, int reader_a, i
     }
     __syncthreads();
     return *flag != 0;
+}
+
+// the same for an explicit list of reader blocks (split rings)
+__device__ __forceinline__ bool same_xcd_list(const RingParams& p, const int* readers, int n, int* flag) {
+    if (threadIdx.x == 0) {
+        unsigned x;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+        x = (x & 0xfu) + 1u;
+        __hip_atomic_store(p.xcc + blockIdx.x, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool same = true;
+        for (int k = 0; k < n; ++k) {
+            unsigned y = 0, spins = 0;
+            while ((y = __hip_atomic_load(p.xcc + readers[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) {
+                if (++spins > SPIN_LIMIT) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            same = same && y == x;
+        }
+        *flag = (p.allow_fast && same) ? 1 : 0;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+// split rings: ring r lives on XCDs 2r (the head in slot 0, then both halves of stages 1 .. sA) and 2r + 1 (stages sA + 1 .. S - 1);
+// block b runs on XCD b % 8 (verified by the host's census), slot = b / 8
+__device__ __forceinline__ int split_block(const RingParams& p, int ring, int stage, int half) {
+    if (stage >= p.S) return 2 * ring;                                          // the head
+    return stage <= p.sA ? 2 * ring + 8 * (1 + 2 * (stage - 1) + half) : 2 * ring + 1 + 8 * (2 * (stage - p.sA - 1) + half);
 }
 
 // debug timeline (builds with -DWNV_FINE_TRACE only; the product kernel carries no stamp code -- the scalar bookkeeping of a
@@ -1004,6 +1051,229 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
     }
 }
 
+// ---- SPLIT RINGS (round 3): one layer = TWO CUs ------------------------------------------------------------------------------
+// A 256 x 128 mat-vec phase costs a CU ~0.29 us however its waves are arranged: four SIMDs issue 128 fp32 FMAs per clock, the
+// phase is VALU-bound (profiles/r03_ring_c2_fine_timeline.txt), and a layer has one such phase on the chain (M_l u) and one on the
+// loop u_l -> h_{l+1} -> N_{l+2} h_{l+1} -> u_{l+2} that runs neck and neck with it.  With 8 utterances per GPU the chip has room for
+// TWO CUs per layer (4 rings x 2 utterances; a ring spans two XCDs, two cross-XCD hops per step): half h of stage l owns gate
+// channels [64 h, 64 h + 64) -- 128 rows of M_l (waves 0-3) and of N_l (waves 4-7), 32 packed FMAs per lane instead of 64 -- and
+// the K-half [64 h, 64 h + 64) of conv1x1_out and conv1x1_skip, whose inputs are the u channels it has just gated itself:
+//   * both halves poll the whole chain input (mailboxes are multi-reader) and each publishes its 64 channels of u_l;
+//   * conv1x1_out / conv1x1_skip become PARTIAL sums over the half's own 64 inputs (no wait for the sibling): Q and the skip
+//     chain carry two partial vectors per slot (bias in half 0); the poller of stage l + 2 forms h_{l+1} = sqrt(.5) (qA + qB + h_l),
+//     the head adds the two skip chains.  Re-association only (<= 1e-6 on the head outputs; parity tests).
+// Needs the head to evaluate layer 0 (L0) and 128 skip channels.  Thread mapping of a wave group: lane (og = gtid >> 3, ks = gtid & 7):
+// eight lanes split K for the four rows {tanh, sigmoid} x local channels 2og, 2og + 1; slots 0-1 = the channel the lane keeps
+// (2og + (ks >= 4)), slots 2-3 = the other one: row_half_mirror adds the partner's slots 2-3 to 0-1, a quad all-reduce finishes.
+__device__ __forceinline__ void group_matvec4(const f2 (&w)[4][8], const float* xslice, const float* za, const float* zb, float& a, float& g) {
+    float2 z = make_float2(*za, *zb);
+    float x[16];
+    lds_read16(xslice, x);
+    f2 acc[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) acc[s] = f2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc[s] = __builtin_elementwise_fma(w[s][k], f2{x[2 * k], x[2 * k + 1]}, acc[s]);
+    asm volatile("" : "+v"(z.x), "+v"(z.y));
+    const float q0 = acc[0].x + acc[0].y, q1 = acc[1].x + acc[1].y, q2 = acc[2].x + acc[2].y, q3 = acc[3].x + acc[3].y;
+    a = quad_allreduce(dpp_fold<0x141>(q0, q2)) + z.x;
+    g = quad_allreduce(dpp_fold<0x141>(q1, q3)) + z.y;
+}
+// ONE wave: two single granules + one pair of granules per lane in one round trip (stage 1 behind the head: its two rows of
+// N_1 h_0 and two values of u_0)
+__device__ __forceinline__ bool rpoll_recv_zx(const u64* ga, const u64* gb, const u64* gx, unsigned tag, float (&v)[4], unsigned int* status, unsigned code, int lane) {
+    unsigned spins = 0;
+    for (;;) {
+        rpoll8_issue<0>(ga); rpoll8_issue<1>(gb); rpoll16_issue<2>(gx);
+        unsigned va, ta, vb, tb;
+        rpoll8_take<0, 2>(va, ta);
+        rpoll8_take<1, 1>(vb, tb);
+        const u4v c = rpoll16_take<2, 0>();
+        if (__all(ta == tag && tb == tag && c.y == tag && c.w == tag)) {
+            v[0] = __uint_as_float(va); v[1] = __uint_as_float(vb); v[2] = __uint_as_float(c.x); v[3] = __uint_as_float(c.z);
+            return true;
+        }
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+    }
+}
+
+template <bool ZMSG>
+__device__ void run_stage_split(const RingParams& p, int ring, int sidx, int half, float* smem) {
+    const StageLds s = carve_stage(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = tid >> 8, gtid = tid & (GT - 1);
+    const int ks = gtid & 7, og = gtid >> 3;
+    const int lc = 2 * og + (ks >= 4 ? 1 : 0);                  // local channel whose (tanh, sigmoid) rows end up in this lane
+    const int chc = 64 * half + lc;                             // ... as a channel of the layer
+    const bool gwriter = (ks & 3) == 0;
+    const int r = tid >> 2, kq = tid & 3;                       // behind the send: four lanes split the half's 64 inputs of output row r
+    const bool qwriter = kq == 0;
+    const int l = sidx;
+    const bool last_stage = sidx == p.S - 1;
+    const int S1 = p.S + 1;
+    constexpr float RS = 0.70710678118654752440f;
+    WNV_TS_DECL;
+
+    f2 wmn[4][8], wo[8], ws[8];
+#pragma unroll
+    for (int slot = 0; slot < 4; ++slot)
+        load_image8g((grp == 0 ? p.w2s : p.wns) + (((size_t)l * 2 + half) * 4 + slot) * 4 * GT * 4, gtid, wmn[slot]);
+    load_image8(p.wos + ((size_t)l * 2 + half) * 4 * RT * 4, tid, wo);
+    load_image8(p.wss + ((size_t)l * 2 + half) * 4 * RT * 4, tid, ws);
+    const float bo_r = half == 0 ? p.bo[(size_t)l * RC + r] : 0.f;          // the biases ride on half 0's partial sums
+    const float bs_r = half == 0 ? p.bskip[(size_t)l * p.Kp + r] : 0.f;
+    if (tid == 0) s.flags[0] = 0;
+    // who reads what this half sends: u_l, the handed-on layer input and the skip chain -> stage l + 1 (the head behind the last
+    // stage; the stage before the last completes the skip sum for the head as well); the residual partials -> stage l + 2
+    if (tid == 0) {
+        int near[4], far[2], nn = 0, nf = 0;
+        if (!last_stage) { near[nn++] = split_block(p, ring, sidx + 1, 0); near[nn++] = split_block(p, ring, sidx + 1, 1); }
+        if (sidx >= p.S - 2) near[nn++] = split_block(p, ring, p.S, 0);
+        if (sidx + 2 < p.S) { far[nf++] = split_block(p, ring, sidx + 2, 0); far[nf++] = split_block(p, ring, sidx + 2, 1); }
+        else if (!last_stage) { far[nf++] = split_block(p, ring, sidx + 1, 0); }    // the last stage reads them for its history push
+        int* rl = s.flags + 4;
+        rl[0] = nn; rl[1] = nf;
+        for (int k = 0; k < nn; ++k) rl[2 + k] = near[k];
+        for (int k = 0; k < nf; ++k) rl[6 + k] = far[k];
+    }
+    __syncthreads();
+    const bool fast = same_xcd_list(p, s.flags + 6, s.flags[4], s.flags + 1);
+    const bool fast_far = same_xcd_list(p, s.flags + 10, s.flags[5], s.flags + 2);
+
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        const int par = t & 1;
+        for (int j = 0; j < p.upr; ++j) {
+            const int b = ring + j * p.n_rings;
+            if (b >= p.B) continue;
+            const u64* x_in = p.xmail + ((size_t)b * S1 + sidx) * RC + 2 * lane;      // wave 0: two granules per lane
+            u64* x_out = p.xmail + ((size_t)b * S1 + sidx + 1) * RC + chc;            // chain waves
+            u64* q_out = p.hmail + ((((size_t)b * 2 + par) * S1 + sidx + 1) * 2 + half) * RC + r;
+            const u64* sm_in = p.smail + (((size_t)b * S1 + sidx) * 2 + half) * p.Kp + r;
+            u64* sm_out = p.smail + (((size_t)b * S1 + sidx + 1) * 2 + half) * p.Kp + r;
+            asm volatile("" : "+v"(x_in), "+v"(x_out), "+v"(q_out), "+v"(sm_in), "+v"(sm_out));
+            float hv0 = 0.f, hv1 = 0.f;                                         // wave 0: h_{l-1}[t], channels 2 lane, 2 lane + 1
+            bool hand_on = false;
+            auto recv128 = [&](const u64* g2, unsigned code, float& v0, float& v1) {
+                return rpoll_recv2<false>(g2, tag, v0, v1, p.status, code, lane);
+            };
+            if (wave == 0) {
+                const float* rec = p.pmail + ((size_t)b * p.L + l) * (4 + GC);
+                if (!bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                *reinterpret_cast<float4*>(s.pre + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
+                if constexpr (ZMSG) {                                           // lane L: rows 64 half + L (tanh) and 128 + 64 half + L (sigmoid)
+                    float v[4] = {0.f, 0.f, 0.f, 0.f};
+                    const u64* zt = p.zmail + (size_t)b * GC + 64 * half + lane;
+                    if (!rpoll_recv_zx(zt, zt + RC, x_in, tag, v, p.status, 0x100u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                    WNV_TS(5); WNV_TS(8);
+                    *reinterpret_cast<float2*>(s.zin + 2 * lane) = make_float2(v[0] + s.pre[64 * half + lane], v[1] + s.pre[RC + 64 * half + lane]);
+                    *reinterpret_cast<float2*>(s.hx + eidx(2 * lane)) = make_float2(v[2], v[3]);
+                } else {
+                    // h_{l-1} = sqrt(.5) (qA + qB + h_{l-2}): the two partial residual terms of stage l - 2 and the layer input stage
+                    // l - 1 handed on (stage 2: h_0 straight from the head, whose q_0 is whole: its half-1 vector is zeros)
+                    const size_t slot = (((size_t)b * 2 + par) * S1 + sidx - 1);
+                    const u64* gsrc = sidx == 2 ? p.xmail + ((size_t)b * S1) * RC + 2 * lane : p.gmail + slot * RC + 2 * lane;
+                    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    // (h_{l-2} is there long before the partials: fetched alone, then the two partials travel together)
+                    const bool ok = recv128(gsrc, 0x480u + (unsigned)sidx, v[0], v[1]) &&
+                                    rpoll_recv2x2(p.hmail + (slot * 2) * RC + 2 * lane, p.hmail + (slot * 2 + 1) * RC + 2 * lane, tag, v[2], v[3], v[4], v[5], p.status,
+                                                  0x400u + (unsigned)sidx, lane);
+                    hv0 = ((v[2] + v[4]) + v[0]) * RS;
+                    hv1 = ((v[3] + v[5]) + v[1]) * RS;
+                    if (!ok) s.flags[0] = 1;
+                    WNV_TS(5);
+                    *reinterpret_cast<float2*>(s.hb + eidx(2 * lane)) = make_float2(hv0, hv1);
+                    hand_on = half == 0 && !last_stage && ok;
+                }
+            }
+            __syncthreads();                                                    // pre_l and h_{l-1} in LDS
+            if (wave == 0 && hand_on)
+                st_granule2(p.gmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + 2 * lane, tag, hv0, hv1, fast);
+            if (grp == 1 && !ZMSG) {
+                WNV_TS(12);
+                float a, g;
+                group_matvec4(wmn, s.hb + ES * ks, s.pre + chc, s.pre + RC + chc, a, g);
+                if (gwriter) *reinterpret_cast<float2*>(s.zin + 2 * lc) = make_float2(a, g);
+                WNV_TS(6);
+            } else if (wave == 0 && !ZMSG) {
+                float v0 = 0.f, v1 = 0.f;
+                if (!recv128(x_in, 0x100u + (unsigned)sidx, v0, v1)) s.flags[0] = 1;
+                WNV_TS(8);
+                *reinterpret_cast<float2*>(s.hx + eidx(2 * lane)) = make_float2(v0, v1);
+            }
+            __syncthreads();                                                    // X[l][t] and zin in LDS
+            if (grp == 1) WNV_TS(0);
+            if (grp == 0) {
+                float a, g;
+                group_matvec4(wmn, s.hx + ES * ks, s.zin + 2 * lc, s.zin + 2 * lc + 1, a, g);
+                const float u = fast_gate(a, g);                                // modules.py:154
+                if (gwriter) {
+                    if (!last_stage) st_granule(x_out, tag, u, fast);
+                    s.us[eidx(lc)] = u;
+                }
+                WNV_TS(1);
+            }
+            __syncthreads();                                                    // this half's 64 channels of u_l in LDS
+            if (grp == 1) WNV_TS(7);
+            float xu[16];
+            lds_read16(s.us + ES * kq, xu);
+            auto h_phase = [&]() {
+                if (!last_stage) {
+                    const float o = quad_allreduce(dot16p(wo, xu)) + bo_r;
+                    if (qwriter) st_granule(q_out, tag, o, fast_far);
+                }
+            };
+            auto skip_phase = [&]() {
+                const float mine = quad_allreduce(dot16p(ws, xu)) + bs_r;
+                float acc = 0.f;
+                bool ok = true;
+                // (half 0's chain starts at the head, half 1's here at stage 1; the last stage publishes its own term alone)
+                if (!last_stage && (sidx > 1 || half == 0)) ok = wave_recv<false>(sm_in, qwriter, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
+                if (qwriter && ok) st_granule(sm_out, tag, acc + mine, fast);
+                if (!ok) s.flags[0] = 1;
+            };
+            if (sidx >= p.S - 2) { skip_phase(); WNV_TS(3); h_phase(); WNV_TS(2); }
+            else { h_phase(); WNV_TS(2); skip_phase(); WNV_TS(3); }
+            __syncthreads();
+            if (s.flags[0]) return;
+            if (wave == 0 && half == 0) {                                       // history of layer l - 1 (and of the last layer): half 0 files it
+                auto file = [&](int layer, const float* vec) {
+                    float* rec = p.fmail + ((size_t)b * p.L + layer) * (4 + RC);
+                    if (lane < RC / 4) {
+                        const float* src = vec + ES * (lane >> 2) + 4 * (lane & 3);
+                        bulk_store16(rec + 4 + 4 * lane, *reinterpret_cast<const float4*>(src));
+                    }
+                    bulk_publish(reinterpret_cast<u64*>(rec), tag, lane);
+                };
+                if (!ZMSG) file(l - 1, s.hb);
+                if (last_stage) {
+                    if constexpr (ZMSG) {
+                        if (!recv128(p.xmail + ((size_t)b * S1) * RC + 2 * lane, 0x500u + (unsigned)sidx, hv0, hv1)) return;
+                    }
+                    const size_t slot = (((size_t)b * 2 + par) * S1 + sidx);
+                    float qa0 = 0.f, qa1 = 0.f, qb0 = 0.f, qb1 = 0.f;
+                    if (!(recv128(p.hmail + (slot * 2) * RC + 2 * lane, 0x500u + (unsigned)sidx, qa0, qa1) &&
+                          recv128(p.hmail + (slot * 2 + 1) * RC + 2 * lane, 0x500u + (unsigned)sidx, qb0, qb1))) return;
+                    *reinterpret_cast<float2*>(s.hh + eidx(2 * lane)) = make_float2(((qa0 + qb0) + hv0) * RS, ((qa1 + qb1) + hv1) * RS);
+                    file(l, s.hh);
+                }
+            }
+            WNV_TS(4);
+            if (half == 0) {
+                if (wave == 0) WNV_TS_FLUSH(b, t, sidx, 0x013Eu, 0);
+                else if (wave < 4) WNV_TS_FLUSH(b, t, sidx, 0x002u, 7 + wave);
+                else if (wave == 4) { WNV_TS_FLUSH(b, t, sidx, 0x10C1u, 0); WNV_TS_FLUSH(b, t, sidx, 0x000Cu, 16); }
+                else if (wave == 5) WNV_TS_FLUSH(b, t, sidx, 0x0040u, 7);
+            }
+        }
+    }
+}
+
 // ---- head -----------------------------------------------------------------------------------------------------------
 // skip sum -> ReLU -> 1x1 (K x K) -> ReLU -> 1x1 (O x K) -> sampler -> first_conv of the next step (wavenet.py:313-336).
 // With K = 128 NK skip channels the K x K matrix does not fit one CU, so the head is NK workgroups ("parts"): part j owns
@@ -1067,6 +1337,19 @@ __device__ __forceinline__ bool head_recv_skip(const RingParams& p, int b, unsig
     }
     return ok;
 }
+// split rings: two partial chains (halves) per slot: (accA + accB) + ownA + ownB, all four granules of a lane in two round trips
+__device__ __forceinline__ bool head_recv_skip_split(const RingParams& p, int b, unsigned tag, float* vs, int tid, int lane, int wave) {
+    bool ok = true;
+    if (wave < 2) {
+        const u64* own = p.smail + (((size_t)b * (p.S + 1) + p.S) * 2) * p.Kp + tid;        // the last stage's terms: halves 0, 1
+        const u64* acc = own - 2 * p.Kp;                                                     // the sums through stage S - 2
+        float a0 = 0.f, a1 = 0.f, o0 = 0.f, o1 = 0.f;
+        ok = rpoll_recv<0>(acc, true, tag, a0, p.status, 0x300u, lane) && rpoll_recv<0>(acc + p.Kp, true, tag, a1, p.status, 0x300u, lane) &&
+             rpoll_recv<0>(own, true, tag, o0, p.status, 0x300u, lane) && rpoll_recv<0>(own + p.Kp, true, tag, o1, p.status, 0x300u, lane);
+        vs[qidx(tid)] = fmaxf((((a0 + a1) + o0) + o1) * p.skip_scale, 0.f);               // wavenet.py:313-316
+    }
+    return ok;
+}
 // hidden slice (wavenet.py:317-318) into s.hid; needs a barrier before and after
 template <int NK, int NW2>
 __device__ __forceinline__ void head_hidden(const HeadSlice<NK, NW2>& w, const float* vs, float* hid, int q, int i) {
@@ -1124,7 +1407,7 @@ __device__ __forceinline__ bool head_collect(const RingParams& p, int b, unsigne
     return ok;
 }
 
-template <int NK, bool L0>
+template <int NK, bool L0, bool SPLIT>
 __device__ void run_head(const RingParams& p, int ring, float* smem) {
     WNV_TS_DECL;
     const HeadLds s = carve_head(smem, NK);
@@ -1168,8 +1451,15 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
         }
     }
     // readers of what the head sends: h_0 -> stages 0 and 1; with layer 0 here: u_0, h_0 -> stage 1, layer 0's residual term -> stage 2
-    const bool fast = l0 ? same_xcd_as(p, ring + p.rstride, 1, ring + (p.S > 2 ? 2 : 1) * p.rstride, s.flags + 1)
-                         : same_xcd_as(p, ring, 1, ring + (p.S > 1 ? p.rstride : 0), s.flags + 1);
+    bool fast;
+    if constexpr (SPLIT) {                                                      // both halves of stages 1 and 2
+        if (tid == 0) { int* rl = s.flags + 4; rl[0] = split_block(p, ring, 1, 0); rl[1] = split_block(p, ring, 1, 1); rl[2] = split_block(p, ring, 2, 0); rl[3] = split_block(p, ring, 2, 1); }
+        __syncthreads();
+        fast = same_xcd_list(p, s.flags + 4, 4, s.flags + 1);
+    } else {
+        fast = l0 ? same_xcd_as(p, ring + p.rstride, 1, ring + (p.S > 2 ? 2 : 1) * p.rstride, s.flags + 1)
+                  : same_xcd_as(p, ring, 1, ring + (p.S > 1 ? p.rstride : 0), s.flags + 1);
+    }
     // wave 2 fetches pre_0 of the step whose input is about to be made (tag tg) into LDS; a barrier follows at the call sites
     auto fetch_pre0 = [&](int b, unsigned tg) {
         if (l0 && wave == 2) {
@@ -1188,8 +1478,9 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
         a.x1 = a.x0 + RC;
         a.z = p.zmail + (size_t)b * GC + tid;
         a.f = p.fmail + ((size_t)b * p.L) * (4 + RC) + 4 + tid;
-        a.q = p.hmail + (((size_t)b * 2 + parn) * S1 + 1) * RC + ch;
-        a.sk = p.smail + ((size_t)b * S1 + 1) * p.Kp + ch;
+        // (split rings: two partial vectors per slot; layer 0's terms are whole and go to half 0, half 1 of the residual slot gets zeros)
+        a.q = p.hmail + ((((size_t)b * 2 + parn) * S1 + 1) * (SPLIT ? 2 : 1)) * RC + ch;
+        a.sk = p.smail + (((size_t)b * S1 + 1) * (SPLIT ? 2 : 1)) * p.Kp + ch;
         asm volatile("" : "+v"(a.x0), "+v"(a.x1), "+v"(a.z), "+v"(a.f), "+v"(a.q), "+v"(a.sk));
         return a;
     };
@@ -1216,7 +1507,10 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             lds_read16(s.us0 + ES * ks, xu);
             const float o0 = dot16p(wo0[0], xu), o1 = dot16p(wo0[1], xu);
             const float o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1)) + bo0;
-            if (writer) st_granule(ad.q, tg, o, fast);                          // (stage 2 is waiting for this one)
+            if (writer) {
+                st_granule(ad.q, tg, o, fast);                                  // (stage 2 is waiting for this one)
+                if constexpr (SPLIT) st_granule(ad.q + RC, tg, 0.f, fast);
+            }
             const float m0 = dot16p(ws0[0], xu), m1 = dot16p(ws0[1], xu);
             const float m = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + bs0;
             if (writer) st_granule(ad.sk, tg, m, fast);
@@ -1252,7 +1546,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             const FeedAddr ad = feed_addr(b, (t + 1) & 1);
             if (t + 1 < p.T) fetch_pre0(b, tag + 1u);
             // ---- wait for the accumulated skip vector of (b, t) -----------------------------------------------
-            if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.flags[0] = 1;
+            if (!(SPLIT ? head_recv_skip_split(p, b, tag, s.vs, tid, lane, wave) : head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave))) s.flags[0] = 1;
             __syncthreads();
             WNV_TS(1);
             float pt = 0.f, ps = 0.f;
@@ -1438,9 +1732,31 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
     }
 }
 
-template <int NK, bool L0>
+template <int NK, bool L0, bool SPLIT>
 __device__ __forceinline__ void ring_body(const RingParams& p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if constexpr (SPLIT) {
+        // split rings (see run_stage_split): block b on XCD b % 8, slot b / 8; ring r = XCDs 2r (head, stages 1 .. sA) and 2r + 1
+        if ((int)blockIdx.x >= p.ring_blocks) {
+            const int k = (int)blockIdx.x - p.ring_blocks;
+            if (k < p.tap_parts * p.L) run_tap(p, k % p.L, k / p.L, smem);
+            return;
+        }
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, ring = xcd >> 1;
+        if (ring >= p.n_rings) return;
+        if ((xcd & 1) == 0) {
+            if (slot == 0) { run_head<NK, true, true>(p, ring, smem); return; }
+            const int stage = 1 + ((slot - 1) >> 1), half = (slot - 1) & 1;
+            if (stage > p.sA) return;
+            if (stage == 1) run_stage_split<true>(p, ring, stage, half, smem);
+            else run_stage_split<false>(p, ring, stage, half, smem);
+        } else {
+            const int stage = p.sA + 1 + (slot >> 1), half = slot & 1;
+            if (stage >= p.S) return;
+            run_stage_split<false>(p, ring, stage, half, smem);
+        }
+        return;
+    } else {
     const int P = p.S + p.NH;                   // workgroups of one ring: S stages + NH head parts
     // block i -> XCD i % 8 (observed, speed only): with rstride == 8 every workgroup of ring r sits on XCD r
     // tap workgroup k (layer k % L, part k / L) sits in the k-th block that is not part of a live ring: first the slots of
@@ -1467,16 +1783,19 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
             else run_head_part<NK, 2>(p, ring, pos - p.S, smem);
         }
     } else {
-        if (pos == p.S) run_head<NK, L0>(p, ring, smem);
+        if (pos == p.S) run_head<NK, L0, false>(p, ring, smem);
         else run_head_part<NK, 1>(p, ring, pos - p.S, smem);
+    }
     }
 }
 
 // NK <= 2: capped at 244 VGPRs -- v244 .. v255 are the poll slots (see "POLLS IN RESERVED REGISTERS")
 template <int NK, bool L0>
-__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK, L0>(p); }
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK, L0, false>(p); }
+// split rings: two CUs per layer (scalar-input models with 128 skip channels, up to 8 utterances)
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel_split(const RingParams p) { ring_body<1, true, true>(p); }
 // K = 512: needs the whole register file; polls one load at a time in compiler-allocated registers
-__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4, false>(p); }
+__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4, false, false>(p); }
 
 // Placement census (once per handle): every workgroup of a one-block-per-CU grid reports the XCC it runs on.  The host derives
 // the number of XCDs and checks the block -> XCD mapping the ring layout relies on (block b on XCD b % n_xcd, observed; HIP
@@ -1499,7 +1818,8 @@ struct WnvRingState {
     int L = 0, S = 0, K = 0, Kp = 0, O = 0, cin = 0, kw = 0, kpre = 0, cin1 = 1;
     float* d_w = nullptr;          // one blob, offsets below (floats)
     size_t o_wn = 0, o_cvec = 0, o_w2 = 0, o_wo = 0, o_bo = 0, o_wpre = 0, o_ws = 0, o_bskip = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0,
-           o_bh2 = 0, o_wf = 0, o_bf = 0, o_l0 = 0;
+           o_bh2 = 0, o_wf = 0, o_bf = 0, o_l0 = 0, o_w2s = 0, o_wns = 0, o_wos = 0, o_wss = 0;
+    bool has_split = false;        // split-ring images present (scalar input, 128 skip channels)
     int* d_dil = nullptr;
     int* d_histoff = nullptr;
     int hist_floats = 0;
@@ -1596,6 +1916,28 @@ static void put_row8g(std::vector<float>& blob, size_t off, const float* M, int 
     }
 }
 
+// split rings (run_stage_split): wave-group row image of HALF h of a (256 x 128) matrix: group thread gtid (ks = gtid & 7, og = gtid >> 3)
+// keeps local channel 2og + (ks >= 4) in slots 0-1 {tanh, sigmoid} and holds the other one of the pair in slots 2-3;
+// laid out [chunk 4][256 threads][4]
+static void put_row4s(std::vector<float>& blob, size_t off, const float* M, int half, int slot) {
+    for (int gtid = 0; gtid < GT; ++gtid) {
+        const int ks = gtid & 7, og = gtid >> 3, hi = ks >= 4 ? 1 : 0;
+        const int lc = 2 * og + ((slot >> 1) == 0 ? hi : 1 - hi);
+        const float* src = M + (size_t)(((slot & 1) ? RC : 0) + 64 * half + lc) * RC + 16 * ks;
+        for (int c = 0; c < 4; ++c)
+            for (int e = 0; e < 4; ++e) blob[off + ((size_t)c * GT + gtid) * 4 + e] = src[4 * c + e];
+    }
+}
+// ... and of the K-half [64 h, 64 h + 64) of a (128 x 128) matrix for the work behind the send: thread tid (row r = tid >> 2, kq = tid & 3)
+// holds M[r][64 h + 16 kq .. + 16); laid out [chunk 4][512 threads][4]
+static void put_rowq(std::vector<float>& blob, size_t off, const float* M, int half) {
+    for (int tid = 0; tid < RT; ++tid) {
+        const float* src = M + (size_t)(tid >> 2) * RC + 64 * half + 16 * (tid & 3);
+        for (int c = 0; c < 4; ++c)
+            for (int e = 0; e < 4; ++e) blob[off + ((size_t)c * RT + tid) * 4 + e] = src[4 * c + e];
+    }
+}
+
 wnv_status wnv_placement_census(int device, int* ncu_out, int* n_xcd_out, bool* map_ok_out, std::string& err) {
     int ncu = 0;
     RING_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device));
@@ -1653,6 +1995,13 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     st->o_wpre = alloc((size_t)L * st->kpre * GC);
     st->o_ws = alloc((size_t)L * NK * 8 * RT * 4);
     st->o_bskip = alloc((size_t)L * Kp);
+    st->has_split = c.scalar_input && NK == 1;
+    if (st->has_split) {
+        st->o_w2s = alloc((size_t)L * 2 * 4 * 4 * GT * 4);
+        st->o_wns = alloc((size_t)L * 2 * 4 * 4 * GT * 4);
+        st->o_wos = alloc((size_t)L * 2 * 4 * RT * 4);
+        st->o_wss = alloc((size_t)L * 2 * 4 * RT * 4);
+    }
     std::vector<int> dil(L), hoff(L);
     int hist = 0;
     const int per = L / c.stacks;
@@ -1695,6 +2044,14 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
         const std::vector<float> wo = padded(T(pfx + "conv1x1_out.weight").data.data(), Ra, Gha, RC, RC);          // (R, G/2, 1)
         put_row8(blob, st->o_wo + ((size_t)l * 2 + 0) * rowsz, wo.data(), 0, 0);
         put_row8(blob, st->o_wo + ((size_t)l * 2 + 1) * rowsz, wo.data(), 0, 1);
+        if (st->has_split)
+            for (int half = 0; half < 2; ++half) {
+                for (int slot = 0; slot < 4; ++slot) {
+                    put_row4s(blob, st->o_w2s + (((size_t)l * 2 + half) * 4 + slot) * (rowsz / 2), mmat.data(), half, slot);
+                    if (l > 0) put_row4s(blob, st->o_wns + (((size_t)l * 2 + half) * 4 + slot) * (rowsz / 2), nmat.data(), half, slot);
+                }
+                put_rowq(blob, st->o_wos + ((size_t)l * 2 + half) * rowsz, wo.data(), half);
+            }
         const HostTensor& bo = T(pfx + "conv1x1_out.bias");
         std::copy(bo.data.begin(), bo.data.end(), blob.begin() + st->o_bo + (size_t)l * RC);
         // deferred: older taps (oldest first) then local conditioning, K-major [kpre][256]
@@ -1714,6 +2071,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
             put_row8(blob, st->o_ws + (((size_t)l * NK + pp) * 2 + 0) * rowsz, ws.data(), RC * pp, 0);
             put_row8(blob, st->o_ws + (((size_t)l * NK + pp) * 2 + 1) * rowsz, ws.data(), RC * pp, 1);
         }
+        if (st->has_split)
+            for (int half = 0; half < 2; ++half) put_rowq(blob, st->o_wss + ((size_t)l * 2 + half) * rowsz, ws.data(), half);
         const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
         std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bskip + (size_t)l * Kp);
         dil[l] = 1 << (l % per);
@@ -1855,6 +2214,22 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         n_rings = rings_that_fit(1);
     }
     if (n_rings < 1) { err = "ring kernel: not enough CUs per XCD for one ring + the tap workgroups"; return WNV_ERR_UNSUPPORTED; }
+    // SPLIT RINGS (run_stage_split): two CUs per layer, 4 rings over 2 XCDs each -- up to 8 utterances of a scalar-input model with 128
+    // skip channels whose head evaluates layer 0.  XCD 2r: head + both halves of stages 1 .. sA; XCD 2r + 1: stages sA + 1 .. S - 1;
+    // the tap workgroups follow behind the rings, round-robin over the XCDs.
+    // MEASURED AND NOT THE DEFAULT (round 3, profiles/r03_ring_split_*): the mat-vec phases shrink as predicted (chain phase 301 -> 226 ns,
+    // N phase 290 -> 215 ns) but every hand-off now waits for the slower of two CUs, twice as many pollers share the lines, and the
+    // ring crosses XCDs (u, the residual partials and the skip sums: 0.5-0.8 us each): 441-453 against 472-479 kSamples/s on one box.
+    // WNV_RING_SPLIT=1 selects it (parity-tested: tests/test_gpu_ring.py::test_split_rings_vs_oracle_and_generic).
+    bool split = false;
+    { const char* e = getenv("WNV_RING_SPLIT"); if (e && e[0] == '1') split = head_l0 && st->has_split && st->S >= 3 && B <= 16; }
+    int sA = 0, max_slots = 0;
+    if (split) {
+        sA = (2 * (st->S - 1) + 1) / 4;
+        max_slots = std::max(1 + 2 * sA, 2 * (st->S - 1 - sA));
+        if (max_slots + (st->L + 7) / 8 > cus_per_xcd) split = false;
+    }
+    if (split) { n_rings = std::min(B, 4); tap_parts = 1; }
     const int upr = (B + n_rings - 1) / n_rings;
     // Block b lands on XCD b % 8 (observed): a ring stride of 8 keeps every workgroup of a ring on one XCD, which the
     // kernel verifies at run time before it uses the same-XCD hand-off.  The grid always has 8 ring slots; the
@@ -1867,6 +2242,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.dist = c.output_distribution;
     p.cin1 = st->cin1; p.softmax = ga.softmax; p.quantize = ga.quantize; p.index_out = ga.index_out;
     p.head_l0 = head_l0 ? 1 : 0;
+    p.split = split ? 1 : 0; p.sA = sA; p.qh = split ? 2 : 1;
     p.pstride = std::max(GC, st->Kp);
     p.hist_floats = st->hist_floats;
     p.skip_scale = (float)std::sqrt(1.0 / st->L);
@@ -1875,6 +2251,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.w2img = w + st->o_w2; p.wnimg = w + st->o_wn; p.cvec = w + st->o_cvec; p.woimg = w + st->o_wo; p.bo = w + st->o_bo; p.wpre = w + st->o_wpre;
     p.wsimg = w + st->o_ws; p.bskip = w + st->o_bskip; p.wh1img = w + st->o_wh1; p.bh1 = w + st->o_bh1;
     p.wh2img = w + st->o_wh2; p.bh2 = w + st->o_bh2; p.wfirst = w + st->o_wf; p.bfirst = w + st->o_bf; p.l0vec = w + st->o_l0;
+    p.w2s = w + st->o_w2s; p.wns = w + st->o_wns; p.wos = w + st->o_wos; p.wss = w + st->o_wss;
     p.zbias = ga.zbias; p.zbias_bstride = ga.zbias_bstride;
     p.zb_ld = (c.gate_channels + 3) & ~3; p.gh = c.gate_channels / 2;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
@@ -1885,7 +2262,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t n_f = (size_t)B * st->L * (4 + RC), n_p = (size_t)B * st->L * (4 + GC);   // stage <-> tap-workgroup bulk records (floats)
     const size_t n_o = (size_t)B * NK * p.Op;                      // partial head outputs of parts 1 .. NK-1
     const size_t n_z = (size_t)B * GC;                             // N_1 h_0 from the head (head_l0)
-    const size_t mail_bytes = (5 * n_h + n_s + n_o + n_z) * sizeof(u64) + (n_f + n_p) * sizeof(float);
+    const size_t qh = split ? 2 : 1;                               // split rings: two partial vectors per residual / skip slot
+    const size_t mail_bytes = (n_h + 2 * n_h * qh + 2 * n_h + n_s * qh + n_o + n_z) * sizeof(u64) + (n_f + n_p) * sizeof(float);
     const size_t hist_bytes = (size_t)B * st->hist_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -1913,9 +2291,9 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.xcc = (unsigned int*)(base + 64);
     p.xmail = (u64*)(base + head_bytes);
     p.hmail = p.xmail + n_h;
-    p.gmail = p.hmail + 2 * n_h;
+    p.gmail = p.hmail + 2 * n_h * qh;
     p.smail = p.gmail + 2 * n_h;
-    p.omail = p.smail + n_s;
+    p.omail = p.smail + n_s * qh;
     p.zmail = p.omail + n_o;
     p.fmail = (float*)(p.zmail + n_z);
     p.pmail = p.fmail + n_f;
@@ -1928,15 +2306,16 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.kreg_rows = std::min(p.kper, KR_MAX);
     p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);                      // multiples of 4 (kper is one)
     while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 150 * 1024) p.klds_rows -= 4;
-    p.ring_blocks = rstride * P;
+    p.ring_blocks = split ? 8 * max_slots : rstride * P;
     const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
                                 st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
-    const void* kfn = NK == 1 ? (head_l0 ? (const void*)wnv_ring_kernel<1, true> : (const void*)wnv_ring_kernel<1, false>)
+    const void* kfn = split ? (const void*)wnv_ring_kernel_split
+                    : NK == 1 ? (head_l0 ? (const void*)wnv_ring_kernel<1, true> : (const void*)wnv_ring_kernel<1, false>)
                               : NK == 2 ? (const void*)wnv_ring_kernel<2, false> : (const void*)wnv_ring_kernel_k512;
     RING_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.tap_parts = tap_parts;
-    const int grid = p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);
+    const int grid = split ? p.ring_blocks + tap_parts * st->L : p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);
     if (p.ring_blocks > ncu) { err = "ring kernel: too many layers for one ring per XCD"; return WNV_ERR_UNSUPPORTED; }
     // every LIVE workgroup must be resident at once (they wait for each other): ask the runtime how many fit a CU with this
     // register / LDS footprint instead of assuming one, and compare with what stays alive (the workgroups of unused ring slots
@@ -1944,7 +2323,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     {
         int per_cu = 0;
         RING_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, RT, lds));
-        const int live = n_rings * Plive + tap_parts * st->L;
+        const int live = (split ? n_rings * (1 + 2 * (st->S - 1)) : n_rings * Plive) + tap_parts * st->L;
         if (per_cu < 1 || live > ncu * per_cu) {
             char buf[160];
             snprintf(buf, sizeof buf, "ring kernel: %d workgroups must be co-resident but the device holds %d (%d CUs x %d per CU)", live,
@@ -1973,7 +2352,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
         p.trace_tap = d_trace + (size_t)trace_n * upr * (st->S + 1) * TRW;
     }
-    if (NK == 1 && head_l0) hipLaunchKernelGGL((wnv_ring_kernel<1, true>), dim3(grid), dim3(RT), lds, stream, p);
+    if (split) hipLaunchKernelGGL(wnv_ring_kernel_split, dim3(grid), dim3(RT), lds, stream, p);
+    else if (NK == 1 && head_l0) hipLaunchKernelGGL((wnv_ring_kernel<1, true>), dim3(grid), dim3(RT), lds, stream, p);
     else if (NK == 1) hipLaunchKernelGGL((wnv_ring_kernel<1, false>), dim3(grid), dim3(RT), lds, stream, p);
     else if (NK == 2) hipLaunchKernelGGL((wnv_ring_kernel<2, false>), dim3(grid), dim3(RT), lds, stream, p);
     else hipLaunchKernelGGL(wnv_ring_kernel_k512, dim3(grid), dim3(RT), lds, stream, p);
