@@ -996,7 +996,12 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                     } else if (pp < NLDS) {
                         m0 = dot16l(s.wsk + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(s.wsk + (size_t)(8 * pp + 4) * RT + tid, xu);
                     } else {                                                    // streams from the L2 (image layout: coalesced 16-B loads)
-                        m0 = dot16l(wsk_g + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(wsk_g + (size_t)(8 * pp + 4) * RT + tid, xu);
+                        // (the pass's base is wave-uniform: kept in SGPRs -- as eight per-lane 64-bit pointers it cost the K = 512
+                        //  instantiation 22 spilled registers and a scratch reload in front of every load)
+                        const unsigned long long sb = reinterpret_cast<unsigned long long>(wsk_g + (size_t)(8 * pp) * RT);
+                        const float4* ub = reinterpret_cast<const float4*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)) << 32) |
+                                                                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb));
+                        m0 = dot16l(ub + tid, xu); m1 = dot16l(ub + (size_t)4 * RT + tid, xu);
                     }
                     const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + (pp == 0 ? bs_r : s.bsk[RC * pp + ch]);
                     float acc = 0.f;
