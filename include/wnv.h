@@ -175,8 +175,11 @@ typedef struct wnv_generate_args {
 /* kernel == 0 ("auto") picks the ring kernel when it covers the configuration (wnv_ring_why_not) AND the device can keep
  * its grid resident (occupancy query x CU count, one ring per XCD as measured by a placement census at load time);
  * otherwise, or when a ring launch ends in WNV_ERR_TIMEOUT (CUs masked or taken by another process: the workgroups
- * were not co-resident), the call is served by the generic kernel, the reason goes to stderr once, and the handle stays
- * on the generic kernel.  An explicit kernel == 2 reports the error instead. */
+ * were not co-resident), the call is served by the generic kernel and the reason goes to stderr.  "Cannot run here"
+ * (WNV_ERR_UNSUPPORTED) keeps the handle on the generic kernel; after a time-out the persistent kernel is tried again
+ * once 2 further calls have been served by the generic kernel (4, 8, ... 32 after consecutive time-outs; wnv_reset() makes
+ * the next call try at once).  An explicit kernel == 2 reports the error instead.  WNV_GEN_ASYNC needs kernel == 2 and at
+ * most 64 utterances (larger batches are run as several launches of 64). */
 wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* args);
 /* Waits for the handle's last WNV_GEN_ASYNC launch and returns its status (WNV_OK when nothing is pending).  Synchronous. */
 wnv_status wnv_wait(wnv_handle h);

@@ -44,7 +44,7 @@ def test_ring_teacher_forced_vs_oracle(name):
     assert_match_or_near_tie(out.cpu(), want, wparams, tape, kw, tol=TOL)
 
 
-@pytest.mark.parametrize("B", [1, 2, 5, 8, 11, 16, 24, 37])
+@pytest.mark.parametrize("B", [1, 2, 5, 8, 11, 16, 24, 37, 100])     # (100: two launches of 64 + 36)
 def test_ring_equals_generic_kernel(B):
     name = "cfg2_mol"
     kw = CONFIGS[name]

@@ -43,8 +43,12 @@ struct wnv_engine {
     Scratch ring, zbias, upA, upB, fwd;
     WnvRingState* ring_state = nullptr;   // pipelined kernel (wnv_ring.hip), built lazily
     WnvWideState* wide_state = nullptr;   // group-ring kernel for wide models (wnv_wide.hip), built lazily
-    bool wide_disabled = false;
-    bool ring_disabled = false;           // auto mode: a ring launch timed out on this device (workgroups not co-resident)
+    bool wide_disabled = false;           // auto mode: the persistent kernel cannot run on this device (WNV_ERR_UNSUPPORTED: permanent)
+    bool ring_disabled = false;
+    // auto mode after a WNV_ERR_TIMEOUT (the workgroups were not co-resident: CUs masked, or taken by somebody else for a moment):
+    // the next `cooldown` calls are served by the generic kernel, then the persistent kernel is tried again; every further time-out
+    // doubles the pause (2, 4, ... 32 calls), a launch that completes clears it, wnv_reset() makes the next call try at once
+    int persist_cooldown = 0, persist_backoff = 0;
     int last_kernel = 0;                  // 1 generic, 2 ring: what served the last wnv_generate
 };
 
@@ -182,12 +186,13 @@ extern "C" wnv_status wnv_create(const wnv_config* cfg, int32_t device, wnv_hand
 }
 
 static void free_dev(wnv_engine* h) {
+    // (first: wnv_ring_destroy waits for a pending asynchronous launch, which still reads the handle's buffers)
+    if (h->ring_state) { wnv_ring_destroy(h->ring_state); h->ring_state = nullptr; }
+    if (h->wide_state) { wnv_wide_destroy(h->wide_state); h->wide_state = nullptr; }
     if (h->d_W) (void)hipFree(h->d_W);
     if (h->d_layers) (void)hipFree(h->d_layers);
     if (h->d_up) (void)hipFree(h->d_up);
     h->d_W = nullptr; h->d_layers = nullptr; h->d_up = nullptr;
-    if (h->ring_state) { wnv_ring_destroy(h->ring_state); h->ring_state = nullptr; }
-    if (h->wide_state) { wnv_wide_destroy(h->wide_state); h->wide_state = nullptr; }
     h->packed = false;
 }
 
@@ -218,6 +223,7 @@ extern "C" wnv_status wnv_reset(wnv_handle h) {
     const wnv_status deferred = wnv_wait(h);                // a pending WNV_GEN_ASYNC launch reports here
     HIP_TRY(hipDeviceSynchronize());
     h->ring.release(); h->zbias.release(); h->upA.release(); h->upB.release(); h->fwd.release();
+    h->persist_cooldown = 0;                                // a persistent kernel that timed out is tried again by the next call
     return deferred;
 }
 
@@ -451,6 +457,11 @@ extern "C" wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* a) {
     if (const char* why = wnv_forward_why_not(m)) return fail(WNV_ERR_UNSUPPORTED, "the MFMA forward kernel does not cover this configuration: %s", why);
     DeviceGuard g(h->device);
     hipStream_t s = (hipStream_t)a->stream;
+    if (h->ring_state) {                                             // the bias table is shared with a pending asynchronous generation
+        std::string err;
+        const wnv_status pst = wnv_ring_wait(h->ring_state, err);
+        if (pst != WNV_OK) return fail(pst, "deferred from the previous asynchronous call: %s", err.c_str());
+    }
     const bool has_g = m.gin > 0;
     const int Bz = has_g ? a->B : 1;
     HIP_TRY(h->zbias.ensure((size_t)Bz * m.L * m.Gp * sizeof(float)));
@@ -517,8 +528,16 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     if (a->g_ids && !a->g && h->embed_off < 0) return fail(WNV_ERR_INVALID_ARG, "g_ids given but the model has no speaker embedding");
     if (a->Tt < 0 || a->Tt > a->T || (a->Tt > 0 && !a->teacher)) return fail(WNV_ERR_INVALID_ARG, "bad teacher-forcing arguments");
     if (a->kernel < 0 || a->kernel > 3) return fail(WNV_ERR_INVALID_ARG, "unknown kernel selector %d", a->kernel);
+    if ((a->flags & WNV_GEN_ASYNC) && a->kernel != 2) return fail(WNV_ERR_INVALID_ARG, "WNV_GEN_ASYNC needs kernel = 2 (the ring kernel chosen explicitly: auto mode must see the launch's status to fall back)");
+    if ((a->flags & WNV_GEN_ASYNC) && a->B > 64) return fail(WNV_ERR_INVALID_ARG, "WNV_GEN_ASYNC takes at most 64 utterances per call (larger batches run as several launches)");
     DeviceGuard g(h->device);
     hipStream_t s = (hipStream_t)a->stream;
+    // a pending asynchronous launch reads the handle's scratch (the bias table below) on every step: it reports -- and ends -- first
+    if (h->ring_state) {
+        std::string err;
+        const wnv_status pst = wnv_ring_wait(h->ring_state, err);
+        if (pst != WNV_OK) return fail(pst, "deferred from the previous asynchronous call: %s", err.c_str());
+    }
     const bool has_g = m.gin > 0;
     const int Bz = has_g ? a->B : 1;
     HIP_TRY(h->zbias.ensure((size_t)Bz * m.L * m.Gp * sizeof(float)));
@@ -539,16 +558,14 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     // asynchronous ring launches only when the caller chose the ring explicitly: auto mode must see the status to fall back
     ga.async = (a->flags & WNV_GEN_ASYNC) && a->kernel == 2;
 
-    if (h->ring_state) {                                             // a pending asynchronous launch reports first
-        std::string err;
-        const wnv_status pst = wnv_ring_wait(h->ring_state, err);
-        if (pst != WNV_OK) return fail(pst, "deferred from the previous asynchronous call: %s", err.c_str());
-    }
     int kernel = a->kernel;
     if (kernel == 0) {
+        // (the ring kernel takes any batch -- more than 64 utterances run in slices --, so the group ring is only for models that
+        //  exceed the ring's geometry)
         if (!h->ring_disabled && wnv_ring_supported(c, a->B) && wnv_ring_default()) kernel = 2;
         else if (!h->wide_disabled && !wnv_ring_supported(c, a->B) && wnv_wide_supported(c, a->B) && wnv_ring_default()) kernel = 3;
         else kernel = 1;
+        if (kernel != 1 && h->persist_cooldown > 0) { --h->persist_cooldown; kernel = 1; }     // pausing after a time-out (see wnv_engine)
     }
     if (kernel == 3) {                     // wide models: one GROUP of 8 workgroups per layer (wnv_wide.hip); same fallback rules as the ring
         if (!wnv_wide_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the group-ring kernel does not cover this configuration: %s", wnv_wide_why_not(c, a->B));
@@ -559,33 +576,44 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
             TurnGuard turn(h->device, s);
             st = wnv_wide_generate(&h->wide_state, h->device, c, h->store, ga, s, err);
         }
-        if (st == WNV_OK) { h->last_kernel = 3; return WNV_OK; }
+        if (st == WNV_OK) { h->last_kernel = 3; h->persist_backoff = 0; return WNV_OK; }
         const bool recoverable = st == WNV_ERR_UNSUPPORTED || st == WNV_ERR_TIMEOUT;
         if (!(a->kernel == 0 && recoverable)) return fail(st, "%s", err.c_str());
-        h->wide_disabled = true;
-        fprintf(stderr, "[wnv] device %d: the group-ring kernel %s (%s); this handle now uses the generic kernel\n", h->device,
-                st == WNV_ERR_TIMEOUT ? "timed out" : "cannot run here", err.c_str());
+        if (st == WNV_ERR_TIMEOUT) {
+            h->persist_backoff = h->persist_backoff ? std::min(2 * h->persist_backoff, 32) : 2;
+            h->persist_cooldown = h->persist_backoff;
+            fprintf(stderr, "[wnv] device %d: the group-ring kernel timed out (%s); its workgroups were not co-resident -- this call and the next %d "
+                            "are served by the generic kernel, then it is tried again\n", h->device, err.c_str(), h->persist_cooldown);
+        } else {
+            h->wide_disabled = true;
+            fprintf(stderr, "[wnv] device %d: the group-ring kernel cannot run here (%s); this handle now uses the generic kernel\n", h->device, err.c_str());
+        }
     }
     if (kernel == 2) {
         if (!wnv_ring_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the pipelined ring kernel does not cover this configuration: %s", wnv_ring_why_not(c, a->B));
         HIP_TRY(zero_onehot_out());
         std::string err;
         wnv_status st;
-        {
+        if (a->kernel == 0 && std::getenv("WNV_INJECT_TIMEOUT")) {   // diagnostic knob: exercises the time-out policy below without
+            st = WNV_ERR_TIMEOUT;                                     // a device that cannot keep the launch resident
+            err = "injected by WNV_INJECT_TIMEOUT";                   // (tests/test_gpu_zz_boundary.py; the real thing: the CU-mask tests)
+        } else {
             TurnGuard turn(h->device, s);
             st = wnv_ring_generate(&h->ring_state, h->device, c, h->store, ga, s, err);
         }
-        if (st == WNV_OK) { h->last_kernel = 2; return WNV_OK; }
+        if (st == WNV_OK) { h->last_kernel = 2; h->persist_backoff = 0; return WNV_OK; }
         // auto mode: a device that cannot host the persistent pipeline (fewer CUs than one ring + its tap workgroups per XCD, a
         // partitioned GPU: WNV_ERR_UNSUPPORTED from the occupancy / placement checks) or did not keep it co-resident (CUs masked
-        // or busy with another process: WNV_ERR_TIMEOUT after the bounded spins) is served by the generic kernel; the handle
-        // stays on it.  An explicit kernel = 2 reports the reason instead.
+        // or busy with another process: WNV_ERR_TIMEOUT after the bounded spins) is served by the generic kernel.  UNSUPPORTED is
+        // permanent for the handle; after a TIMEOUT the persistent kernel is tried again after a pause that doubles with every
+        // consecutive time-out (persist_cooldown).  An explicit kernel = 2 reports the reason instead.
         const bool recoverable = st == WNV_ERR_UNSUPPORTED || st == WNV_ERR_TIMEOUT;
         if (!(a->kernel == 0 && recoverable)) return fail(st, "%s", err.c_str());
         if (st == WNV_ERR_TIMEOUT) {
-            h->ring_disabled = true;
+            h->persist_backoff = h->persist_backoff ? std::min(2 * h->persist_backoff, 32) : 2;
+            h->persist_cooldown = h->persist_backoff;
             fprintf(stderr, "[wnv] device %d: the pipelined ring kernel timed out (%s); its workgroups were not co-resident -- "
-                            "this handle now uses the generic kernel\n", h->device, err.c_str());
+                            "this call and the next %d are served by the generic kernel, then it is tried again\n", h->device, err.c_str(), h->persist_cooldown);
         } else if (!h->ring_disabled) {
             h->ring_disabled = true;
             fprintf(stderr, "[wnv] device %d: the pipelined ring kernel cannot run here (%s); using the generic kernel\n", h->device, err.c_str());

@@ -89,6 +89,7 @@ struct RingParams {
     float* hist;
     const float *c_up, *initial, *teacher, *noise;
     unsigned long long seed;
+    int b0, noise_B;                   // this launch is utterances [b0, b0 + B) of a call of noise_B (noise tape / Philox stream addressing)
     float *out, *params_out;
     unsigned int* status;
     unsigned long long* trace;         // optional [T_trace][upr][S+1][16] wall-clock stamps of ring 0's utterances (debug)
@@ -1305,7 +1306,7 @@ __host__ __device__ constexpr size_t head_lds_floats(int NK) { return (size_t)GC
 
 // noise value `idx` of (t, b): from the tape (rng = "replay") or the in-kernel Philox stream
 __device__ __forceinline__ float head_noise(const RingParams& p, int t, int b, int idx, int kind) {
-    return p.noise ? p.noise[((size_t)t * p.B + b) * p.nz + idx] : wnv_noise_gen(p.seed, t, b, idx, kind);
+    return p.noise ? p.noise[((size_t)t * p.noise_B + p.b0 + b) * p.nz + idx] : wnv_noise_gen(p.seed, t, p.b0 + b, idx, kind);
 }
 
 // the slice of the output MLP one head part owns: W1 rows [128 part, +128) x K and W2[:, 128 part .. +128) (NW2 row images: rows i,
@@ -1851,7 +1852,6 @@ static const char* why_not(const wnv_config& c, int B) {
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 512 - (c.kernel_size - 1) * RC) return "too many local-conditioning channels";
     { int nk = (c.skip_out_channels + 127) / 128; if (nk == 3) nk = 4; if (c.layers + nk > 32) return "too many layers for one ring per XCD"; }
-    if (B > 64) return "more than 64 utterances per call";
     return nullptr;
 }
 bool wnv_ring_supported(const wnv_config& c, int B) { return why_not(c, B) == nullptr; }
@@ -1864,11 +1864,11 @@ const char* wnv_ring_why_not(const wnv_config& c, int B) { const char* w = why_n
 
 void wnv_ring_destroy(WnvRingState* st) {
     if (!st) return;
+    if (st->pending) (void)hipStreamSynchronize(st->pending_stream);   // an asynchronous launch still reads all of the below
     if (st->d_w) (void)hipFree(st->d_w);
     if (st->d_dil) (void)hipFree(st->d_dil);
     if (st->d_histoff) (void)hipFree(st->d_histoff);
     if (st->d_state) (void)hipFree(st->d_state);
-    if (st->pending) (void)hipStreamSynchronize(st->pending_stream);
     if (st->h_status) (void)hipHostFree(st->h_status);
     delete st;
 }
@@ -2179,6 +2179,28 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         if (st0 != WNV_OK) { wnv_ring_destroy(*pst); *pst = nullptr; return st0; }
     }
     WnvRingState* st = *pst;
+    constexpr int BSLICE = 64;                                       // utterances one launch pipelines through its rings
+    if (ga.B > BSLICE) {
+        // larger batches: slices of 64, one launch each (utterances are independent; the noise tape and the Philox stream are
+        // addressed with the utterance's index in the whole call, so the samples do not depend on the slicing)
+        const int cin1 = st->cin1, cin = st->cin, O = st->O;
+        for (int b0 = 0; b0 < ga.B; b0 += BSLICE) {
+            WnvGenArgs g = ga;
+            g.B = std::min(BSLICE, ga.B - b0);
+            g.b0 = ga.b0 + b0; g.noise_B = ga.noise_B > 0 ? ga.noise_B : ga.B;
+            g.async = 0;
+            if (ga.c_up) g.c_up = ga.c_up + (size_t)b0 * ga.T * cin;
+            if (ga.initial) g.initial = ga.initial + (size_t)b0 * cin1;
+            if (ga.teacher) g.teacher = ga.teacher + (size_t)b0 * ga.Tt * cin1;
+            if (ga.zbias_bstride != 0) g.zbias = ga.zbias + (size_t)b0 * ga.zbias_bstride;
+            g.out = ga.out + (size_t)b0 * cin1 * ga.T;
+            if (ga.params_out) g.params_out = ga.params_out + (size_t)b0 * O * ga.T;
+            if (ga.index_out) g.index_out = ga.index_out + (size_t)b0 * ga.T;
+            const wnv_status s0 = wnv_ring_generate(pst, device, c, store, g, stream, err);
+            if (s0 != WNV_OK) return s0;
+        }
+        return WNV_OK;
+    }
     const int B = ga.B;
     { std::string perr; wnv_status pst = wnv_ring_wait(st, perr); if (pst != WNV_OK) { err = perr; return pst; } }
     const int ncu = st->ncu, NX = st->n_xcd;
@@ -2304,6 +2326,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.pmail = p.fmail + n_f;
     p.hist = p.pmail + n_p;
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
+    p.b0 = ga.b0; p.noise_B = ga.noise_B > 0 ? ga.noise_B : B;
     p.out = ga.out; p.params_out = ga.params_out;
     // LDS: the stage carve is the larger one
     // tap workgroups: K rows per wave (a multiple of 4), first in VGPRs, then in LDS, the remainder streams from L2

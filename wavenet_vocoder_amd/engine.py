@@ -228,6 +228,11 @@ class Engine:
         """Status of the last asynchronous launch (raises TimeoutError if a bounded in-kernel wait gave up)."""
         check(_lib.lib().wnv_wait(self._h))
 
+    def reset_buffers(self) -> None:
+        """``wnv_reset``: waits for the device, frees the handle's scratch buffers (they are re-grown on demand) and lets a persistent
+        kernel that timed out be tried again by the very next call (include/wnv.h).  The weights stay loaded."""
+        check(_lib.lib().wnv_reset(self._h))
+
     def last_kernel(self) -> int:
         """1 = generic kernel, 2 = pipelined ring kernel served the last ``generate`` (0: none yet)."""
         return int(_lib.lib().wnv_last_kernel(self._h))
