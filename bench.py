@@ -175,28 +175,49 @@ def dry_run(args, world, rank):
         tt = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    ranks = rank_report(dist, torch.device("cpu"), 2.0 * (1 + rank), 2)          # (the same gather as the real run; "kernel" 2 = ring)
     if rank == 0:
         print(json.dumps({"metric": "audio kSamples/sec (24 kHz MoL egs/mol, batch=8 per GPU), whole job", "value": 0.0,
                           "unit": "kSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
                           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)", "dry_run": True,
-                          "config": {"workload": f"{args.workload} dry run, B={B} x T={T}", "parallelism": f"utterance-sharded x{world}"}}),
+                          "config": {"workload": f"{args.workload} dry run, B={B} x T={T}", "parallelism": f"utterance-sharded x{world}"},
+                          "ranks": ranks}),
               flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return 0
 
 
-def latency_floor_us(kw, n_head_parts=1):
-    """Serial-chain floor of the one-layer-per-CU design, from the committed microbenchmarks: per layer one same-XCD CU -> CU
-    hop (profiles/ubench/hop2.txt: 0.444 us, plain store -> sc1 poll, whatever the store flavour) + the on-chain G x G/2 mat-vec at
-    the CU's fp32 FMA peak (128 FMA/clk at 2.4 GHz: 256 x 128 MACs = 0.107 us); head: the skip hop and the first_conv hop + the
-    K x K and O x K mat-vecs at the same FMA peak (+ one more hop when the head is split over several workgroups)."""
-    hop, fma_per_us = 0.444, 128 * 2400.0
+def latency_floor_us(kw, n_head_parts=1, hop=0.276):
+    """Serial-chain floor of the one-layer-per-CU design, from the committed microbenchmarks: per stage on the chain one same-XCD
+    CU -> CU hop + the on-chain G x G/2 mat-vec at the CU's fp32 FMA peak (128 FMA/clk at 2.4 GHz: 256 x 128 MACs = 0.107 us); head:
+    the skip hop and the hop to the first stage + the K x K and O x K mat-vecs at the same FMA peak (+ one more hop when the head is
+    split over several workgroups).  `hop`: 0.276 us = the BEST same-XCD ping-pong the microbenchmarks reach in the ring's own
+    configuration (profiles/ubench/hop234_same_box.txt, ubench_hop4: polls in reserved registers); 0.444 us =
+    ubench_hop2, what round 2 quoted.  Scalar-input models with 128 skip channels have one stage less on the chain: the head
+    evaluates layer 0 (two FMAs per channel)."""
+    fma_per_us = 128 * 2400.0
     G, K, O = kw["gate_channels"], kw["skip_out_channels"], kw["out_channels"]
+    stages = kw["layers"] - (1 if kw.get("scalar_input", False) and K <= 128 and kw["layers"] >= 2 else 0)
     layer = hop + (G * (G // 2)) / fma_per_us
     head = 2 * hop + (K * K / max(n_head_parts, 1) + O * K) / fma_per_us + (hop if n_head_parts > 1 else 0.0)
-    return kw["layers"] * layer + head
+    return stages * layer + head
+
+
+def rank_report(dist, dev, kernel_ms, last_kernel):
+    """What every rank ran, gathered on all ranks: a rank that silently fell back to the generic kernel would otherwise hide inside a
+    MAX-reduced time.  Returns {"kernel_ms": [...], "last_kernel": [...]} by rank."""
+    mine = torch.tensor([float(kernel_ms), float(last_kernel)], dtype=torch.float64, device=dev)
+    if dist is None:
+        rows = [mine]
+    else:
+        rows = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(rows, mine)
+    names = {0: "none", 1: "generic", 2: "ring", 3: "group ring"}
+    ms = [round(float(r[0]), 3) for r in rows]
+    return {"kernel_ms_by_rank": ms, "kernel_ms_min": min(ms), "kernel_ms_max": max(ms),
+            "last_kernel_by_rank": [names.get(int(r[1]), "?") for r in rows]}
 
 
 def main():
@@ -273,6 +294,7 @@ def main():
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    ranks = rank_report(dist, dev, sum(kern_ms) / len(kern_ms), eng.last_kernel())
 
     if rank == 0:
         total_samples = world * B * T * args.steps
@@ -292,7 +314,8 @@ def main():
             except Exception:
                 traffic, traffic_src = None, None
         us_step = kdur / T * 1e6
-        floor = latency_floor_us(kw, max(kw["skip_out_channels"] // 128, 1))
+        nparts = max(kw["skip_out_channels"] // 128, 1)
+        floor, floor_hop2 = latency_floor_us(kw, nparts), latency_floor_us(kw, nparts, hop=0.444)
         line = {
             "metric": "audio kSamples/sec (24 kHz MoL egs/mol, batch=8 per GPU), whole job",
             "value": round(value, 3), "unit": "kSamples/s", "n_gpus": world, "steps": args.steps,
@@ -314,8 +337,10 @@ def main():
                              "note": "for reference only: the sample loop does not stream from HBM (traffic << algorithmic bytes)"},
             "roofline_latency": {"bound": "serial chain latency", "floor_us_per_step": round(floor, 3), "achieved_us_per_step": round(us_step, 3),
                                  "frac": round(floor / us_step, 4),
-                                 "model": "L x (CU->CU hop 0.444 us [profiles/ubench/hop2.txt] + on-chain 256x128 mat-vec at the fp32 FMA peak "
-                                          "0.107 us) + head (2 hops + KxK and OxK mat-vecs)"},
+                                 "model": "stages on the chain x (best same-XCD CU->CU hop 0.276 us [profiles/ubench/hop234_same_box.txt, ubench_hop4] + "
+                                          "on-chain 256x128 mat-vec at the fp32 FMA peak 0.107 us) + head (2 hops + KxK and OxK mat-vecs)",
+                                 "floor_us_per_step_hop2_0p444": round(floor_hop2, 3), "frac_hop2_0p444": round(floor_hop2 / us_step, 4)},
+            "ranks": ranks,
         }
         if world == 1 and args.batch == B_PER_GPU and args.workload == WORKLOAD and not args.no_extras:
             # informative only (not `value`): the same kernel with 32 utterances per GPU -- the rings pipeline four

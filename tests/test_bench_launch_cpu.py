@@ -30,6 +30,12 @@ def test_self_launch_prints_one_line_with_n_gpus(n):
     assert j["n_gpus"] == n and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["dry_run"] is True
     # ranks sleep 2 ms x (rank + 1) per step: the reported time is the slowest rank's (MAX over ranks), not rank 0's
     assert j["ms_per_step"] >= 2.0 * n * 0.9
+    # what every rank ran travels in the line too (a rank that fell back to the generic kernel must not hide inside the MAX):
+    # per-rank kernel time and the kernel that served each rank, gathered by the same collective path as the real run
+    rk = j["ranks"]
+    assert rk["last_kernel_by_rank"] == ["ring"] * n
+    assert rk["kernel_ms_by_rank"] == [2.0 * (r + 1) for r in range(n)]
+    assert rk["kernel_ms_min"] == 2.0 and rk["kernel_ms_max"] == 2.0 * n
 
 
 def test_under_torch_distributed_run():

@@ -23,6 +23,34 @@ import torch
 __all__ = ["noise_width", "make_noise_tape"]
 
 _EPS = 1e-5
+_BULK_OK: dict = {}
+
+
+def _bulk_matches_per_step(kind: str) -> bool:
+    """One-time probe per draw kind: does ONE bulk call of this torch build walk the generator's stream exactly like a sequence of
+    per-step calls?  It does wherever the CPU kernels consume the Mersenne-Twister stream element by element (this ROCm build: yes,
+    pinned by tests/test_host_cpu.py) -- a build that routes a distribution through a vectorised library path of its own (MKL VSL)
+    need not.  The probe draws two steps both ways from scratch generators; on a mismatch the tape is drawn step by step."""
+    ok = _BULK_OK.get(kind)
+    if ok is None:
+        g1, g2 = torch.Generator().manual_seed(1234), torch.Generator().manual_seed(1234)
+        if kind == "exponential":
+            a = torch.empty(2, 3, 40).exponential_(1.0, generator=g1)
+            b = torch.stack([torch.empty(3, 40).exponential_(1.0, generator=g2) for _ in range(2)])
+        elif kind == "uniform":
+            a = torch.empty(2, 3 * 11).uniform_(_EPS, 1.0 - _EPS, generator=g1)
+            b = torch.stack([torch.cat([torch.empty(3, 1, 10).uniform_(_EPS, 1.0 - _EPS, generator=g2).reshape(-1),
+                                        torch.empty(3, 1).uniform_(_EPS, 1.0 - _EPS, generator=g2).reshape(-1)]) for _ in range(2)])
+        elif kind == "normal16":
+            a = torch.empty(2, 16, 1).normal_(0.0, 1.0, generator=g1)
+            b = torch.stack([torch.empty(16, 1).normal_(0.0, 1.0, generator=g2) for _ in range(2)])
+        else:                                                      # "normal_strided": batches below 16 through a strided view
+            buf = torch.empty(2 * 5, 2)
+            buf[:, 0].normal_(0.0, 1.0, generator=g1)
+            a = buf[:, 0].reshape(2, 5, 1)
+            b = torch.stack([torch.empty(5, 1).normal_(0.0, 1.0, generator=g2) for _ in range(2)])
+        ok = _BULK_OK[kind] = bool(torch.equal(a.reshape(-1), b.reshape(-1)))
+    return ok
 
 
 def noise_width(scalar_input: bool, output_distribution: str, out_channels: int) -> int:
@@ -55,20 +83,21 @@ def make_noise_tape(T: int, B: int, *, scalar_input: bool, output_distribution: 
     nz = noise_width(scalar_input, output_distribution, out_channels)
     kw = {} if generator is None else {"generator": generator}
     if not scalar_input:
+        per_step = per_step or not _bulk_matches_per_step("exponential")
         if per_step:
             return torch.stack([torch.empty(B, out_channels).exponential_(1.0, **kw) for _ in range(T)]) if T else torch.empty(0, B, nz)
         return torch.empty(T, B, out_channels).exponential_(1.0, **kw)
     mix = nz - 1
     normal = output_distribution == "Normal"
     tape = torch.empty(T, B, nz, dtype=torch.float32)
-    if not per_step and not normal:
+    if not per_step and not normal and _bulk_matches_per_step("uniform"):
         raw = torch.empty(T, B * mix + B).uniform_(_EPS, 1.0 - _EPS, **kw)       # per step: u1 (B, 1, mix) then u2 (B, 1)
         tape[:, :, :mix] = raw[:, :B * mix].view(T, B, mix)
         tape[:, :, mix] = raw[:, B * mix:]
         return tape
-    if not per_step and mix == 0 and B % 16 == 0:
+    if not per_step and mix == 0 and B % 16 == 0 and _bulk_matches_per_step("normal16"):
         return torch.empty(T, B, 1).normal_(0.0, 1.0, **kw)
-    if not per_step and mix == 0 and B < 16 and T > 0:
+    if not per_step and mix == 0 and B < 16 and T > 0 and _bulk_matches_per_step("normal_strided"):
         # per-step calls of fewer than 16 elements take normal_'s element-by-element path (one Box-Muller pair per two values, the
         # second one cached in the generator), and so does a call on a NON-CONTIGUOUS tensor of any size: a strided view makes one
         # bulk draw walk the very same stream (T = 24 064, B = 8: 10 ms instead of 0.1 s of per-step calls)

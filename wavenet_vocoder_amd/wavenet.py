@@ -172,6 +172,13 @@ class WaveNet(EngineHost, nn.Module):
             return False
         if x.size(2) > (1 << 23):                # 31-bit buffer offsets (wnv_forward: WNV_ERR_INVALID_ARG beyond)
             return False
+        if g is not None:
+            # the kernels take ONE global-conditioning vector (or speaker id) per utterance; anything else -- e.g. an external g of
+            # shape (B, gin, T) that varies over time, which the reference's _expand_global_features accepts (wavenet.py:194) --
+            # is evaluated on the torch path, as the reference evaluates it
+            per_utt = x.size(0) * (1 if self.embed_speakers is not None else self.gin_channels)
+            if g.numel() != per_utt:
+                return False
         return x.size(1) == (1 if self.scalar_input else self.out_channels)
 
     def _forward_engine(self, x, c, g, softmax):
