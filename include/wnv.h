@@ -28,13 +28,14 @@
 #ifndef WNV_H_
 #define WNV_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define WNV_ABI_VERSION 2
+#define WNV_ABI_VERSION 3
 #define WNV_MAX_UPSAMPLE_STAGES 8
 
 typedef enum wnv_status {
@@ -162,6 +163,11 @@ typedef struct wnv_generate_args {
                                /* 3 = group ring for wide models (8 workgroups per layer)                */
     int32_t flags;             /* WNV_GEN_* bits                                                         */
     void* stream;
+    const uint32_t* noise_ready; /* ABI 3, optional: a STREAMED tape.  Device-visible address of a counter in coherent host    */
+                               /* memory (wnv_pinned_alloc): steps [0, *noise_ready) of `noise` are valid, the caller keeps   */
+                               /* filling the tape and advancing the counter while the kernel runs; the kernel waits (bounded) */
+                               /* for every step it is about to read.  Needs kernel == 2 and WNV_GEN_ASYNC.  NULL: the whole   */
+                               /* tape is valid at the call.                                                                   */
 } wnv_generate_args;
 
 /* The pipelined ring kernel is a persistent launch whose workgroups wait for each other; every wait is bounded and a
@@ -295,6 +301,19 @@ typedef struct wnv_logmel_args {
     void* stream;
 } wnv_logmel_args;
 wnv_status wnv_logmel(wnv_mel_handle h, const wnv_logmel_args* args);
+
+/* ---- host helpers for a streamed replay tape (ABI 3) -------------------------------------------------
+ * The reference draws its sampling noise from torch's CPU generator inside the loop (wavenet.py:334-335: OneHotCategorical ->
+ * torch.multinomial's exponential race, B x 256 values per step); a replay of that stream is 49 M values for the benchmark batch
+ * of a mu-law model -- longer to draw than the kernel takes to run.  These helpers let the host draw it WHILE the kernel runs. */
+/* Coherent, device-mapped host memory (hipHostMalloc, coherent + mapped): *host_ptr for the CPU, *device_ptr for wnv_generate_args. */
+wnv_status wnv_pinned_alloc(size_t bytes, void** host_ptr, void** device_ptr);
+wnv_status wnv_pinned_free(void* host_ptr);
+/* out[i] = (float)(-log1p(-u[i])), u in [0, 1) double: the transform ATen's CPU exponential_ applies to its uniform draw
+ * (TransformationHelper.h: -1 / lambda * log1p(-u), lambda = 1, computed in double, libm's log1p), on `threads` host threads.
+ * With u = torch.empty(n, dtype=float64).uniform_(0, 1) this reproduces torch.empty(n).exponential_(1) bit for bit and leaves the
+ * generator in the same state (tests/test_host_cpu.py).  Pure host code. */
+wnv_status wnv_exponential_from_uniform(const double* u, float* out, int64_t n, int32_t threads);
 
 /* ---- misc --------------------------------------------------------------------------------------- */
 const char* wnv_last_error(void);

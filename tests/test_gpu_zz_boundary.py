@@ -233,3 +233,30 @@ def test_persistent_launches_of_two_handles_take_turns():
     for i in range(2):
         assert len(results[i]) == 2 and all(torch.equal(r, serial[i]) for r in results[i]), i
         assert engines[i].last_kernel() == 2, "a handle fell back to the generic kernel"
+
+
+def test_streamed_replay_tape_equals_the_tape_drawn_up_front():
+    """One-hot models, rng = "replay" (the public default): the tape of B x 256 exponentials per step is drawn WHILE the ring kernel runs
+    (coherent host memory + a counter the kernel waits for, wnv_generate_args.noise_ready).  Same seed -> the same sampled classes as
+    with the tape drawn up front and handed over whole, bit for bit, and the generator left in the same state; the ring kernel served
+    the call.  (wavenet.py:332-335.)"""
+    name, B, T = "cfg1_mulaw256", 3, 2048
+    m = build(name).to("cuda")
+    c, _ = inputs(name, B, T)
+    c = c.cuda()
+    m.stream_replay_tape = False
+    torch.manual_seed(77)
+    want = m.incremental_forward(c=c, T=T)
+    after_want = torch.rand(4)
+    m.stream_replay_tape = True
+    torch.manual_seed(77)
+    got = m.incremental_forward(c=c, T=T)
+    after_got = torch.rand(4)
+    assert m._get_engine().last_kernel() == 2
+    assert torch.equal(got, want)
+    assert torch.equal(after_got, after_want)                 # the same number of draws came out of the same generator
+    assert got.shape == (B, 256, T) and float(got.sum()) == B * T            # one-hot
+    # a different seed gives a different utterance (the tape is really consumed)
+    torch.manual_seed(78)
+    other = m.incremental_forward(c=c, T=T)
+    assert not torch.equal(other, got)

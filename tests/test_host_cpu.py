@@ -339,3 +339,27 @@ def test_upsample_stretch_modes():
     assert make_config(**kw, upsample_mode="bilinear").upsample_mode == 1 and make_config(**kw).upsample_mode == 0
     with pytest.raises(NotImplementedError):
         make_config(**kw, upsample_mode="area")
+
+
+def test_fast_exponential_draws_are_torchs_own():
+    """noise.exponential_draws (one float64 uniform_ call + wnv_exponential_from_uniform on several threads) must BE
+    torch.Tensor.exponential_(1.0): same numbers, same generator state afterwards -- it replaces the serial draw of the replay tape
+    of one-hot models (49 M values for the benchmark batch) and feeds the tape that is streamed to the running kernel."""
+    import ctypes as C
+    from wavenet_vocoder_amd import _lib
+    from wavenet_vocoder_amd.noise import exponential_draws
+    for n, seed in ((1, 1), (5, 2), (4097, 3), (300_000, 4)):
+        g1, g2 = torch.Generator().manual_seed(seed), torch.Generator().manual_seed(seed)
+        a = torch.empty(n).exponential_(1.0, generator=g1)
+        b = torch.empty(n)
+        assert exponential_draws(b, g2)
+        assert torch.equal(a, b)
+        assert torch.equal(torch.empty(7).normal_(generator=g1), torch.empty(7).normal_(generator=g2))      # same state behind the draws
+    # the transform itself, any thread count, edge values of u
+    u = torch.tensor([0.0, 2.0 ** -53, 0.5, 1.0 - 2.0 ** -53], dtype=torch.float64).repeat(3000)
+    want = (-torch.log1p(-u)).float()
+    for th in (1, 3, 64):
+        out = torch.empty(u.numel())
+        assert _lib.lib().wnv_exponential_from_uniform(u.data_ptr(), out.data_ptr(), u.numel(), th) == 0
+        assert torch.equal(out, want)
+    assert _lib.lib().wnv_exponential_from_uniform(None, None, 0, 4) == 0

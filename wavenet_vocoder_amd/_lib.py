@@ -13,7 +13,7 @@ from typing import Optional
 __all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "ForwardArgs", "MelConfig", "LogmelArgs", "LIB_PATH",
            "WNV_ABI_VERSION", "DIST", "UPSAMPLE"]
 
-WNV_ABI_VERSION = 2
+WNV_ABI_VERSION = 3
 WNV_MAX_UPSAMPLE_STAGES = 8
 WNV_GEN_ASYNC = 1
 # WNV_LIB selects another build of the same sources (debug/trace builds: python -m wavenet_vocoder_amd.build --out ... --flags ...)
@@ -66,7 +66,7 @@ class GenerateArgs(C.Structure):
         ("initial", C.c_void_p), ("teacher", C.c_void_p), ("Tt", C.c_int64), ("noise", C.c_void_p),
         ("seed", C.c_uint64), ("softmax", C.c_int32), ("quantize", C.c_int32), ("out", C.c_void_p),
         ("params_out", C.c_void_p), ("index_out", C.c_void_p), ("kernel", C.c_int32), ("flags", C.c_int32),
-        ("stream", C.c_void_p),
+        ("stream", C.c_void_p), ("noise_ready", C.c_void_p),
     ]
 
 
@@ -109,6 +109,9 @@ class GluConfig(C.Structure):
 _PROTOS = {
     # name: (restype, argtypes)
     "wnv_abi_version": (C.c_int32, []),
+    "wnv_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "wnv_pinned_free": (C.c_int, [C.c_void_p]),
+    "wnv_exponential_from_uniform": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
     "wnv_last_error": (C.c_char_p, []),
     "wnv_create": (C.c_int, [C.POINTER(Config), C.c_int32, C.POINTER(C.c_void_p)]),
     "wnv_destroy": (C.c_int, [C.c_void_p]),

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <thread>
+#include <cmath>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -136,6 +138,35 @@ static wnv_status validate_config(const wnv_config* c) {
 }
 
 extern "C" int32_t wnv_abi_version(void) { return WNV_ABI_VERSION; }
+
+// ---- host helpers for a streamed replay tape (include/wnv.h) ---------------------------------------------------------------------
+extern "C" wnv_status wnv_pinned_alloc(size_t bytes, void** host_ptr, void** device_ptr) {
+    if (!host_ptr || !device_ptr || bytes == 0) return fail(WNV_ERR_INVALID_ARG, "bad arguments to wnv_pinned_alloc");
+    void* hp = nullptr;
+    HIP_TRY(hipHostMalloc(&hp, bytes, hipHostMallocCoherent | hipHostMallocMapped));
+    void* dp = nullptr;
+    hipError_t e = hipHostGetDevicePointer(&dp, hp, 0);
+    if (e != hipSuccess) { (void)hipHostFree(hp); return fail(WNV_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
+    *host_ptr = hp; *device_ptr = dp;
+    return WNV_OK;
+}
+extern "C" wnv_status wnv_pinned_free(void* host_ptr) {
+    if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
+    return WNV_OK;
+}
+extern "C" wnv_status wnv_exponential_from_uniform(const double* u, float* out, int64_t n, int32_t threads) {
+    if ((!u || !out) && n > 0) return fail(WNV_ERR_INVALID_ARG, "NULL buffer");
+    if (n < 0) return fail(WNV_ERR_INVALID_ARG, "n < 0");
+    // ATen, CPU: static_cast<float>(-1.0 / lambda * log1p(-u)) with lambda = 1.0, in double (TransformationHelper.h, exponential<double>)
+    auto work = [u, out](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) out[i] = static_cast<float>(-1.0 / 1.0 * std::log1p(-u[i])); };
+    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(threads, 64), n / 4096));
+    if (nt <= 1) { work(0, n); return WNV_OK; }
+    std::vector<std::thread> pool;
+    const int64_t per = (n + nt - 1) / nt;
+    for (int k = 0; k < nt; ++k) pool.emplace_back(work, std::min<int64_t>(n, k * per), std::min<int64_t>(n, (k + 1) * per));
+    for (auto& th : pool) th.join();
+    return WNV_OK;
+}
 thread_local std::string wnv_g_err;
 extern "C" const char* wnv_last_error(void) { return wnv_g_err.c_str(); }
 
@@ -529,6 +560,8 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     if (a->Tt < 0 || a->Tt > a->T || (a->Tt > 0 && !a->teacher)) return fail(WNV_ERR_INVALID_ARG, "bad teacher-forcing arguments");
     if (a->kernel < 0 || a->kernel > 3) return fail(WNV_ERR_INVALID_ARG, "unknown kernel selector %d", a->kernel);
     if ((a->flags & WNV_GEN_ASYNC) && a->kernel != 2) return fail(WNV_ERR_INVALID_ARG, "WNV_GEN_ASYNC needs kernel = 2 (the ring kernel chosen explicitly: auto mode must see the launch's status to fall back)");
+    if (a->noise_ready && !(a->noise && a->kernel == 2 && (a->flags & WNV_GEN_ASYNC)))
+        return fail(WNV_ERR_INVALID_ARG, "a streamed noise tape (noise_ready) needs noise, kernel = 2 and WNV_GEN_ASYNC: the caller fills the tape while the kernel runs");
     if ((a->flags & WNV_GEN_ASYNC) && a->B > 64) return fail(WNV_ERR_INVALID_ARG, "WNV_GEN_ASYNC takes at most 64 utterances per call (larger batches run as several launches)");
     DeviceGuard g(h->device);
     hipStream_t s = (hipStream_t)a->stream;
@@ -554,6 +587,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     ga.zbias = (const float*)h->zbias.p; ga.zbias_bstride = has_g ? (long long)m.L * m.Gp : 0;
     ga.seed = a->seed; ga.softmax = a->softmax; ga.quantize = c.scalar_input ? 1 : a->quantize;
     ga.nz = wnv_noise_width(&c);
+    ga.noise_ready = a->noise_ready;
     ga.out = a->out; ga.params_out = a->params_out; ga.index_out = a->index_out;
     // asynchronous ring launches only when the caller chose the ring explicitly: auto mode must see the status to fall back
     ga.async = (a->flags & WNV_GEN_ASYNC) && a->kernel == 2;

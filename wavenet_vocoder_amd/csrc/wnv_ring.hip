@@ -90,6 +90,7 @@ struct RingParams {
     const float *c_up, *initial, *teacher, *noise;
     unsigned long long seed;
     int b0, noise_B;                   // this launch is utterances [b0, b0 + B) of a call of noise_B (noise tape / Philox stream addressing)
+    const unsigned* noise_ready;       // streamed tape (coherent host memory): steps [0, *noise_ready) of `noise` are valid; null: all of it
     float *out, *params_out;
     unsigned int* status;
     unsigned long long* trace;         // optional [T_trace][upr][S+1][16] wall-clock stamps of ring 0's utterances (debug)
@@ -1308,6 +1309,22 @@ __host__ __device__ constexpr size_t head_lds_floats(int NK) { return (size_t)GC
 __device__ __forceinline__ float head_noise(const RingParams& p, int t, int b, int idx, int kind) {
     return p.noise ? p.noise[((size_t)t * p.noise_B + p.b0 + b) * p.nz + idx] : wnv_noise_gen(p.seed, t, p.b0 + b, idx, kind);
 }
+// STREAMED TAPE: the host is still drawing the tape while the kernel runs (coherent host memory; wnv_generate_args.noise_ready).
+// Every wave that is about to read step t waits until the counter has passed it -- one PCIe read per tape chunk, the value seen is
+// kept in `seen`.  Bounded like every wait (the host draws ~1e5 steps per second: the budget is seconds).  Returns false on abort.
+__device__ __forceinline__ bool wait_noise(const RingParams& p, int t, unsigned& seen) {
+    if (!p.noise_ready || (unsigned)t < seen) return true;
+    unsigned spins = 0;
+    for (;;) {
+        seen = __hip_atomic_load(p.noise_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)t < seen) return true;
+        if ((++spins & 63u) == 0u) {
+            if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if ((threadIdx.x & 63) == 0) atomicCAS(p.status, 0u, 0x800u); return false; }
+        }
+        __builtin_amdgcn_s_sleep(32);
+    }
+}
 
 // the slice of the output MLP one head part owns: W1 rows [128 part, +128) x K and W2[:, 128 part .. +128) (NW2 row images: rows i,
 // and rows 128 + i for one-hot models)
@@ -1536,12 +1553,14 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
         feed(b, p.tag_base + 1u, feed_addr(b, 0), xs, l0 && tid < RC ? c_t + s.pre0[tid] : 0.f, l0 && tid < RC ? c_s + s.pre0[RC + tid] : 0.f);
     }
 
+    unsigned noise_seen = 0;
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
         for (int j = 0; j < p.upr; ++j) {
             const int b = ring + j * p.n_rings;
             if (b >= p.B) continue;
             // ---- everything that does not depend on the network, while the ring works ---------------------------
+            if (!wait_noise(p, t, noise_seen)) s.flags[0] = 1;
             float gum = 0.f, lr = 0.f, forced = 0.f;
             if (i < nmix) gum = -logf(-logf(head_noise(p, t, b, i, 0)));          // Gumbel noise (mixture.py:138-140)
             if (wave < 2) {
@@ -1685,12 +1704,14 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
         send_input(b, dense, 127, p.tag_base + 1u);
     }
 
+    unsigned noise_seen = 0;
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
         for (int j = 0; j < p.upr; ++j) {
             const int b = ring + j * p.n_rings;
             if (b >= p.B) continue;
             // noise of this step, while the ring works: e ~ Exp(1) per class
+            if (!wait_noise(p, t, noise_seen)) s.ints[0] = 1;
             if (tid < O) s.nzb[tid] = head_noise(p, t, b, tid, 2);
             if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.ints[0] = 1;
             __syncthreads();
@@ -2165,7 +2186,7 @@ wnv_status wnv_ring_wait(WnvRingState* st, std::string& err) {
     RING_HIP(hipStreamSynchronize(st->pending_stream));
     if (*st->h_status != 0) {
         char buf[160];
-        snprintf(buf, sizeof buf, "ring kernel gave up waiting (code 0x%x: 0x1ss = activation into stage ss, 0x2ss = skip into stage ss, 0x300 = head)", *st->h_status);
+        snprintf(buf, sizeof buf, "ring kernel gave up waiting (code 0x%x: 0x1ss = activation into stage ss, 0x2ss = skip into stage ss, 0x300 = head, 0x800 = streamed noise tape)", *st->h_status);
         err = buf;
         return WNV_ERR_TIMEOUT;
     }
@@ -2327,6 +2348,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.hist = p.pmail + n_p;
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.b0 = ga.b0; p.noise_B = ga.noise_B > 0 ? ga.noise_B : B;
+    p.noise_ready = ga.noise_ready;
     p.out = ga.out; p.params_out = ga.params_out;
     // LDS: the stage carve is the larger one
     // tap workgroups: K rows per wave (a multiple of 4), first in VGPRs, then in LDS, the remainder streams from L2

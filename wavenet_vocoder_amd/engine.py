@@ -91,8 +91,38 @@ def _tensor_table(named: Dict[str, torch.Tensor]):
     return arr, keep
 
 
-def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
+def _ptr(t) -> Optional[int]:
+    """A tensor's address, or an address given as an int (device pointers of PinnedBuffer)."""
+    return None if t is None else (int(t) if isinstance(t, int) else t.data_ptr())
+
+
+class PinnedBuffer:
+    """Coherent, device-mapped host memory (wnv_pinned_alloc): ``.host`` / ``.dev`` addresses and zero-copy torch views -- what a
+    replay tape that is still being drawn while the kernel reads it lives in (include/wnv.h, wnv_generate_args.noise_ready)."""
+
+    def __init__(self, nbytes: int):
+        host, dev = C.c_void_p(), C.c_void_p()
+        check(_lib.lib().wnv_pinned_alloc(C.c_size_t(int(nbytes)), C.byref(host), C.byref(dev)))
+        self.host, self.dev, self.nbytes = host.value, dev.value, int(nbytes)
+
+    def view(self, dtype: torch.dtype, shape: Sequence[int], offset: int = 0) -> torch.Tensor:
+        import numpy as np
+        raw = (C.c_ubyte * (self.nbytes - offset)).from_address(self.host + offset)
+        n = 1
+        for d in shape:
+            n *= int(d)
+        return torch.from_numpy(np.frombuffer(raw, dtype=np.uint8))[: n * torch.empty((), dtype=dtype).element_size()].view(dtype).view(*shape)
+
+    def free(self):
+        if self.host:
+            _lib.lib().wnv_pinned_free(C.c_void_p(self.host))
+            self.host = self.dev = 0
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def _stream(device: torch.device) -> int:
@@ -199,10 +229,12 @@ class Engine:
 
     def generate(self, *, B: int, T: int, c_up=None, g=None, g_ids=None, initial=None, teacher=None,
                  noise=None, seed: int = 0, softmax: bool = True, quantize: bool = True,
-                 want_params: bool = False, want_index: bool = False, kernel: int = 0, asynchronous: bool = False):
+                 want_params: bool = False, want_index: bool = False, kernel: int = 0, asynchronous: bool = False,
+                 noise_ready=None):
         """Runs the whole autoregressive loop.  Returns (out (B,C,T), params (B,O,T)|None, index (B,T)|None).
         ``asynchronous`` (ring kernel chosen explicitly, kernel=2): return right after the launch; ``wait()`` or the next
-        call reports a bounded-spin timeout (WNV_GEN_ASYNC in include/wnv.h)."""
+        call reports a bounded-spin timeout (WNV_GEN_ASYNC in include/wnv.h).  ``noise`` / ``noise_ready`` may be device
+        addresses (ints) of a PinnedBuffer: a tape the caller keeps filling while the kernel runs (needs kernel=2, asynchronous)."""
         dev = self.device
         cfg = self.cfg
         C_out = 1 if cfg.scalar_input else cfg.out_channels
@@ -221,6 +253,7 @@ class Engine:
         a.kernel = int(kernel)
         a.flags = _lib.WNV_GEN_ASYNC if asynchronous else 0
         a.stream = _stream(dev)
+        a.noise_ready = _ptr(noise_ready)
         check(_lib.lib().wnv_generate(self._h, C.byref(a)))
         return out, params, index
 

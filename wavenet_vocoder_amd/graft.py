@@ -19,8 +19,8 @@ from typing import Optional
 
 import torch
 
-from .engine import Engine, check_checkpoint, make_config, require_gpu_tensor
-from .noise import make_noise_tape
+from .engine import Engine, PinnedBuffer, check_checkpoint, make_config, require_gpu_tensor
+from .noise import exponential_draws, make_noise_tape
 
 __all__ = ["EngineHost", "infer_config_kwargs", "make_wavenet_amd"]
 
@@ -188,6 +188,12 @@ class EngineHost:
         # noise
         noise, seed = None, 0
         if self.rng == "replay":
+            if not self.scalar_input and quantize and self.kernel in (0, 2) and self.stream_replay_tape and T >= 1024:
+                # a mu-law model draws B x out_channels exponentials per step (wavenet.py:334-335): the tape takes longer to draw than
+                # the kernel runs -- so it is drawn WHILE the kernel runs (ring kernel only; anything else takes the path below)
+                out = self._generate_streamed(eng, B, T, c_up, g_feat, g_ids, init, test_inputs, softmax)
+                if out is not None:
+                    return out
             tape = make_noise_tape(T, B, scalar_input=self.scalar_input,
                                    output_distribution=self.output_distribution, out_channels=self.out_channels)
             noise = tape.to(dev, non_blocking=False).contiguous()
@@ -200,6 +206,52 @@ class EngineHost:
                                       quantize=quantize, want_params=self.capture_params, kernel=self.kernel)
         self.last_params = params
         return out
+
+
+    stream_replay_tape = True     # one-hot models: draw the replay tape while the ring kernel runs (False: draw it first, as for the other kernels)
+
+    def _generate_streamed(self, eng, B, T, c_up, g_feat, g_ids, init, test_inputs, softmax):
+        """``rng = "replay"`` for one-hot models at kernel speed: the tape of B x out_channels exponentials per step -- the numbers
+        torch's CPU generator hands the reference's ``OneHotCategorical.sample`` (wavenet.py:334-335) -- lives in coherent host memory
+        the device reads directly; the ring kernel is launched asynchronously at once and waits, step by step, for a counter the host
+        advances as it draws the tape chunk by chunk (same draws, same order, same generator: ``exponential_draws``).  Returns None
+        -- with the generator untouched -- when the ring kernel does not take the call (other kernels get their tape up front)."""
+        nz = self.out_channels
+        probe = torch.empty(1)
+        state = torch.get_rng_state()
+        if not exponential_draws(probe):                        # the fast draw is unavailable on this build: let the caller draw as before
+            return None
+        torch.set_rng_state(state)
+        tape_buf = PinnedBuffer(T * B * nz * 4)
+        ready_buf = PinnedBuffer(64)
+        try:
+            tape = tape_buf.view(torch.float32, (T, B, nz))
+            ready = ready_buf.view(torch.int32, (1,))
+            ready[0] = 0
+            try:
+                out, params, _ = eng.generate(B=B, T=T, c_up=c_up, g=g_feat, g_ids=g_ids, initial=init, teacher=test_inputs, noise=tape_buf.dev,
+                                              noise_ready=ready_buf.dev, softmax=softmax, quantize=True, want_params=self.capture_params,
+                                              kernel=2, asynchronous=True)
+            except (NotImplementedError, TimeoutError):         # not a ring configuration / no room for the ring: nothing was drawn
+                return None
+            step = max(64, (1 << 19) // (B * nz))               # ~0.5 M values per chunk: a few milliseconds of drawing
+            for t0 in range(0, T, step):
+                t1 = min(T, t0 + step)
+                exponential_draws(tape[t0:t1])
+                ready[0] = t1                                    # (x86: the tape's stores are visible before the counter's)
+            try:
+                eng.wait()
+            except TimeoutError:
+                # the launch lost its CUs on the way: the tape is complete by now -- serve the call through the ordinary path with it
+                noise = tape.clone().to(eng.device)
+                out, params, _ = eng.generate(B=B, T=T, c_up=c_up, g=g_feat, g_ids=g_ids, initial=init, teacher=test_inputs, noise=noise,
+                                              softmax=softmax, quantize=True, want_params=self.capture_params, kernel=1)
+            self.last_params = params
+            return out
+        finally:
+            torch.cuda.synchronize(eng.device)                   # nothing on the device reads the buffers any more
+            tape_buf.free()
+            ready_buf.free()
 
 
 def make_wavenet_amd(reference_wavenet_cls):
