@@ -404,7 +404,7 @@ __device__ __forceinline__ int split_block(const RingParams& p, int ring, int st
 // run-time "is this step traced" test sat on the chain of every stage): a role notes the device-wide 100 MHz wall clock in
 // REGISTERS where something happens (WNV_TS: one s_memrealtime, no wait, no store) and lane 0 of a wave writes the slots it owns
 // once per step, behind everything that is timed (WNV_TS_FLUSH).
-constexpr int TRW = 32;            // stamp slots per (step, position)
+constexpr int TRW = 16;            // stamp slots per (step, position)
 #ifdef WNV_FINE_TRACE
 // (every utterance of ring 0 is stamped: utterance b = j n_rings is the j-th of that ring)
 __device__ __forceinline__ bool ts_traced(const RingParams& p, int b, int t) {
@@ -423,10 +423,18 @@ __device__ __forceinline__ void ts_flush(const RingParams& p, int b, int t, int 
 }
 #define WNV_TS_DECL unsigned long long tsv[TRW] = {0}
 #define WNV_TS(k) (tsv[k] = __builtin_amdgcn_s_memrealtime())
+// the less important stamps: every live stamp is an SGPR pair in a kernel that has none to spare (with all of them the trace build
+// spills vector registers in its hot loops and runs 25 % slower than the product): -DWNV_FINE_TRACE=2 turns them on
+#if WNV_FINE_TRACE + 0 >= 2
+#define WNV_TSX(k) WNV_TS(k)
+#else
+#define WNV_TSX(k) ((void)0)
+#endif
 #define WNV_TS_FLUSH(b, t, pos, mask, shift) ts_flush(p, b, t, pos, tsv, mask, shift)
 #else
 #define WNV_TS_DECL
 #define WNV_TS(k) ((void)0)
+#define WNV_TSX(k) ((void)0)
 #define WNV_TS_FLUSH(b, t, pos, mask, shift) ((void)0)
 #endif
 
@@ -941,7 +949,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             if (wave == 0 && hand_on)                                           // (behind the barrier: the N waves start first)
                 st_granule2(p.gmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + 2 * lane, tag, hv0, hv1, fast);
             if (grp == 1 && !zmsg) {                                            // the N waves; the chain waves go on to the chain input
-                WNV_TS(12);
+                WNV_TSX(12);
                 __builtin_amdgcn_s_setprio(3);                                  // wave 4 shares its SIMD with the polling wave 0
                 float a, g;
                 if (!first_stage) group_matvec8(wmn, s.hb + ES * ks, s.pre + chc, s.pre + RC + chc, a, g);
@@ -973,7 +981,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             }
             // ---- behind the send -----------------------------------------------------------------------------------
             __syncthreads();                                                    // u_l complete in LDS
-            if (grp == 1) WNV_TS(7);
+            if (grp == 1) WNV_TSX(7);
             float xu[16];
             lds_read16(s.us + ES * ks, xu);
             // conv1x1_out + bias, published for stage l + 2's poller, which adds the residual (see above)
@@ -1016,8 +1024,8 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             // the residual increment is what the next-but-one stage waits for; at the last stage the skip term (the head's input) is
             // the urgent one -- and at the stage before it too: the sum it completes is the other half of the head's input, while its
             // q only feeds the last stage's history push
-            if (last_stage || sidx == p.S - 2) { skip_phase(); WNV_TS(3); h_phase(); WNV_TS(2); }
-            else { h_phase(); WNV_TS(2); skip_phase(); WNV_TS(3); }
+            if (last_stage || sidx == p.S - 2) { skip_phase(); WNV_TSX(3); h_phase(); WNV_TS(2); }
+            else { h_phase(); WNV_TS(2); skip_phase(); WNV_TSX(3); }
             // ---- history push + next step's pre-activations (its barriers fence the LDS vectors for the next step) -------
             __syncthreads();                        // fences the LDS vectors against the next step; makes flags[0] uniform
             if (s.flags[0]) return;                 // a bounded wait gave up somewhere: drain (status holds the code)
@@ -1047,12 +1055,12 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                     }
                 }
             }
-            WNV_TS(4);
+            WNV_TSX(4);
             // timeline slots: 0 X and zin in LDS | 1 u sent (wave 0) | 2 q sent | 3 skip sent | 4 step done | 5 h_{l-1} formed | 6 zin ready |
             // 7 barrier behind u | 8 chain input's poll hit | 9-11 u sent by waves 1-3
             if (wave == 0) WNV_TS_FLUSH(b, t, sidx, 0x013Eu, 0);
             else if (wave < 4) WNV_TS_FLUSH(b, t, sidx, 0x002u, 7 + wave);
-            else if (wave == 4) { WNV_TS_FLUSH(b, t, sidx, 0x10C1u, 0); WNV_TS_FLUSH(b, t, sidx, 0x000Cu, 16); }   // 12: N waves released; 18, 19: slots 2, 3 as wave 4 saw them
+            else if (wave == 4) WNV_TS_FLUSH(b, t, sidx, 0x10C1u, 0);            // 12: N waves released
             else if (wave == 5) WNV_TS_FLUSH(b, t, sidx, 0x0040u, 7);          // 13: zin ready as wave 5 saw it
         }
     }
@@ -1202,7 +1210,7 @@ __device__ void run_stage_split(const RingParams& p, int ring, int sidx, int hal
             if (wave == 0 && hand_on)
                 st_granule2(p.gmail + (((size_t)b * 2 + par) * S1 + sidx) * RC + 2 * lane, tag, hv0, hv1, fast);
             if (grp == 1 && !ZMSG) {
-                WNV_TS(12);
+                WNV_TSX(12);
                 float a, g;
                 group_matvec4(wmn, s.hb + ES * ks, s.pre + chc, s.pre + RC + chc, a, g);
                 if (gwriter) *reinterpret_cast<float2*>(s.zin + 2 * lc) = make_float2(a, g);
@@ -1226,7 +1234,7 @@ __device__ void run_stage_split(const RingParams& p, int ring, int sidx, int hal
                 WNV_TS(1);
             }
             __syncthreads();                                                    // this half's 64 channels of u_l in LDS
-            if (grp == 1) WNV_TS(7);
+            if (grp == 1) WNV_TSX(7);
             float xu[16];
             lds_read16(s.us + ES * kq, xu);
             auto h_phase = [&]() {
@@ -1244,8 +1252,8 @@ __device__ void run_stage_split(const RingParams& p, int ring, int sidx, int hal
                 if (qwriter && ok) st_granule(sm_out, tag, acc + mine, fast);
                 if (!ok) s.flags[0] = 1;
             };
-            if (sidx >= p.S - 2) { skip_phase(); WNV_TS(3); h_phase(); WNV_TS(2); }
-            else { h_phase(); WNV_TS(2); skip_phase(); WNV_TS(3); }
+            if (sidx >= p.S - 2) { skip_phase(); WNV_TSX(3); h_phase(); WNV_TS(2); }
+            else { h_phase(); WNV_TS(2); skip_phase(); WNV_TSX(3); }
             __syncthreads();
             if (s.flags[0]) return;
             if (wave == 0 && half == 0) {                                       // history of layer l - 1 (and of the last layer): half 0 files it
@@ -1270,11 +1278,11 @@ __device__ void run_stage_split(const RingParams& p, int ring, int sidx, int hal
                     file(l, s.hh);
                 }
             }
-            WNV_TS(4);
+            WNV_TSX(4);
             if (half == 0) {
                 if (wave == 0) WNV_TS_FLUSH(b, t, sidx, 0x013Eu, 0);
                 else if (wave < 4) WNV_TS_FLUSH(b, t, sidx, 0x002u, 7 + wave);
-                else if (wave == 4) { WNV_TS_FLUSH(b, t, sidx, 0x10C1u, 0); WNV_TS_FLUSH(b, t, sidx, 0x000Cu, 16); }
+                else if (wave == 4) WNV_TS_FLUSH(b, t, sidx, 0x10C1u, 0);
                 else if (wave == 5) WNV_TS_FLUSH(b, t, sidx, 0x0040u, 7);
             }
         }
