@@ -84,9 +84,14 @@ struct WideParams {
     int trace_t0, trace_n, trace_b;
 };
 
+// (timeline stamps exist in -DWNV_FINE_TRACE builds only: the run-time test sat on the chain of every group)
 __device__ __forceinline__ void wstamp(const WideParams& p, int b, int t, int pos, int k, int who) {
+#ifdef WNV_FINE_TRACE
     if (p.trace && b == p.trace_b && (int)threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
         p.trace[((size_t)(t - p.trace_t0) * (p.L + 1) + pos) * 8 + k] = wall_clock64();
+#else
+    (void)p; (void)b; (void)t; (void)pos; (void)k; (void)who;
+#endif
 }
 
 __device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v, bool fast) {
@@ -560,10 +565,32 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
                 if (p.params_out) p.params_out[((size_t)b * p.O + lane) * p.T + t] = o;
             }
             __syncthreads();
-            // ---- sample, redundantly in every thread (no cross-lane traffic), then first_conv of step t + 1 ------------------------
+            // ---- sample in every wave on its own (all 512 threads feed first_conv), then first_conv of step t + 1.  Up to 16 mixture
+            //      components: lane c evaluates component c (independent LDS reads, one round trip), the Gumbel-max is a 16-lane DPP max
+            //      butterfly + ballot (first index wins ties), v_readlane fetches the winner's sample (as wnv_ring.hip's head) ----------------
             {
-                int bi = 0;
-                if (nmix > 0) {                                                                      // Gumbel-max, first index wins ties
+                float xo;
+                const float lr = s.nz[nmix];
+                if (nmix <= 16) {
+                    float key = -INFINITY, mean = 0.f, ls = 0.f;
+                    if (nmix == 0) { mean = s.obuf[o_mean]; ls = s.obuf[o_ls]; }                     // mixture.py:258-261
+                    else if (lane < nmix) { key = vbuf[lane]; mean = s.obuf[o_mean + lane]; ls = s.obuf[o_ls + lane]; }       // mixture.py:143-146
+                    float xc = p.dist == 1 ? mean + __expf(ls) * lr : lr * __expf(ls) + mean;
+                    xc = fminf(fmaxf(xc, -1.0f), 1.0f);                                              // mixture.py:154 / :269
+                    if (nmix > 0) {
+                        float m = key;
+                        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xF, 0xF, true)));
+                        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xF, 0xF, true)));
+                        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xF, 0xF, true)));
+                        m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x140, 0xF, 0xF, true)));
+                        const unsigned long long win = __ballot(lane < nmix && key == m);
+                        const int wl = win ? __ffsll((long long)win) - 1 : 0;
+                        xo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), wl));
+                    } else {
+                        xo = xc;
+                    }
+                } else {
+                    int bi = 0;
                     float best = -INFINITY;
                     for (int c = 0; c < nchunk; ++c) {
                         const float4 v = reinterpret_cast<const float4*>(vbuf)[c];
@@ -572,10 +599,10 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
                         if (v.z > best) { best = v.z; bi = 4 * c + 2; }
                         if (v.w > best) { best = v.w; bi = 4 * c + 3; }
                     }
+                    const float mean = s.obuf[o_mean + bi], ls = s.obuf[o_ls + bi];
+                    xo = p.dist == 1 ? mean + expf(ls) * lr : lr * expf(ls) + mean;
+                    xo = fminf(fmaxf(xo, -1.0f), 1.0f);
                 }
-                const float mean = s.obuf[o_mean + bi], ls = s.obuf[o_ls + bi], lr = s.nz[nmix];    // mixture.py:143-146 / :258-261
-                float xo = p.dist == 1 ? mean + expf(ls) * lr : lr * expf(ls) + mean;
-                xo = fminf(fmaxf(xo, -1.0f), 1.0f);                                                  // mixture.py:154 / :269
                 if (t + 1 < p.T) {
                     const float xs = t + 1 < p.Tt ? p.teacher[(size_t)b * p.Tt + t + 1] : xo;        // wavenet.py:297-305
                     st_granule(p.xmail + ((size_t)b * (p.L + 1)) * XW + GHD + tid, tag + 1u, fmaf(wf, xs, bf), fast_first);
