@@ -27,6 +27,11 @@ CASES = {
                                          n_speakers=3, use_speaker_embedding=True), 3, 64, 128),
     "mol_320_512_256_nine_layers": (dict(out_channels=30, layers=9, stacks=3, residual_channels=320, gate_channels=512, skip_out_channels=256,
                                          kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=20), 8, 48, 96),
+    # the reference constructor's DEFAULT geometry (wavenet.py:98-101: 512 / 512 / 512): two skip banks per slice, the head is four workgroups
+    "mol_512_512_512_default_constructor": (dict(out_channels=30, layers=6, stacks=2, residual_channels=512, gate_channels=512, skip_out_channels=512,
+                                                 kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=80), 2, 96, 160),
+    "gauss_384_512_400_five_utterances": (dict(out_channels=2, layers=5, stacks=1, residual_channels=384, gate_channels=512, skip_out_channels=400,
+                                               kernel_size=2, dropout=0.0, scalar_input=True, output_distribution="Normal", cin_channels=7), 5, 40, 88),
     # more than 8 utterances: the tap stream takes them in two passes, the deferred history copies run two utterances behind
     "mol_512_384_256_thirteen_utterances": (dict(out_channels=30, layers=4, stacks=2, residual_channels=512, gate_channels=384, skip_out_channels=256,
                                                  kernel_size=3, dropout=0.0, scalar_input=True, output_distribution="Logistic", cin_channels=33), 13, 40, 72),

@@ -61,6 +61,8 @@ struct WideParams {
     int L, nL, B, T, Tt, O, cin, cinp, kw, nz, dist, kpre, nkb;
     int b0, noise_B;                                      // this launch is utterances [b0, b0 + B) of a call of noise_B (noise addressing)
     int head_x, head_li, fast;
+    int NB, KW;                                           // skip banks of 256 channels (1; 2 for 257 .. 512 skip channels) and the padded skip width 256 NB
+    u64* omail;                                           // K = 512: partial head outputs of head parts 1 .. 3 -> part 0: O[b][4][64]
     int cin1, softmax, quantize;                          // first_conv input channels (1 = scalar input); categorical switches (wavenet.py:332-335)
     int* index_out;
     u64* hidmail;                                         // one-hot models: hidden layer of the head, HID[b][256] (head part A -> part B)
@@ -226,7 +228,7 @@ __device__ __forceinline__ float dot_skip(const float4 (&w)[4], const float* xq)
 }
 
 struct StageLds {
-    float *hx, *ux, *pz, *po, *ps, *pre, *xin, *pt;
+    float *hx, *ux, *pz, *po, *ps, *ps2, *pre, *xin, *pt;
     int* flags;
 };
 __device__ __forceinline__ StageLds carve_stage(float* smem, int kpre) {
@@ -236,7 +238,8 @@ __device__ __forceinline__ StageLds carve_stage(float* smem, int kpre) {
     s.pz = s.ux + GHD;                     // [8][64] partial z
     s.po = s.pz + 8 * 64;                  // [8][64] partial conv1x1_out
     s.ps = s.po + 8 * 64;                  // [16][32] partial conv1x1_skip
-    s.pre = s.ps + 16 * 32;                // [BMAX][64] pre_j of the step being computed
+    s.ps2 = s.ps + 16 * 32;                // [16][32] the same for skip bank 1 (K > 256)
+    s.pre = s.ps2 + 16 * 32;               // [BMAX][64] pre_j of the step being computed
     s.pt = s.pre + BMAX * 64;              // [8][BMAX][64] partial taps
     s.flags = reinterpret_cast<int*>(s.pt + 8 * BMAX * 64);
     s.xin = reinterpret_cast<float*>(s.flags + 16);      // [xin_slots(B)][kpre] tap inputs of the next step
@@ -244,7 +247,7 @@ __device__ __forceinline__ StageLds carve_stage(float* smem, int kpre) {
     return s;
 }
 __host__ __device__ inline int xin_slots(int B) { return B <= 1 ? 1 : B <= 2 ? 2 : B <= 4 ? 4 : B <= 8 ? 8 : 16; }     // what stream_pre<NB> reads
-__host__ __device__ inline size_t stage_lds_floats(int kpre, int B) { return (size_t)RWD + GHD + 3 * 512 + BMAX * 64 + 8 * BMAX * 64 + 16 + (size_t)xin_slots(B) * kpre; }
+__host__ __device__ inline size_t stage_lds_floats(int kpre, int B) { return (size_t)RWD + GHD + 4 * 512 + BMAX * 64 + 8 * BMAX * 64 + 16 + (size_t)xin_slots(B) * kpre; }
 
 __device__ __forceinline__ float reduce_quads2(f2 s01, f2 s23) { return swap16_sum(swap32_sum(s01.x, s01.y), swap32_sum(s23.x, s23.y)); }
 
@@ -354,13 +357,14 @@ __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next
     const StageLds s = carve_stage(smem, p.kpre);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool first = l == 0;
-    float4 wn[16], wm[8], wo[8], ws[4];
+    float4 wn[16], wm[8], wo[8], ws[4], ws2[4];
     load_img<16>(wn, p.wn + (size_t)(l * PG + j) * 8 * 16 * 64 * 4, wave, lane);      // N_l (group 0: W_cur,0) x h_{l-1}, K span 64 wave (lane-quad images)
     load_img<8>(wm, p.wm + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);        // M_l x u_{l-1}, K span 32 wave (group 0: zeros)
     load_img<8>(wo, p.wo + (size_t)(l * PG + j) * 8 * 8 * 64 * 4, wave, lane);        // W_out,l-1 rows 64 j + ..
-    load_img<4>(ws, p.ws + (size_t)(l * PG + j) * 8 * 4 * 64 * 4, wave, lane);        // W_skip,l-1 rows 32 j + .., K span 32 wave
+    load_img<4>(ws, p.ws + (size_t)((l * 2 + 0) * PG + j) * 8 * 4 * 64 * 4, wave, lane);        // W_skip,l-1 rows 32 j + .. (bank 0: skip channels < 256), K span 32 wave
+    load_img<4>(ws2, p.ws + (size_t)((l * 2 + 1) * PG + j) * 8 * 4 * 64 * 4, wave, lane);       // ... bank 1: skip channels 256 + 32 j + .. (zeros unless K > 256)
     const float bo_r = p.bo[(size_t)l * RWD + RS * j + lane];                         // b_out,l-1
-    const float bs_r = p.bs[(size_t)l * KWD + KS * j + (lane & 31)];                  // b_skip,l-1
+    const float bs_r = p.bs[(size_t)l * p.KW + (wave == 3 ? KWD : 0) + KS * j + (lane & 31)];        // b_skip,l-1 (wave 2: bank 0, wave 3: bank 1)
     const float cv_a = p.cvec[(size_t)l * 2 * GHD + GS * j + (lane & 31)], cv_g = p.cvec[(size_t)l * 2 * GHD + GHD + GS * j + (lane & 31)];
     const int d = p.lay_dil[l], rows = (p.kw - 1) * d;
     // this workgroup's own copy of layer l's input history, utterance 0
@@ -402,6 +406,7 @@ __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next
                     dot_quad<8>(wo, uq, ao);
                     s.po[wave * 64 + lane] = reduce_quads(ao);
                     s.ps[ps_at] = dot_skip(ws, uq);
+                    if (p.NB > 1) s.ps2[ps_at] = dot_skip(ws2, uq);
                 }
                 s.pz[wave * 64 + lane] = reduce_quads(az);
             }
@@ -421,16 +426,18 @@ __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next
                 for (int w = 0; w < 8; ++w) o += s.po[w * 64 + lane];
                 const float hv = first ? hp : (o + hp) * 0.70710678118654752440f;                                        // modules.py:157-162
                 st_granule(x_out + GHD + RS * j + lane, tag, hv, fast_next);
-            } else if (wave == 2 && !first) {                      // skip sum over layers 0 .. l-1 (wavenet.py:312) -> group l + 1 / the tail
+            } else if ((wave == 2 || (wave == 3 && p.NB > 1)) && !first) {       // skip sum over layers 0 .. l-1 (wavenet.py:312) -> group l + 1 / the tail; one wave per bank
+                const float* psb = wave == 2 ? s.ps : s.ps2;
+                const size_t bank = wave == 2 ? 0 : KWD;
                 float sk = bs_r, acc = 0.f;
                 bool ok = true;
                 if (lane < KS) {
 #pragma unroll
-                    for (int h = 0; h < 16; ++h) sk += s.ps[h * 32 + lane];
+                    for (int h = 0; h < 16; ++h) sk += psb[h * 32 + lane];
                 }
-                if (l > 1) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 2) + l) * KWD + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)l, lane);
+                if (l > 1) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 2) + l) * p.KW + bank + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)l, lane);
                 if (!ok) s.flags[0] = 1;
-                else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 2) + l + 1) * KWD + KS * j + lane, tag, acc + sk, fast_next);
+                else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 2) + l + 1) * p.KW + bank + KS * j + lane, tag, acc + sk, fast_next);
             }
         }
         // ---- behind the chain: the full h_l of the last two utterances -> history (waves 6, 7), then pre_j[t + 1] for every utterance
@@ -455,12 +462,13 @@ __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next
 // ---- the tail group: conv1x1_skip of the LAST layer (8 workgroups, 32 skip rows each) + the running skip sum -> the head ------------
 __device__ void run_wide_tail(const WideParams& p, int j, bool fast_next, float* smem) {
     float* ux = smem;                                              // [256] u_{L-1}
-    float* ps = ux + GHD;                                          // [16][32] partial sums
-    int* flags = reinterpret_cast<int*>(ps + 16 * 32);
+    float* ps = ux + GHD;                                          // [2 banks][16][32] partial sums
+    int* flags = reinterpret_cast<int*>(ps + 2 * 16 * 32);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    float4 ws[4];
+    float4 ws[4], ws2[4];
     load_img<4>(ws, p.wsl + (size_t)j * 8 * 4 * 64 * 4, wave, lane);
-    const float bs_r = p.bs[(size_t)p.L * KWD + KS * j + (lane & 31)];
+    load_img<4>(ws2, p.wsl + (size_t)(PG + j) * 8 * 4 * 64 * 4, wave, lane);            // bank 1 (zeros unless K > 256)
+    const float bs_r = p.bs[(size_t)p.L * p.KW + (wave == 1 ? KWD : 0) + KS * j + (lane & 31)];
     if (tid == 0) flags[0] = 0;
     __syncthreads();
     for (int t = 0; t < p.T; ++t) {
@@ -471,18 +479,24 @@ __device__ void run_wide_tail(const WideParams& p, int j, bool fast_next, float*
             }
             __syncthreads();
             if (flags[0]) return;
-            ps[(2 * wave + ((lane >> 4) & 1)) * 32 + (lane & 15) + 16 * (lane >> 5)] = dot_skip(ws, ux + 32 * wave + 8 * (lane >> 4));
+            {
+                const int at = (2 * wave + ((lane >> 4) & 1)) * 32 + (lane & 15) + 16 * (lane >> 5);
+                ps[at] = dot_skip(ws, ux + 32 * wave + 8 * (lane >> 4));
+                if (p.NB > 1) ps[512 + at] = dot_skip(ws2, ux + 32 * wave + 8 * (lane >> 4));
+            }
             __syncthreads();
-            if (wave == 0) {
+            if (wave == 0 || (wave == 1 && p.NB > 1)) {            // one wave per bank
+                const float* psb = ps + 512 * wave;
+                const size_t bank = (size_t)KWD * wave;
                 float sk = bs_r, acc = 0.f;
                 bool ok = true;
                 if (lane < KS) {
 #pragma unroll
-                    for (int h = 0; h < 16; ++h) sk += ps[h * 32 + lane];
+                    for (int h = 0; h < 16; ++h) sk += psb[h * 32 + lane];
                 }
-                if (p.L > 1) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 2) + p.L) * KWD + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)p.L, lane);
+                if (p.L > 1) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 2) + p.L) * p.KW + bank + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)p.L, lane);
                 if (!ok) flags[0] = 1;
-                else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + KS * j + lane, tag, acc + sk, fast_next);
+                else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * p.KW + bank + KS * j + lane, tag, acc + sk, fast_next);
             }
         }
     }
@@ -534,7 +548,7 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
                 else s.nz[tid] = p.dist == 1 ? logf(r) - logf(1.0f - r) : r;                         // mixture.py:151-152 / :265-267
             }
             if (wave < 2) {
-                if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
+                if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * p.KW + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
                 // (a lane rewrites the two values it has just stored)
                 float2* v2 = reinterpret_cast<float2*>(s.vs + 128 * wave + 2 * lane);
                 *v2 = make_float2(fmaxf(v2->x * p.skip_scale, 0.f), fmaxf(v2->y * p.skip_scale, 0.f));     // wavenet.py:313-316
@@ -615,6 +629,134 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
     }
 }
 
+// ---- head of scalar-input models with 257 .. 512 skip channels (the reference constructor's default geometry, wavenet.py:98-101): the
+// hidden layer (512 x 512 = 1 MB) is four register files, so the head is FOUR workgroups ("parts", as in wnv_ring.hip): part q owns
+// hidden units [128 q, 128 q + 128) -- it reads the whole skip sum, computes its hidden slice (W1 rows in VGPRs, 128 floats per thread)
+// and the partial head outputs W2[:, 128 q ..] . hidden_q; parts 1 .. 3 send their partials to part 0, which adds them in part order,
+// samples and feeds group 0.
+struct Head5Lds {
+    float *vs, *ph, *hid, *pout, *obuf, *nz;
+    int* flags;
+};
+__device__ __forceinline__ Head5Lds carve_head5(float* smem) {
+    Head5Lds s;
+    s.vs = smem; s.ph = s.vs + 512; s.hid = s.ph + 4 * 128; s.pout = s.hid + 128; s.obuf = s.pout + 8 * 64; s.nz = s.obuf + 64;
+    s.flags = reinterpret_cast<int*>(s.nz + 64);
+    return s;
+}
+constexpr size_t HEAD5_LDS_FLOATS = 512 + 4 * 128 + 128 + 8 * 64 + 64 + 64 + 16;
+
+__device__ void run_wide_head512(const WideParams& p, int q, bool fast_first, bool fast_parts, float* smem) {
+    const Head5Lds s = carve_head5(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4 w1[32], w2[4];
+    load_img<32>(w1, p.wh1 + (size_t)q * 8 * 32 * 64 * 4, wave, lane);      // lane-quad image: hidden rows 128 q + (wave & 1) 64 + .., K quarter (wave >> 1)
+    load_img<4>(w2, p.wh2 + (size_t)q * 8 * 4 * 64 * 4, wave, lane);        // lane-quad image: output rows 0 .. 63 (< O), hidden span 128 q + 16 wave + ..
+    const float wf = p.wfirst[tid], bf = p.bfirst[tid];
+    const float b1 = tid < 128 ? p.bh1[128 * q + tid] : 0.f;
+    const float b2 = lane < p.O ? p.bh2[lane] : 0.f;
+    const bool single = p.dist == 2 && p.O <= 3;
+    const int nmix = single ? 0 : p.O / 3;
+    const int o_mean = single ? (p.O == 2 ? 0 : 1) : nmix, o_ls = single ? (p.O == 2 ? 1 : 2) : 2 * nmix;
+    float* vbuf = s.nz + 32;                             // [32] mixture logit + Gumbel noise, padded with -inf
+    if (tid < 32) vbuf[tid] = -INFINITY;
+    if (tid == 0) s.flags[0] = 0;
+    __syncthreads();
+    if (q == 0)                                          // the input of step 0 (wavenet.py:283-289, :297-308)
+        for (int b = 0; b < p.B; ++b) {
+            const float xs = p.Tt > 0 ? p.teacher[(size_t)b * p.Tt] : (p.initial ? p.initial[b] : 0.f);
+            st_granule(p.xmail + ((size_t)b * (p.L + 1)) * XW + GHD + tid, p.tag_base + 1u, fmaf(wf, xs, bf), fast_first);
+        }
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        for (int b = 0; b < p.B; ++b) {
+            if (q == 0 && tid < p.nz) {                  // the noise terms of the sampler, while the groups work
+                const int kind = (p.dist == 2 && tid == p.nz - 1) ? 1 : 0;
+                const float r = p.noise ? p.noise[((size_t)t * p.noise_B + p.b0 + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, p.b0 + b, tid, kind);
+                if (tid < nmix) s.nz[tid] = -logf(-logf(r));                                         // Gumbel noise (mixture.py:138-140)
+                else s.nz[tid] = p.dist == 1 ? logf(r) - logf(1.0f - r) : r;                         // mixture.py:151-152 / :265-267
+            }
+            if (wave < 4) {                              // the whole skip sum (512 channels), every part
+                if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * p.KW + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
+                float2* v2 = reinterpret_cast<float2*>(s.vs + 128 * wave + 2 * lane);
+                *v2 = make_float2(fmaxf(v2->x * p.skip_scale, 0.f), fmaxf(v2->y * p.skip_scale, 0.f));     // wavenet.py:313-316
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+            if (q == 0) wstamp(p, b, t, p.L, 0, 0);                                                 // skip sum gathered
+            {
+                f2 a[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+                dot_quad<32>(w1, s.vs + 128 * (wave >> 1) + 32 * (lane >> 4), a);
+                s.ph[(wave >> 1) * 128 + (wave & 1) * 64 + lane] = reduce_quads(a);
+            }
+            __syncthreads();
+            if (tid < 128) s.hid[tid] = fmaxf(((s.ph[tid] + s.ph[128 + tid]) + (s.ph[256 + tid] + s.ph[384 + tid])) + b1, 0.f);      // wavenet.py:317-318
+            __syncthreads();
+            {
+                f2 a[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+                dot_quad<4>(w2, s.hid + 16 * wave + 4 * (lane >> 4), a);
+                s.pout[wave * 64 + lane] = reduce_quads(a);
+            }
+            __syncthreads();
+            if (wave == 0) {
+                float o = 0.f;
+                if (lane < p.O) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) o += s.pout[w * 64 + lane];
+                }
+                if (q > 0) {
+                    if (lane < p.O) st_granule(p.omail + ((size_t)b * 4 + q) * 64 + lane, tag, o, fast_parts);
+                } else {
+                    bool ok = true;
+                    for (int part = 1; part < 4 && ok; ++part) {                                     // partial outputs, in part order
+                        float v = 0.f;
+                        ok = recv_lanes(p.omail + ((size_t)b * 4 + part) * 64, p.O, tag, v, p.status, 0x480u + (unsigned)part, lane);
+                        o += v;
+                    }
+                    if (!ok) s.flags[0] = 1;
+                    o += b2;
+                    if (lane < p.O) {
+                        s.obuf[lane] = o;                                                            // wavenet.py:319
+                        if (lane < nmix) vbuf[lane] = o + s.nz[lane];
+                        if (p.params_out) p.params_out[((size_t)b * p.O + lane) * p.T + t] = o;
+                    }
+                }
+            }
+            if (q > 0) continue;                         // (parts 1 .. 3: back to the next skip sum; their LDS is fenced by the barriers above)
+            __syncthreads();
+            if (s.flags[0]) return;
+            {   // sample in every wave on its own (all 512 threads feed first_conv), then first_conv of step t + 1 (as run_wide_head)
+                float xo;
+                const float lr = s.nz[nmix];
+                float key = -INFINITY, mean = 0.f, ls = 0.f;
+                if (nmix == 0) { mean = s.obuf[o_mean]; ls = s.obuf[o_ls]; }                         // mixture.py:258-261
+                else if (lane < nmix && lane < 16) { key = vbuf[lane]; mean = s.obuf[o_mean + lane]; ls = s.obuf[o_ls + lane]; }     // mixture.py:143-146
+                float xc = p.dist == 1 ? mean + __expf(ls) * lr : lr * __expf(ls) + mean;
+                xc = fminf(fmaxf(xc, -1.0f), 1.0f);                                                  // mixture.py:154 / :269
+                if (nmix > 0) {
+                    float m = key;
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0xB1, 0xF, 0xF, true)));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x4E, 0xF, 0xF, true)));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x141, 0xF, 0xF, true)));
+                    m = fmaxf(m, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x140, 0xF, 0xF, true)));
+                    const unsigned long long win = __ballot(lane < nmix && lane < 16 && key == m);
+                    const int wl = win ? __ffsll((long long)win) - 1 : 0;
+                    xo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), wl));
+                } else {
+                    xo = xc;
+                }
+                if (t + 1 < p.T) {
+                    const float xs = t + 1 < p.Tt ? p.teacher[(size_t)b * p.Tt + t + 1] : xo;        // wavenet.py:297-305
+                    st_granule(p.xmail + ((size_t)b * (p.L + 1)) * XW + GHD + tid, tag + 1u, fmaf(wf, xs, bf), fast_first);
+                }
+                if (tid == 0) p.out[(size_t)b * p.T + t] = xo;
+            }
+            wstamp(p, b, t, p.L, 1, 0);                                                             // next input sent
+            __syncthreads();                                                                        // obuf / vbuf / nz are free again
+        }
+    }
+}
+
 // ---- head of one-hot (mu-law categorical) models: TWO workgroups, because the hidden layer (256 x 256) and the output layer
 // (out_channels x 256, 256 x 256 for mu-law 256) fill a register file each.  Part A: skip sum -> ReLU -> 1x1 -> ReLU -> publish the
 // hidden vector.  Part B: 1x1 -> softmax -> OneHotCategorical (sample_categorical of wnv_sample.h: argmax(p_hat / e)) -> first_conv
@@ -634,7 +776,7 @@ __device__ void run_wide_head_a(const WideParams& p, float* smem) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
         for (int b = 0; b < p.B; ++b) {
             if (wave < 2) {
-                if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * KWD + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
+                if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * p.KW + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
                 // (a lane rewrites the two values it has just stored)
                 float2* v2 = reinterpret_cast<float2*>(s.vs + 128 * wave + 2 * lane);
                 *v2 = make_float2(fmaxf(v2->x * p.skip_scale, 0.f), fmaxf(v2->y * p.skip_scale, 0.f));     // wavenet.py:313-316
@@ -746,6 +888,10 @@ __device__ void run_wide_head_b(const WideParams& p, bool fast_first, float* sme
 __global__ void __launch_bounds__(WT) wnv_wide_kernel(const WideParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int x = blockIdx.x & 7, li = blockIdx.x >> 3;
+    if (p.NB > 1 && x == p.head_x && li >= p.head_li && li < p.head_li + 4) {     // 257 .. 512 skip channels: four head parts on one XCD
+        run_wide_head512(p, li - p.head_li, p.fast && p.head_x == 0, p.fast != 0, smem);
+        return;
+    }
     if (x == p.head_x && li == p.head_li) {
         if (p.cin1 == 1) run_wide_head(p, p.fast && p.head_x == 0, smem);      // group 0 lives on XCD 0
         else run_wide_head_a(p, smem);
@@ -769,7 +915,7 @@ __global__ void __launch_bounds__(WT) wnv_wide_kernel(const WideParams p) {
 // =================================================================================================
 struct WnvWideState {
     int device = 0;
-    int L = 0, O = 0, cin = 0, cinp = 0, kw = 0, kpre = 0, nkb = 0, cin1 = 1;
+    int L = 0, O = 0, cin = 0, cinp = 0, kw = 0, kpre = 0, nkb = 0, cin1 = 1, NB = 1;
     float* d_w = nullptr;
     size_t o_wn = 0, o_wm = 0, o_wo = 0, o_ws = 0, o_wsl = 0, o_bo = 0, o_bs = 0, o_cvec = 0, o_wpre = 0, o_wh1 = 0, o_bh1 = 0, o_wh2 = 0, o_bh2 = 0, o_wf = 0, o_bf = 0;
     int* d_dil = nullptr;
@@ -788,10 +934,14 @@ static const char* wide_why_not(const wnv_config& c, int B) {
     if (c.scalar_input && c.out_channels > 64) return "scalar-input models need out_channels <= 64";
     if (!c.scalar_input && c.out_channels > 256) return "one-hot models need out_channels <= 256";
     if (c.residual_channels > RWD || c.gate_channels > 2 * GHD) return "needs residual_channels <= 512 and gate_channels <= 512";
-    if (c.skip_out_channels > KWD) return "needs skip_out_channels <= 256";
+    if (c.skip_out_channels > 2 * KWD) return "needs skip_out_channels <= 512";
+    if (c.skip_out_channels > KWD && !c.scalar_input) return "one-hot models need skip_out_channels <= 256";
+    if (c.skip_out_channels > KWD && c.output_distribution != 2 && c.out_channels > 48) return "models with more than 256 skip channels need at most 16 mixture components";
+    if (c.skip_out_channels > KWD && c.output_distribution == 2 && c.out_channels > 3 && c.out_channels > 48) return "models with more than 256 skip channels need at most 16 mixture components";
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 128) return "needs cin_channels <= 128";
     if (c.layers > 30) return "needs layers <= 30 (8 workgroups per layer and 8 for the tail, 32 CUs per XCD, one or two more for the head)";
+    if (c.skip_out_channels > KWD && ((c.layers + 1 + 7) / 8) * PG + 4 > 32 && c.layers + 1 > 7 * ((c.layers + 1 + 7) / 8)) return "no XCD has four free CUs for the head parts at this depth";
     (void)B;                                           // any batch: the host runs it in slices of 16 utterances
     return nullptr;
 }
@@ -821,6 +971,8 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
     const int L = c.layers, kw = c.kernel_size, cin = c.cin_channels > 0 ? c.cin_channels : 0, cinp = (cin + 15) & ~15;
     const int Ra = c.residual_channels, Ga = c.gate_channels, Gha = Ga / 2, Ka = c.skip_out_channels, O = c.out_channels;
     st->L = L; st->O = O; st->cin = cin; st->cinp = cinp; st->kw = kw;
+    const int NB = Ka > KWD ? 2 : 1, KW = KWD * NB;                  // skip banks of 256 channels
+    st->NB = NB;
     st->kpre = (kw - 1) * RWD + cinp; st->nkb = st->kpre / 4;
     std::vector<float> blob;
     auto alloc = [&](size_t n) { size_t o = (blob.size() + 3) & ~(size_t)3; blob.resize(o + n, 0.f); return o; };
@@ -833,10 +985,10 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
     st->o_wn = alloc((size_t)L * PG * n_wn);
     st->o_wm = alloc((size_t)L * PG * n_wm);
     st->o_wo = alloc((size_t)L * PG * n_wo);
-    st->o_ws = alloc((size_t)L * PG * n_ws);
-    st->o_wsl = alloc((size_t)PG * n_ws);
+    st->o_ws = alloc((size_t)L * 2 * PG * n_ws);                    // [layer][bank][slice]
+    st->o_wsl = alloc((size_t)2 * PG * n_ws);                       // [bank][slice]
     st->o_bo = alloc((size_t)L * RWD);
-    st->o_bs = alloc((size_t)(L + 1) * KWD);
+    st->o_bs = alloc((size_t)(L + 1) * KW);
     st->o_cvec = alloc((size_t)L * 2 * GHD);
     st->o_wpre = alloc((size_t)L * PG * n_pre);
     std::vector<int> dil(L), hoff(L);
@@ -848,12 +1000,12 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
     // skip image of layer `ls` for slice j
     // lane-quad images (dot_quad / dot_skip): lane = (column i = lane & 15, K quarter q = lane >> 4); row slot e of a lane
     auto quad_row = [&](int lane, int e) { static const int g[4] = {0, 2, 1, 3}; return 16 * g[e] + (lane & 15); };
-    auto put_skip = [&](float* is, const HostTensor& wsk, int j) {
+    auto put_skip = [&](float* is, const HostTensor& wsk, int j, int bank) {
         for (int w = 0; w < 8; ++w)
             for (int lane = 0; lane < 64; ++lane)
                 for (int cq = 0; cq < 4; ++cq)
                     for (int e = 0; e < 4; ++e) {
-                        const int so = KS * j + 16 * (e & 1) + (lane & 15);           // skip row
+                        const int so = KWD * bank + KS * j + 16 * (e & 1) + (lane & 15);           // skip row
                         const int k = 32 * w + 8 * (lane >> 4) + 2 * cq + (e >> 1);
                         is[(((size_t)w * 4 + cq) * 64 + lane) * 4 + e] = (so < Ka && k < Gha) ? wsk.data[(size_t)so * Gha + k] : 0.f;
                     }
@@ -909,8 +1061,10 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
                             io[(((size_t)w * 8 + cq) * 64 + lane) * 4 + e] = (l > 0 && ro < Ra && k < Gha) ? wout->data[(size_t)ro * Gha + k] : 0.f;
                         }
                     }
-            if (l > 0) put_skip(blob.data() + st->o_ws + (size_t)(l * PG + j) * n_ws, *wsk, j);
-            if (l == L - 1) put_skip(blob.data() + st->o_wsl + (size_t)j * n_ws, T(pfx + "conv1x1_skip.weight"), j);
+            for (int bank = 0; bank < NB; ++bank) {
+                if (l > 0) put_skip(blob.data() + st->o_ws + (size_t)((l * 2 + bank) * PG + j) * n_ws, *wsk, j, bank);
+                if (l == L - 1) put_skip(blob.data() + st->o_wsl + (size_t)(bank * PG + j) * n_ws, T(pfx + "conv1x1_skip.weight"), j, bank);
+            }
             for (int kb = 0; kb < st->kpre / 16; ++kb)                  // older taps (oldest first) then local conditioning: lane-quad blocks of 16 k, [kb][4][lane][4]
                 for (int cq = 0; cq < 4; ++cq)
                     for (int lane = 0; lane < 64; ++lane)
@@ -932,11 +1086,11 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
         if (l > 0) {
             std::copy(bout->data.begin(), bout->data.end(), blob.begin() + st->o_bo + (size_t)l * RWD);
             const HostTensor& bs = T(ppx + "conv1x1_skip.bias");
-            std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bs + (size_t)l * KWD);
+            std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bs + (size_t)l * KW);
         }
         if (l == L - 1) {
             const HostTensor& bs = T(pfx + "conv1x1_skip.bias");
-            std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bs + (size_t)L * KWD);
+            std::copy(bs.data.begin(), bs.data.end(), blob.begin() + st->o_bs + (size_t)L * KW);
         }
         dil[l] = 1 << (l % per);
         hoff[l] = (int)hist;
@@ -947,9 +1101,28 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
     // one-hot models rows lane + 64 q (q = 0 .. 3), K chunk 32 w -> [w][8 q + c][lane][4]
     const int cin1 = c.scalar_input ? 1 : O;
     st->cin1 = cin1;
-    st->o_wh1 = alloc((size_t)8 * 32 * 64 * 4);
-    st->o_wh2 = alloc((size_t)8 * (cin1 > 1 ? 32 : 8) * 64 * 4);
-    {
+    st->o_wh1 = alloc((size_t)(NB > 1 ? 4 : 1) * 8 * 32 * 64 * 4);
+    st->o_wh2 = alloc(NB > 1 ? (size_t)4 * 8 * 4 * 64 * 4 : (size_t)8 * (cin1 > 1 ? 32 : 8) * 64 * 4);
+    if (NB > 1) {
+        // four head parts (run_wide_head512): part q: W1 rows 128 q + (w & 1) 64 + .., K quarter (w >> 1), lane-quad -> [q][w][32][lane][4];
+        // W2 rows 0 .. 63, hidden span 128 q + 16 w + .., lane-quad -> [q][w][4][lane][4]
+        const HostTensor& w1 = T("last_conv_layers.1.weight");         // (K, K, 1)
+        const HostTensor& w2 = T("last_conv_layers.3.weight");         // (O, K, 1)
+        for (int q = 0; q < 4; ++q)
+            for (int w = 0; w < 8; ++w)
+                for (int lane = 0; lane < 64; ++lane) {
+                    for (int cq = 0; cq < 32; ++cq)
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = 128 * q + (w & 1) * 64 + quad_row(lane, e), k = 128 * (w >> 1) + 32 * (lane >> 4) + cq;
+                            blob[st->o_wh1 + ((((size_t)q * 8 + w) * 32 + cq) * 64 + lane) * 4 + e] = (row < Ka && k < Ka) ? w1.data[(size_t)row * Ka + k] : 0.f;
+                        }
+                    for (int cq = 0; cq < 4; ++cq)
+                        for (int e = 0; e < 4; ++e) {
+                            const int orow = quad_row(lane, e), k = 128 * q + 16 * w + 4 * (lane >> 4) + cq;
+                            blob[st->o_wh2 + ((((size_t)q * 8 + w) * 4 + cq) * 64 + lane) * 4 + e] = (orow < O && k < Ka) ? w2.data[(size_t)orow * Ka + k] : 0.f;
+                        }
+                }
+    } else {
         const HostTensor& w1 = T("last_conv_layers.1.weight");         // (K, K, 1)
         const HostTensor& w2 = T("last_conv_layers.3.weight");         // (O, K, 1)
         for (int w = 0; w < 8; ++w)
@@ -975,7 +1148,7 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
                 }
             }
     }
-    st->o_bh1 = alloc(KWD);
+    st->o_bh1 = alloc(KW);
     std::copy(T("last_conv_layers.1.bias").data.begin(), T("last_conv_layers.1.bias").data.end(), blob.begin() + st->o_bh1);
     st->o_bh2 = alloc(256);
     std::copy(T("last_conv_layers.3.bias").data.begin(), T("last_conv_layers.3.bias").data.end(), blob.begin() + st->o_bh2);
@@ -1038,7 +1211,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     const int nL = (NG + 7) / 8;                                     // groups per XCD
     // the head goes to the XCD of the tail group when that XCD has a free slot, else to the first XCD that has one
     int head_x = -1, head_li = -1;
-    const int n_head = st->cin1 > 1 ? 2 : 1;                        // one-hot models: the head is two workgroups
+    const int n_head = st->NB > 1 ? 4 : st->cin1 > 1 ? 2 : 1;      // one-hot models: two workgroups; more than 256 skip channels: four parts
     auto groups_on = [&](int x) { return std::max(0, std::min(nL, NG - x * nL)); };
     const int last_x = (NG - 1) / nL;
     for (int k = 0; k < 8 && head_x < 0; ++k) {
@@ -1051,6 +1224,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     p.dist = c.output_distribution; p.kpre = st->kpre; p.nkb = st->nkb;
     p.b0 = ga.b0; p.noise_B = ga.noise_B > 0 ? ga.noise_B : B;
     p.head_x = head_x; p.head_li = head_li;
+    p.NB = st->NB; p.KW = KWD * st->NB;
     p.cin1 = st->cin1; p.softmax = ga.softmax; p.quantize = ga.quantize; p.index_out = ga.index_out;
     { const char* e = getenv("WNV_RING_FAST"); p.fast = !(e && e[0] == '0'); }
     p.skip_scale = (float)std::sqrt(1.0 / L);
@@ -1063,9 +1237,10 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     p.hist_b_floats = (long long)PG * st->hist_layer_floats;
     // state: [status 64 B][X B (L+1) 768 u64][SK B (L+2) 256 u64][hidden B 256 u64][history B x 8 copies x layers]
     const size_t head_bytes = 64;
-    const size_t n_x = (size_t)B * (L + 1) * XW, n_s = (size_t)B * (L + 2) * KWD;
+    const size_t n_x = (size_t)B * (L + 1) * XW, n_s = (size_t)B * (L + 2) * KWD * st->NB;
     const size_t n_hid = (size_t)B * KWD;
-    const size_t mail_bytes = (n_x + n_s + n_hid) * sizeof(u64);
+    const size_t n_om = (size_t)B * 4 * 64;                         // partial head outputs of head parts 1 .. 3 (more than 256 skip channels)
+    const size_t mail_bytes = (n_x + n_s + n_hid + n_om) * sizeof(u64);
     const size_t hist_bytes = (size_t)B * p.hist_b_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -1090,10 +1265,11 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     p.xmail = (u64*)(base + head_bytes);
     p.smail = p.xmail + n_x;
     p.hidmail = p.smail + n_s;
-    p.hist = (float*)(p.hidmail + n_hid);
+    p.omail = p.hidmail + n_hid;
+    p.hist = (float*)(p.omail + n_om);
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.out = ga.out; p.params_out = ga.params_out;
-    const size_t lds = std::max(std::max(stage_lds_floats(p.kpre, B), HEAD_LDS_FLOATS), CAT_LDS_FLOATS) * sizeof(float);
+    const size_t lds = std::max(std::max(std::max(stage_lds_floats(p.kpre, B), HEAD_LDS_FLOATS), CAT_LDS_FLOATS), HEAD5_LDS_FLOATS) * sizeof(float);
     if (lds > 160 * 1024) { err = "wide kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
     WIDE_HIP(hipFuncSetAttribute((const void*)wnv_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
