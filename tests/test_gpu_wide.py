@@ -80,10 +80,13 @@ ONEHOT_WIDE = dict(out_channels=256, layers=6, stacks=2, residual_channels=512, 
                    dropout=0.0, cin_channels=80)        # the published CMU-ARCTIC geometry (mu-law 256 in / out), six layers of it
 
 
-def test_wide_onehot_vs_oracle_and_generic():
-    """One-hot wide models: the head is two workgroups (hidden layer | output layer + softmax + OneHotCategorical + first_conv row
+@pytest.mark.parametrize("K", [256, 512])
+def test_wide_onehot_vs_oracle_and_generic(K):
+    """(K = 512: the reference constructor's bare defaults -- wavenet.py:98-101: mu-law 256 in / out, 512 / 512 / 512 -- six layers of it
+    with an 80-mel conditioning added: four hidden-layer workgroups + two output-layer workgroups.)
+    One-hot wide models: the head is two workgroups (hidden layer | output layer + softmax + OneHotCategorical + first_conv row
     gather).  Teacher-forced probabilities against the oracle, sampled classes of a free run equal the oracle's until a near tie."""
-    kw = ONEHOT_WIDE
+    kw = dict(ONEHOT_WIDE, skip_out_channels=K)
     torch.manual_seed(29)
     m = tame_head_(wnv.WaveNet(**kw).eval())
     o = Oracle(oracle_config(kw), m.state_dict())

@@ -795,6 +795,40 @@ __device__ void run_wide_head_a(const WideParams& p, float* smem) {
     }
 }
 
+// one-hot models with 257 .. 512 skip channels: part A is FOUR workgroups (hidden units [128 q, 128 q + 128) each, as run_wide_head512),
+// part B two (the output layer's K halves; B1 sends its partial logits to B0)
+__device__ void run_wide_head512a(const WideParams& p, int q, float* smem) {
+    const Head5Lds s = carve_head5(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float4 w1[32];
+    load_img<32>(w1, p.wh1 + (size_t)q * 8 * 32 * 64 * 4, wave, lane);
+    const float b1 = tid < 128 ? p.bh1[128 * q + tid] : 0.f;
+    const bool fast = p.fast != 0;                         // the B parts sit on the same XCD
+    if (tid == 0) s.flags[0] = 0;
+    __syncthreads();
+    for (int t = 0; t < p.T; ++t) {
+        const unsigned tag = p.tag_base + (unsigned)t + 1u;
+        for (int b = 0; b < p.B; ++b) {
+            if (wave < 4) {
+                if (!recv128(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * p.KW + 128 * wave, tag, s.vs + 128 * wave, p.status, 0x400u, lane)) s.flags[0] = 1;
+                float2* v2 = reinterpret_cast<float2*>(s.vs + 128 * wave + 2 * lane);
+                *v2 = make_float2(fmaxf(v2->x * p.skip_scale, 0.f), fmaxf(v2->y * p.skip_scale, 0.f));     // wavenet.py:313-316
+            }
+            __syncthreads();
+            if (s.flags[0]) return;
+            {
+                f2 a[4] = {f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}, f2{0.f, 0.f}};
+                dot_quad<32>(w1, s.vs + 128 * (wave >> 1) + 32 * (lane >> 4), a);
+                s.ph[(wave >> 1) * 128 + (wave & 1) * 64 + lane] = reduce_quads(a);
+            }
+            __syncthreads();
+            if (tid < 128)                                                                              // wavenet.py:317-318
+                st_granule(p.hidmail + (size_t)b * p.KW + 128 * q + tid, tag, fmaxf(((s.ph[tid] + s.ph[128 + tid]) + (s.ph[256 + tid] + s.ph[384 + tid])) + b1, 0.f), fast);
+            __syncthreads();
+        }
+    }
+}
+
 struct CatLds {
     float *hid, *pout, *obuf, *nz, *vin;
     int* ints;
@@ -807,12 +841,12 @@ __device__ __forceinline__ CatLds carve_cat(float* smem) {
 }
 constexpr size_t CAT_LDS_FLOATS = KWD + 8 * 256 + 3 * 256 + 16;
 
-__device__ void run_wide_head_b(const WideParams& p, bool fast_first, float* smem) {
+__device__ void run_wide_head_b(const WideParams& p, bool fast_first, int part, int nparts, float* smem) {
     const CatLds s = carve_cat(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int O = p.O;
     float4 w2[32];                                         // rows lane + 64 q (q = 0 .. 3), K chunk 32 wave: [wave][q * 8 + c][lane][4]
-    load_img<32>(w2, p.wh2, wave, lane);
+    load_img<32>(w2, p.wh2 + (size_t)part * 8 * 32 * 64 * 4, wave, lane);      // (part: the hidden half [256 part, 256 part + 256) of a 512-wide hidden layer)
     const float b2 = tid < O ? p.bh2[tid] : 0.f;
     const float bf = p.bfirst[tid];
     if (tid == 0) { s.ints[0] = 0; s.ints[1] = 127; }     // abort flag; sampled class
@@ -832,16 +866,16 @@ __device__ void run_wide_head_b(const WideParams& p, bool fast_first, float* sme
         }
         st_granule(p.xmail + ((size_t)b * (p.L + 1)) * XW + GHD + tid, tag_next, h, fast_first);
     };
-    for (int b = 0; b < p.B; ++b) {                        // wavenet.py:283-289: one-hot of class 127 unless given
+    for (int b = 0; b < p.B && part == 0; ++b) {           // wavenet.py:283-289: one-hot of class 127 unless given
         const float* dense = p.Tt > 0 ? p.teacher + (size_t)b * p.Tt * O : (p.initial ? p.initial + (size_t)b * O : nullptr);
         send_input(b, dense, 127, p.tag_base + 1u);
     }
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
         for (int b = 0; b < p.B; ++b) {
-            if (tid < O) s.nz[tid] = p.noise ? p.noise[((size_t)t * p.noise_B + p.b0 + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, p.b0 + b, tid, 2);   // e ~ Exp(1)
+            if (part == 0 && tid < O) s.nz[tid] = p.noise ? p.noise[((size_t)t * p.noise_B + p.b0 + b) * p.nz + tid] : wnv_noise_gen(p.seed, t, p.b0 + b, tid, 2);   // e ~ Exp(1)
             if (wave < 2) {
-                if (!recv128(p.hidmail + (size_t)b * KWD + 128 * wave, tag, s.hid + 128 * wave, p.status, 0x480u, lane)) s.ints[0] = 1;
+                if (!recv128(p.hidmail + (size_t)b * p.KW + 256 * part + 128 * wave, tag, s.hid + 128 * wave, p.status, 0x480u, lane)) s.ints[0] = 1;
             }
             __syncthreads();
             if (s.ints[0]) return;
@@ -853,14 +887,33 @@ __device__ void run_wide_head_b(const WideParams& p, bool fast_first, float* sme
                 s.pout[wave * 256 + 64 * q + lane] = dot_bcast<8>(wq, s.hid + 32 * wave);
             }
             __syncthreads();
-            if (tid < O) {
-                float o = b2;
+            if (part > 0) {                                        // the other K half: partial logits -> part 0
+                if (tid < O) {
+                    float o = 0.f;
 #pragma unroll
-                for (int w = 0; w < 8; ++w) o += s.pout[w * 256 + tid];
-                s.obuf[tid] = o;                                                                     // wavenet.py:319
-                if (p.params_out) p.params_out[((size_t)b * O + tid) * p.T + t] = o;
+                    for (int w = 0; w < 8; ++w) o += s.pout[w * 256 + tid];
+                    st_granule(p.omail + (size_t)b * 256 + tid, tag, o, p.fast != 0);
+                }
+                __syncthreads();
+                continue;
+            }
+            {
+                float o = b2, other = 0.f;
+                if (tid < O) {
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) o += s.pout[w * 256 + tid];
+                }
+                if (nparts > 1 && wave < 4 && 64 * wave < O) {
+                    if (!recv_lanes(p.omail + (size_t)b * 256 + 64 * wave, min(64, O - 64 * wave), tag, other, p.status, 0x490u, lane)) s.ints[0] = 1;
+                    o += other;
+                }
+                if (tid < O) {
+                    s.obuf[tid] = o;                                                                 // wavenet.py:319
+                    if (p.params_out) p.params_out[((size_t)b * O + tid) * p.T + t] = o;
+                }
             }
             __syncthreads();
+            if (s.ints[0]) return;
             if (wave == 0) {                                                                         // wavenet.py:332-335
                 const int idx = sample_categorical(O, s.obuf, s.nz, p.softmax, p.quantize, lane);
                 if (p.quantize) {
@@ -889,7 +942,12 @@ __global__ void __launch_bounds__(WT) wnv_wide_kernel(const WideParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int x = blockIdx.x & 7, li = blockIdx.x >> 3;
     if (p.NB > 1 && x == p.head_x && li >= p.head_li && li < p.head_li + 4) {     // 257 .. 512 skip channels: four head parts on one XCD
-        run_wide_head512(p, li - p.head_li, p.fast && p.head_x == 0, p.fast != 0, smem);
+        if (p.cin1 == 1) run_wide_head512(p, li - p.head_li, p.fast && p.head_x == 0, p.fast != 0, smem);
+        else run_wide_head512a(p, li - p.head_li, smem);
+        return;
+    }
+    if (p.NB > 1 && p.cin1 > 1 && x == p.head_x && (li == p.head_li + 4 || li == p.head_li + 5)) {     // ... and, one-hot, the two output-layer parts
+        run_wide_head_b(p, p.fast && p.head_x == 0, li - p.head_li - 4, 2, smem);
         return;
     }
     if (x == p.head_x && li == p.head_li) {
@@ -898,7 +956,7 @@ __global__ void __launch_bounds__(WT) wnv_wide_kernel(const WideParams p) {
         return;
     }
     if (p.cin1 > 1 && x == p.head_x && li == p.head_li + 1) {
-        run_wide_head_b(p, p.fast && p.head_x == 0, smem);
+        run_wide_head_b(p, p.fast && p.head_x == 0, 0, 1, smem);
         return;
     }
     const int sl = li / PG, j = li % PG, l = x * p.nL + sl;         // groups 0 .. L-1: the layers; group L: the tail
@@ -935,13 +993,10 @@ static const char* wide_why_not(const wnv_config& c, int B) {
     if (!c.scalar_input && c.out_channels > 256) return "one-hot models need out_channels <= 256";
     if (c.residual_channels > RWD || c.gate_channels > 2 * GHD) return "needs residual_channels <= 512 and gate_channels <= 512";
     if (c.skip_out_channels > 2 * KWD) return "needs skip_out_channels <= 512";
-    if (c.skip_out_channels > KWD && !c.scalar_input) return "one-hot models need skip_out_channels <= 256";
-    if (c.skip_out_channels > KWD && c.output_distribution != 2 && c.out_channels > 48) return "models with more than 256 skip channels need at most 16 mixture components";
-    if (c.skip_out_channels > KWD && c.output_distribution == 2 && c.out_channels > 3 && c.out_channels > 48) return "models with more than 256 skip channels need at most 16 mixture components";
+    if (c.skip_out_channels > KWD && c.scalar_input && c.out_channels > 48) return "scalar-input models with more than 256 skip channels need at most 16 mixture components";
     if (c.kernel_size < 2 || c.kernel_size > 4) return "needs 2 <= kernel_size <= 4";
     if (c.cin_channels > 128) return "needs cin_channels <= 128";
     if (c.layers > 30) return "needs layers <= 30 (8 workgroups per layer and 8 for the tail, 32 CUs per XCD, one or two more for the head)";
-    if (c.skip_out_channels > KWD && ((c.layers + 1 + 7) / 8) * PG + 4 > 32 && c.layers + 1 > 7 * ((c.layers + 1 + 7) / 8)) return "no XCD has four free CUs for the head parts at this depth";
     (void)B;                                           // any batch: the host runs it in slices of 16 utterances
     return nullptr;
 }
@@ -1102,7 +1157,7 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
     const int cin1 = c.scalar_input ? 1 : O;
     st->cin1 = cin1;
     st->o_wh1 = alloc((size_t)(NB > 1 ? 4 : 1) * 8 * 32 * 64 * 4);
-    st->o_wh2 = alloc(NB > 1 ? (size_t)4 * 8 * 4 * 64 * 4 : (size_t)8 * (cin1 > 1 ? 32 : 8) * 64 * 4);
+    st->o_wh2 = alloc(NB > 1 ? (cin1 > 1 ? (size_t)2 * 8 * 32 * 64 * 4 : (size_t)4 * 8 * 4 * 64 * 4) : (size_t)8 * (cin1 > 1 ? 32 : 8) * 64 * 4);
     if (NB > 1) {
         // four head parts (run_wide_head512): part q: W1 rows 128 q + (w & 1) 64 + .., K quarter (w >> 1), lane-quad -> [q][w][32][lane][4];
         // W2 rows 0 .. 63, hidden span 128 q + 16 w + .., lane-quad -> [q][w][4][lane][4]
@@ -1116,11 +1171,20 @@ static wnv_status wide_build(WnvWideState** out, int device, const wnv_config& c
                             const int row = 128 * q + (w & 1) * 64 + quad_row(lane, e), k = 128 * (w >> 1) + 32 * (lane >> 4) + cq;
                             blob[st->o_wh1 + ((((size_t)q * 8 + w) * 32 + cq) * 64 + lane) * 4 + e] = (row < Ka && k < Ka) ? w1.data[(size_t)row * Ka + k] : 0.f;
                         }
-                    for (int cq = 0; cq < 4; ++cq)
-                        for (int e = 0; e < 4; ++e) {
-                            const int orow = quad_row(lane, e), k = 128 * q + 16 * w + 4 * (lane >> 4) + cq;
-                            blob[st->o_wh2 + ((((size_t)q * 8 + w) * 4 + cq) * 64 + lane) * 4 + e] = (orow < O && k < Ka) ? w2.data[(size_t)orow * Ka + k] : 0.f;
-                        }
+                    if (cin1 == 1) {
+                        for (int cq = 0; cq < 4; ++cq)
+                            for (int e = 0; e < 4; ++e) {
+                                const int orow = quad_row(lane, e), k = 128 * q + 16 * w + 4 * (lane >> 4) + cq;
+                                blob[st->o_wh2 + ((((size_t)q * 8 + w) * 4 + cq) * 64 + lane) * 4 + e] = (orow < O && k < Ka) ? w2.data[(size_t)orow * Ka + k] : 0.f;
+                            }
+                    } else if (q < 2) {                                 // one-hot: output-layer part q = hidden half [256 q, 256 q + 256): rows lane + 64 r, K chunk 32 w
+                        for (int r = 0; r < 4; ++r)
+                            for (int cq = 0; cq < 8; ++cq)
+                                for (int e = 0; e < 4; ++e) {
+                                    const int k = 256 * q + 32 * w + 4 * cq + e, orow = lane + 64 * r;
+                                    blob[st->o_wh2 + ((((size_t)q * 8 + w) * 32 + 8 * r + cq) * 64 + lane) * 4 + e] = (orow < O && k < Ka) ? w2.data[(size_t)orow * Ka + k] : 0.f;
+                                }
+                    }
                 }
     } else {
         const HostTensor& w1 = T("last_conv_layers.1.weight");         // (K, K, 1)
@@ -1211,7 +1275,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     const int nL = (NG + 7) / 8;                                     // groups per XCD
     // the head goes to the XCD of the tail group when that XCD has a free slot, else to the first XCD that has one
     int head_x = -1, head_li = -1;
-    const int n_head = st->NB > 1 ? 4 : st->cin1 > 1 ? 2 : 1;      // one-hot models: two workgroups; more than 256 skip channels: four parts
+    const int n_head = st->NB > 1 ? (st->cin1 > 1 ? 6 : 4) : st->cin1 > 1 ? 2 : 1;      // one-hot models: two workgroups; more than 256 skip channels: four parts (+ two for a one-hot output layer)
     auto groups_on = [&](int x) { return std::max(0, std::min(nL, NG - x * nL)); };
     const int last_x = (NG - 1) / nL;
     for (int k = 0; k < 8 && head_x < 0; ++k) {
@@ -1238,7 +1302,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     // state: [status 64 B][X B (L+1) 768 u64][SK B (L+2) 256 u64][hidden B 256 u64][history B x 8 copies x layers]
     const size_t head_bytes = 64;
     const size_t n_x = (size_t)B * (L + 1) * XW, n_s = (size_t)B * (L + 2) * KWD * st->NB;
-    const size_t n_hid = (size_t)B * KWD;
+    const size_t n_hid = (size_t)B * KWD * st->NB;
     const size_t n_om = (size_t)B * 4 * 64;                         // partial head outputs of head parts 1 .. 3 (more than 256 skip channels)
     const size_t mail_bytes = (n_x + n_s + n_hid + n_om) * sizeof(u64);
     const size_t hist_bytes = (size_t)B * p.hist_b_floats * sizeof(float);
