@@ -193,7 +193,11 @@ def test_unsupported_configs_say_so():
         eng.generate(B=1, T=16, c_up=cz, kernel=2)
     out, _, _ = eng.generate(B=1, T=16, c_up=cz, kernel=0)            # auto: the group ring for wide models
     assert eng.last_kernel() == 3 and torch.isfinite(out).all()
-    kw = dict(kw, skip_out_channels=512)                              # 512 skip channels on a wide model: neither persistent kernel
+    kw = dict(kw, skip_out_channels=512)                              # 512 skip channels on a wide model: the group ring since round 3
+    eng = wnv.WaveNet(**kw).eval().to("cuda")._get_engine()
+    out, _, _ = eng.generate(B=1, T=16, c_up=cz, kernel=0)
+    assert eng.last_kernel() == 3 and torch.isfinite(out).all()
+    kw = dict(kw, skip_out_channels=640)                              # beyond 512: neither persistent kernel
     eng = wnv.WaveNet(**kw).eval().to("cuda")._get_engine()
     with pytest.raises(NotImplementedError, match="group-ring kernel"):
         eng.generate(B=1, T=16, c_up=cz, kernel=3)
