@@ -4,24 +4,40 @@
 #include <hip/hip_runtime.h>
 
 namespace {
+// Wave-wide all-reduces without the LDS crossbar (round 3): four DPP steps inside a row of 16 lanes (quad_perm x 2, row_half_mirror,
+// row_mirror), then v_permlane16_swap / v_permlane32_swap across the rows -- six VALU instructions instead of six ds_bpermute round
+// trips (~0.1 us each): the 256-way softmax + multinomial of a mu-law step does four of these in a row (wavenet.py:332-335).
+template <int CTRL> __device__ __forceinline__ float wnv_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL> __device__ __forceinline__ int wnv_dpp_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// the value of the lane 16 / 32 away (rows 0 <-> 1, 2 <-> 3;  halves 0 <-> 1)
+__device__ __forceinline__ float wnv_xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(((threadIdx.x >> 4) & 1) ? r[0] : r[1]);        // (r[0]: odd rows hold the even rows' values; r[1]: even rows hold the odd rows')
+}
+__device__ __forceinline__ float wnv_xor32(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(((threadIdx.x >> 5) & 1) ? r[0] : r[1]);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += wnv_dpp<0xB1>(v); v += wnv_dpp<0x4E>(v); v += wnv_dpp<0x141>(v); v += wnv_dpp<0x140>(v);
+    v += wnv_xor16(v);
+    return v + wnv_xor32(v);
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, wnv_dpp<0xB1>(v)); v = fmaxf(v, wnv_dpp<0x4E>(v)); v = fmaxf(v, wnv_dpp<0x141>(v)); v = fmaxf(v, wnv_dpp<0x140>(v));
+    v = fmaxf(v, wnv_xor16(v));
+    return fmaxf(v, wnv_xor32(v));
 }
-// argmax with first-index tie break (torch.max / argmax semantics on CPU)
+// argmax with first-index tie break (torch.max / argmax semantics on CPU): the wave maximum, then the smallest index that attains it
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o, 64);
-        const int oi = __shfl_xor(i, o, 64);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
+    const float m = wave_max(v);
+    int c = v == m ? i : 0x7fffffff;
+    c = min(c, wnv_dpp_i<0xB1>(c)); c = min(c, wnv_dpp_i<0x4E>(c)); c = min(c, wnv_dpp_i<0x141>(c)); c = min(c, wnv_dpp_i<0x140>(c));
+    c = min(c, __float_as_int(wnv_xor16(__int_as_float(c))));
+    c = min(c, __float_as_int(wnv_xor32(__int_as_float(c))));
+    v = m; i = c;
 }
 
 // ---- sampling (wave 0 only) ----------------------------------------------------------------------
