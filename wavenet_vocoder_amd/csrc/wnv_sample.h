@@ -72,6 +72,47 @@ __device__ __forceinline__ float sample_scalar(int dist, int O, const float* obu
 // class (when quantize), else -1.
 __device__ __forceinline__ int sample_categorical(int O, float* obuf, const float* nzv,
                                                   int softmax, int quantize, int lane) {
+    // up to 256 classes: a lane keeps its (at most four) classes n = lane + 64 k in registers through all stages -- one LDS read of the
+    // logits and the noise, one write of the probabilities (round 2 went through LDS between the stages: five round trips);
+    // the per-lane partial sums run over k in the order the strided loops did
+    if (O <= 256) {
+        float x[4], e[4];
+        bool on[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            on[k] = lane + 64 * k < O;
+            x[k] = on[k] ? obuf[lane + 64 * k] : 0.f;
+            e[k] = (on[k] && quantize) ? nzv[lane + 64 * k] : 1.f;
+        }
+        if (softmax) {                                                          // wavenet.py:332
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (on[k]) mx = fmaxf(mx, x[k]);
+            mx = wave_max(mx);
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (on[k]) { x[k] = expf(x[k] - mx); s += x[k]; }
+            s = wave_sum(s);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (on[k]) { x[k] = x[k] / s; obuf[lane + 64 * k] = x[k]; }
+        }
+        if (!quantize) return -1;
+        // OneHotCategorical(p).sample(): Categorical renormalises, multinomial takes argmax(p_hat / e)
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (on[k]) s2 += x[k];
+        s2 = wave_sum(s2);
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!on[k]) continue;
+            const float q = (x[k] / s2) / e[k];
+            if (q > best) { best = q; bi = lane + 64 * k; }
+        }
+        wave_argmax(best, bi);
+        return bi;
+    }
     if (softmax) {                                                              // wavenet.py:332
         float mx = -INFINITY;
         for (int n = lane; n < O; n += 64) mx = fmaxf(mx, obuf[n]);
