@@ -1427,15 +1427,39 @@ __device__ void run_head_part(const RingParams& p, int ring, int part, float* sm
     }
 }
 
-// part 0 collects the partial outputs of parts 1 .. NH-1 (lanes q == 0 own output row `row`); in part order
-__device__ __forceinline__ bool head_collect(const RingParams& p, int b, unsigned tag, int row, bool active, float& o, int lane) {
-    bool ok = true;
-    for (int part = 1; part < p.NH && ok; ++part) {
-        float v = 0.f;
-        ok = wave_recv<false>(p.omail + ((size_t)b * p.NH + part) * p.Op + row, active, tag, v, p.status, 0x380u + (unsigned)part, lane);
-        o += v;
+// part 0 collects the partial outputs of parts 1 .. NH-1 (lanes q == 0 own output rows row + RC r, r < NR); every granule a lane
+// waits for is polled in the SAME round trip (round 2 polled part after part and row after row: up to three / two extra L2 round
+// trips behind the arrival); the sums are formed in part order
+template <int NR>
+__device__ __forceinline__ bool head_collect(const RingParams& p, int b, unsigned tag, int row, const bool (&active)[NR], float (&o)[NR], int lane) {
+    constexpr int MAXP = 3;                                                     // NH <= 4
+    const u64* g = p.omail + ((size_t)b * p.NH + 1) * p.Op + row;
+    const int np = p.NH - 1;
+    float v[NR][MAXP];
+    unsigned spins = 0;
+    for (;;) {
+        u64 x[NR][MAXP];
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k)
+                x[r][k] = (active[r] && k < np) ? ld_granule(g + (size_t)k * p.Op + RC * r) : ((u64)tag << 32);
+        bool ok = true;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+            for (int k = 0; k < MAXP; ++k) { v[r][k] = __uint_as_float((unsigned)x[r][k]); ok = ok && (unsigned)(x[r][k] >> 32) == tag; }
+        if (__all(ok)) break;
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(p.status, 0u, 0x381u); return false; }
+        }
     }
-    return ok;
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int k = 0; k < MAXP; ++k) if (k < np) o[r] += v[r][k];
+    return true;
 }
 
 template <int NK, bool L0, bool SPLIT>
@@ -1593,7 +1617,12 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             float x[32];
             lds_read32(s.hid + QS * q, x);
             float o = quad_allreduce(dot32p(w.wh2[0], x));                        // wavenet.py:319
-            if (NK > 1 && !head_collect(p, b, tag, i, q == 0 && i < p.O, o, lane)) s.flags[0] = 1;
+            if (NK > 1) {
+                const bool act[1] = {q == 0 && i < p.O};
+                float ov[1] = {o};
+                if (!head_collect<1>(p, b, tag, i, act, ov, lane)) s.flags[0] = 1;
+                o = ov[0];
+            }
             o += bh2;
             if (q == 0 && i < p.O) {
                 s.obuf[i] = o;
@@ -1731,8 +1760,10 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
             float oa = quad_allreduce(dot32p(w.wh2[0], x));                       // wavenet.py:319, rows i and 128 + i
             float ob = quad_allreduce(dot32p(w.wh2[1], x));
             if (NK > 1) {
-                if (!head_collect(p, b, tag, i, q == 0 && i < O, oa, lane)) s.ints[0] = 1;
-                if (!head_collect(p, b, tag, RC + i, q == 0 && RC + i < O, ob, lane)) s.ints[0] = 1;
+                const bool act[2] = {q == 0 && i < O, q == 0 && RC + i < O};
+                float ov[2] = {oa, ob};
+                if (!head_collect<2>(p, b, tag, i, act, ov, lane)) s.ints[0] = 1;
+                oa = ov[0]; ob = ov[1];
             }
             oa += bh2a; ob += bh2b;
             if (q == 0) {
@@ -1740,24 +1771,28 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
                 if (RC + i < O) { s.obuf[RC + i] = ob; if (p.params_out) p.params_out[((size_t)b * O + RC + i) * p.T + t] = ob; }
             }
             __syncthreads();
-            if (wave == 0) {                                                        // wavenet.py:332-335
+            // wavenet.py:332-335, then :297-308 for step t + 1.  Waves 0 and 1 each sample on their own (same inputs, same class) and send
+            // their 64 channels of first_conv's row at once: no barrier and no LDS round trip between the argmax and the chain store
+            const bool dense_next = t + 1 < p.Tt || !p.quantize;
+            if (wave < (p.quantize ? 2 : 1)) {              // (quantize = False: the probabilities go back into obuf -- one wave)
                 const int idx = sample_categorical(O, s.obuf, s.nzb, p.softmax, p.quantize, lane);
                 if (p.quantize) {
-                    if (lane == 0) {
+                    if (t + 1 < p.T && !dense_next) {
+                        st_granule(p.xmail + ((size_t)b * S1) * RC + tid, tag + 1u, s.wfl[(size_t)idx * RC + tid] + bf, fast);
+                        WNV_TS(0);
+                    }
+                    if (tid == 0) {
                         p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;             // out is pre-zeroed by the host
                         if (p.index_out) p.index_out[(size_t)b * p.T + t] = idx;
-                        s.ints[1] = idx;
                     }
-                } else {
+                } else if (wave == 0) {
                     for (int n = lane; n < O; n += 64) p.out[((size_t)b * O + n) * p.T + t] = s.obuf[n];
                 }
             }
             __syncthreads();
-            if (t + 1 < p.T) {                                                      // wavenet.py:297-308 for step t + 1
-                const float* dense = nullptr;
-                if (t + 1 < p.Tt) dense = p.teacher + ((size_t)b * p.Tt + t + 1) * O;
-                else if (!p.quantize) dense = s.obuf;                               // fed-back probabilities
-                send_input(b, dense, s.ints[1], tag + 1u);
+            if (t + 1 < p.T && dense_next) {
+                // teacher-forced input, or fed-back probabilities (quantize = False, tests only)
+                send_input(b, t + 1 < p.Tt ? p.teacher + ((size_t)b * p.Tt + t + 1) * O : s.obuf, 0, tag + 1u);
                 WNV_TS(0);
             }
             WNV_TS(2);

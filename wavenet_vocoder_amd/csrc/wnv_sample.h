@@ -94,7 +94,8 @@ __device__ __forceinline__ int sample_categorical(int O, float* obuf, const floa
             for (int k = 0; k < 4; ++k) if (on[k]) { x[k] = expf(x[k] - mx); s += x[k]; }
             s = wave_sum(s);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (on[k]) { x[k] = x[k] / s; obuf[lane + 64 * k] = x[k]; }
+            for (int k = 0; k < 4; ++k) if (on[k]) { x[k] = x[k] / s; if (!quantize) obuf[lane + 64 * k] = x[k]; }   // (quantize: nobody reads them,
+            // and a second wave sampling the same step may still be reading the logits)
         }
         if (!quantize) return -1;
         // OneHotCategorical(p).sample(): Categorical renormalises, multinomial takes argmax(p_hat / e)
