@@ -103,6 +103,11 @@ CASES = {
                                    upsample_conditional_features=True,
                                    upsample_params=dict(upsample_scales=[4, 2], cin_channels=6, cin_pad=1, mode="bilinear"),
                                    **COMPACT), 2, 40, 40, {}),
+    # ... and mode="bicubic" (round 3; "area" / "nearest-exact" equal "nearest" for integer factors: tests/test_host_cpu.py)
+    "mol_upsample_bicubic": (dict(out_channels=30, cin_channels=6, cin_pad=1, scalar_input=True,
+                                  upsample_conditional_features=True,
+                                  upsample_params=dict(upsample_scales=[3, 4], cin_channels=6, cin_pad=1, mode="bicubic"),
+                                  **COMPACT), 2, 48, 48, {}),
 }
 
 

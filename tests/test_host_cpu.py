@@ -323,22 +323,33 @@ def test_bulk_noise_tape_equals_the_per_step_replay(scalar, dist, C):
 
 
 def test_upsample_stretch_modes():
-    """Stretch2d: "nearest" and "bilinear" (upsample.py:19-21) are implemented -- on the device too (wnv_config.upsample_mode, pinned by the
-    reference-made fixture mol_upsample_bilinear); anything else is refused by the host module and by make_config."""
+    """Stretch2d (upsample.py:19-21): every mode F.interpolate accepts for a 4-D map is taken -- on the device too
+    (wnv_config.upsample_mode 0 / 1 / 2, pinned by the reference-made fixtures mol_upsample_bilinear / mol_upsample_bicubic).
+    "area" and "nearest-exact" share mode 0 with "nearest": for integer factors they pick the same sample (checked here against
+    torch); the 3-D / 5-D modes are refused like F.interpolate refuses them."""
     import torch.nn.functional as F
     from wavenet_vocoder_amd.upsample import Stretch2d
     from wavenet_vocoder_amd.engine import make_config
     x = torch.randn(2, 1, 5, 7)
     assert torch.equal(Stretch2d(3, 1, "nearest")(x), F.interpolate(x, scale_factor=(1, 3), mode="nearest"))
-    assert torch.equal(Stretch2d(4, 1, "bilinear")(x), F.interpolate(x, scale_factor=(1, 4), mode="bilinear"))
+    for mode in ("bilinear", "bicubic", "area", "nearest-exact"):
+        assert torch.equal(Stretch2d(4, 1, mode)(x), F.interpolate(x, scale_factor=(1, 4), mode=mode))
+    xl = torch.randn(1, 1, 3, 4001)
+    for s in (2, 3, 4, 5, 7, 11, 16):
+        near = F.interpolate(xl, scale_factor=(1, s), mode="nearest")
+        assert torch.equal(near, xl.repeat_interleave(s, dim=3))                # what device mode 0 computes: in[q / s]
+        assert torch.equal(F.interpolate(xl, scale_factor=(1, s), mode="area"), near)
+        assert torch.equal(F.interpolate(xl, scale_factor=(1, s), mode="nearest-exact"), near)
     with pytest.raises(NotImplementedError):
-        Stretch2d(2, 1, "bicubic")
+        Stretch2d(2, 1, "trilinear")
     kw = dict(out_channels=30, layers=2, stacks=1, residual_channels=8, gate_channels=16, skip_out_channels=8, kernel_size=2, cin_channels=4,
               gin_channels=-1, n_speakers=None, use_speaker_embedding=False, scalar_input=True, output_distribution="Logistic",
               upsample_net="ConvInUpsampleNetwork", upsample_scales=[2, 2], freq_axis_kernel_size=1, cin_pad=0)
     assert make_config(**kw, upsample_mode="bilinear").upsample_mode == 1 and make_config(**kw).upsample_mode == 0
+    assert make_config(**kw, upsample_mode="bicubic").upsample_mode == 2
+    assert make_config(**kw, upsample_mode="area").upsample_mode == 0 and make_config(**kw, upsample_mode="nearest-exact").upsample_mode == 0
     with pytest.raises(NotImplementedError):
-        make_config(**kw, upsample_mode="area")
+        make_config(**kw, upsample_mode="linear")
 
 
 def test_fast_exponential_draws_are_torchs_own():

@@ -25,7 +25,9 @@ UPSAMPLE = {None: 0, "none": 0, "ConvInUpsampleNetwork": 1, "UpsampleNetwork": 2
 UPSAMPLE_ACT = {"none": (0, None), "ReLU": (1, None), "LeakyReLU": (2, "negative_slope"), "Tanh": (3, None), "Sigmoid": (4, None), "ELU": (5, "alpha")}
 UPSAMPLE_ACT_DEFAULT = {"negative_slope": 0.01, "alpha": 1.0}
 # Stretch2d mode (upsample.py:19-21: F.interpolate(x, scale_factor=(1, s), mode=mode)) -> wnv_config.upsample_mode
-UPSAMPLE_MODE = {"nearest": 0, "bilinear": 1}
+# ("area" -- adaptive average pooling -- and "nearest-exact" pick the same single sample as "nearest" when the factor is an integer, which
+#  Stretch2d's factors are; "linear" / "trilinear" are for 3-D / 5-D inputs: F.interpolate itself refuses them for Stretch2d's 4-D map)
+UPSAMPLE_MODE = {"nearest": 0, "area": 0, "nearest-exact": 0, "bilinear": 1, "bicubic": 2}
 
 # status codes -> Python exceptions (include/wnv.h "Conventions")
 _STATUS_EXC = {

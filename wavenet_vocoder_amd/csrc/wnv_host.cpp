@@ -128,7 +128,7 @@ static wnv_status validate_config(const wnv_config* c) {
         if (c->freq_axis_kernel_size < 1 || c->freq_axis_kernel_size > 15 || c->freq_axis_kernel_size % 2 == 0)
             return fail(WNV_ERR_UNSUPPORTED, "freq_axis_kernel_size %d: an odd size <= 15 is implemented", c->freq_axis_kernel_size);
         if (c->upsample_activation < 0 || c->upsample_activation > WNV_UPACT_ELU) return fail(WNV_ERR_INVALID_ARG, "unknown upsample_activation %d", c->upsample_activation);
-        if (c->upsample_mode < 0 || c->upsample_mode > 1) return fail(WNV_ERR_UNSUPPORTED, "upsample_mode %d: 0 (nearest) and 1 (bilinear) are implemented", c->upsample_mode);
+        if (c->upsample_mode < 0 || c->upsample_mode > 2) return fail(WNV_ERR_UNSUPPORTED, "upsample_mode %d: 0 (nearest; also what area / nearest-exact do for integer factors), 1 (bilinear) and 2 (bicubic) are implemented", c->upsample_mode);
         for (int i = 0; i < c->n_upsample_scales; ++i)
             if (c->upsample_scales[i] < 1) return fail(WNV_ERR_INVALID_ARG, "upsample scale < 1");
     }

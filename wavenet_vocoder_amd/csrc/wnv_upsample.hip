@@ -51,10 +51,31 @@ __device__ __forceinline__ float up_act(float x, int act, float a) {
 // sample q of the stretched row (upsample.py:19-21, F.interpolate(x, scale_factor=(1, s), mode=...)): nearest = in[q / s]; bilinear with
 // align_corners = False (torch's default): source position ratio (q + 0.5) - 0.5 with ratio = 1 / s, clamped at 0, the right neighbour
 // clamped at the last sample (ATen UpSample.h: area_pixel_compute_source_index / compute_source_index_and_lambda); the mel-bin axis has
-// scale 1, i.e. is copied
+// scale 1, i.e. is copied.  bicubic (mode 2): the same source position WITHOUT the clamp at 0, four taps floor(src) - 1 .. + 2 with their
+// indices clamped to the row, Keys' kernel with A = -0.75 (ATen UpSample.h: cubic_convolution1/2, get_cubic_upsample_coefficients,
+// upsample_get_value_bounded); along the mel-bin axis (scale 1) the fraction is 0 and the coefficients are exactly {0, 1, 0, 0}: a copy.
+// ("area" = adaptive average pooling and "nearest-exact" pick the same single sample as "nearest" for an integer factor: the host maps
+//  them to mode 0, tests/test_host_cpu.py checks that against F.interpolate.)
 __device__ __forceinline__ float stretched(const float* row, long long q, int scale, long long Tin, int mode) {
     if (mode == 0) return row[q / scale];
     const float ratio = (float)(1.0 / (double)scale);
+    if (mode == 2) {
+        const float A = -0.75f;
+        const float real = ratio * ((float)q + 0.5f) - 0.5f;
+        const float fl = floorf(real);
+        const long long ix = (long long)fl;
+        const float t = fminf(fmaxf(real - fl, 0.f), 1.f);
+        const float x0 = t + 1.0f, x2 = 1.0f - t, x3 = 2.0f - t;
+        const float c0 = ((A * x0 - 5.0f * A) * x0 + 8.0f * A) * x0 - 4.0f * A;
+        const float c1 = ((A + 2.0f) * t - (A + 3.0f)) * t * t + 1.0f;
+        const float c2 = ((A + 2.0f) * x2 - (A + 3.0f)) * x2 * x2 + 1.0f;
+        const float c3 = ((A * x3 - 5.0f * A) * x3 + 8.0f * A) * x3 - 4.0f * A;
+        const long long hi = Tin - 1;
+        const long long i0 = min(max(ix - 1, 0LL), hi), i1 = min(max(ix, 0LL), hi), i2 = min(max(ix + 1, 0LL), hi), i3 = min(max(ix + 2, 0LL), hi);
+        float acc = row[i0] * c0;
+        acc += row[i1] * c1; acc += row[i2] * c2; acc += row[i3] * c3;
+        return acc;
+    }
     float src = ratio * ((float)q + 0.5f) - 0.5f;
     src = src < 0.f ? 0.f : src;
     const long long i0 = (long long)src;

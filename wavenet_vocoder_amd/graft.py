@@ -54,8 +54,10 @@ def infer_config_kwargs(m) -> dict:
         for layer in inner.up_layers:
             name = type(layer).__name__
             if name == "Stretch2d":
-                if getattr(layer, "mode", "nearest") not in ("nearest", "bilinear") or int(getattr(layer, "y_scale", 1)) != 1:
-                    raise NotImplementedError("nearest and bilinear stretching along time are implemented (upsample.py:20)")
+                from ._lib import UPSAMPLE_MODE
+                if getattr(layer, "mode", "nearest") not in UPSAMPLE_MODE or int(getattr(layer, "y_scale", 1)) != 1 \
+                        or float(layer.x_scale) != int(layer.x_scale):
+                    raise NotImplementedError("stretching along time by an integer factor is implemented (upsample.py:20)")
                 mode = getattr(layer, "mode", "nearest")
                 scales.append(int(layer.x_scale))
             elif hasattr(layer, "kernel_size"):

@@ -26,17 +26,18 @@ __all__ = ["Stretch2d", "UpsampleNetwork", "ConvInUpsampleNetwork"]
 
 class Stretch2d(nn.Module):
     """Stretch of a ``(B, 1, C, T)`` map, ``x_scale`` along time and ``y_scale`` along the channel axis (upsample.py:14-21:
-    ``F.interpolate(x, scale_factor=(y_scale, x_scale), mode=mode)``).  ``mode``: "nearest" (every reference preset) or "bilinear"."""
+    ``F.interpolate(x, scale_factor=(y_scale, x_scale), mode=mode)``).  ``mode``: any mode F.interpolate takes for a 4-D map -- "nearest" (every reference preset), "bilinear", "bicubic", "area",
+    "nearest-exact"."""
 
     def __init__(self, x_scale, y_scale, mode="nearest"):
         super().__init__()
-        if mode not in ("nearest", "bilinear"):
-            raise NotImplementedError(f"mode={mode!r}: 'nearest' (every reference preset) and 'bilinear' are implemented")
+        if mode not in ("nearest", "bilinear", "bicubic", "area", "nearest-exact"):
+            raise NotImplementedError(f"mode={mode!r}: F.interpolate's modes for a 4-D map are nearest, bilinear, bicubic, area, nearest-exact")
         self.x_scale, self.y_scale, self.mode = int(x_scale), int(y_scale), mode
 
     def forward(self, x):
-        if self.mode == "bilinear":
-            return F.interpolate(x, scale_factor=(self.y_scale, self.x_scale), mode="bilinear")
+        if self.mode != "nearest":
+            return F.interpolate(x, scale_factor=(self.y_scale, self.x_scale), mode=self.mode)
         if self.y_scale != 1:
             x = x.repeat_interleave(self.y_scale, dim=2)
         return x.repeat_interleave(self.x_scale, dim=3)
