@@ -3,16 +3,20 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/ring_trace.txt"
 os.makedirs(os.path.dirname(out), exist_ok=True)
-os.environ["WNV_RING_TRACE"] = out
+if not os.environ.get("TRACE_OFF"):
+    os.environ["WNV_RING_TRACE"] = out
 import torch
 from tests._configs import build, inputs
 B, T = int(os.environ.get("B", 8)), 4096
-m = build("cfg2_mol").to("cuda")
+CFG = os.environ.get("CFG", "cfg2_mol")
+m = build(CFG).to("cuda")
 eng = m._get_engine()
-c, _ = inputs("cfg2_mol", B, T)
+c, g = inputs(CFG, B, T)
 c_up = eng.upsample(c.cuda(), T_expected=T)
-eng.generate(B=B, T=T, c_up=c_up, seed=1, kernel=2)
+eng.generate(B=B, T=T, c_up=c_up, seed=1, kernel=2, **({"g_ids": g.cuda()} if g is not None else {}))
 torch.cuda.synchronize()
+if os.environ.get("TRACE_OFF"):
+    print("ran without the trace switch, last kernel", eng.last_kernel()); sys.exit(0)
 rows = [l.split() for l in open(out) if not l.startswith("#")]
 S = max(int(r[1]) for r in rows)
 steps = sorted({int(r[0]) for r in rows})

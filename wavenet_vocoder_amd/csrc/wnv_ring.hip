@@ -996,28 +996,68 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             // term alone and the head adds it to the sum through stage S - 2 (same order of additions): the accumulated sum travels
             // as a chain of its own, one hop + one poll per stage, and runs ~0.6 us behind the u's -- the last stage used to wait
             // for it with the whole ring idle.
+            auto skip_term = [&](int pp) -> float {                             // this stage's term of skip channels 128 pp + ch
+                float m0, m1;
+                if (last_stage && pp == (NK > NLDS ? NLDS : 0)) {
+                    m0 = dot16p(wo[0], xu); m1 = dot16p(wo[1], xu);
+                } else if (pp < NLDS) {
+                    m0 = dot16l(s.wsk + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(s.wsk + (size_t)(8 * pp + 4) * RT + tid, xu);
+                } else {                                                        // streams from the L2 (image layout: coalesced 16-B loads)
+                    // (the pass's base is wave-uniform: kept in SGPRs -- as eight per-lane 64-bit pointers it cost the K = 512
+                    //  instantiation 22 spilled registers and a scratch reload in front of every load)
+                    const unsigned long long sb = reinterpret_cast<unsigned long long>(wsk_g + (size_t)(8 * pp) * RT);
+                    const float4* ub = reinterpret_cast<const float4*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)) << 32) |
+                                                                       (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb));
+                    m0 = dot16l(ub + tid, xu); m1 = dot16l(ub + (size_t)4 * RT + tid, xu);
+                }
+                return quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + (pp == 0 ? bs_r : s.bsk[RC * pp + ch]);
+            };
             auto skip_phase = [&]() {
                 bool ok = true;
-#pragma unroll
-                for (int pp = 0; pp < NK; ++pp) {                               // skip channels 128 pp + ch
-                    float m0, m1;
-                    if (last_stage && pp == (NK > NLDS ? NLDS : 0)) {
-                        m0 = dot16p(wo[0], xu); m1 = dot16p(wo[1], xu);
-                    } else if (pp < NLDS) {
-                        m0 = dot16l(s.wsk + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(s.wsk + (size_t)(8 * pp + 4) * RT + tid, xu);
-                    } else {                                                    // streams from the L2 (image layout: coalesced 16-B loads)
-                        // (the pass's base is wave-uniform: kept in SGPRs -- as eight per-lane 64-bit pointers it cost the K = 512
-                        //  instantiation 22 spilled registers and a scratch reload in front of every load)
-                        const unsigned long long sb = reinterpret_cast<unsigned long long>(wsk_g + (size_t)(8 * pp) * RT);
-                        const float4* ub = reinterpret_cast<const float4*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)) << 32) |
-                                                                           (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb));
-                        m0 = dot16l(ub + tid, xu); m1 = dot16l(ub + (size_t)4 * RT + tid, xu);
+                if constexpr (NK <= 2) {                                        // term, poll, store per pass (K = 256 measured both ways:
+#pragma unroll                                                                  // 414 this way, 400 kSamples/s the other)
+                    for (int pp = 0; pp < NK; ++pp) {                           // skip channels 128 pp + ch
+                        float m0, m1;
+                        if (last_stage && pp == (NK > NLDS ? NLDS : 0)) {
+                            m0 = dot16p(wo[0], xu); m1 = dot16p(wo[1], xu);
+                        } else {
+                            m0 = dot16l(s.wsk + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(s.wsk + (size_t)(8 * pp + 4) * RT + tid, xu);
+                        }
+                        const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + (pp == 0 ? bs_r : s.bsk[RC * pp + ch]);
+                        float acc = 0.f;
+                        if (sidx > 0 && !last_stage && ok)
+                            ok = wave_recv<false>(sm_in + RC * pp, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
+                        if (writer && ok) st_granule(sm_out + RC * pp, tag, acc + mine, fast);
                     }
-                    const float mine = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + (pp == 0 ? bs_r : s.bsk[RC * pp + ch]);
-                    float acc = 0.f;
-                    if (sidx > 0 && !last_stage && ok)
-                        ok = wave_recv<false>(sm_in + RC * pp, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
-                    if (writer && ok) st_granule(sm_out + RC * pp, tag, acc + mine, fast);
+                } else {
+                    // K = 512: all four terms first (two of them stream from the L2), then ONE poll loop for the four granules of the sum so
+                    // far (first form: term, poll, store per pass -- three extra L2 round trips in every stage; the accumulated sum reached
+                    // the head 3.2 us after the last gate, profiles/r03_ring_k512_fine_timeline.txt)
+                    float mine[NK], acc[NK];
+#pragma unroll
+                    for (int pp = 0; pp < NK; ++pp) { mine[pp] = skip_term(pp); acc[pp] = 0.f; }
+                    if (sidx > 0 && !last_stage) {
+                        unsigned spins = 0;
+                        for (;;) {
+                            bool hit = true;
+                            if (writer) {
+                                u64 x[NK];
+#pragma unroll
+                                for (int pp = 0; pp < NK; ++pp) x[pp] = ld_granule(sm_in + RC * pp);
+#pragma unroll
+                                for (int pp = 0; pp < NK; ++pp) { acc[pp] = __uint_as_float((unsigned)x[pp]); hit = hit && (unsigned)(x[pp] >> 32) == tag; }
+                            }
+                            if (__all(hit)) break;
+                            if ((++spins & 255u) == 0u) {
+                                if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = false; break; }
+                                if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(p.status, 0u, 0x200u + (unsigned)sidx); ok = false; break; }
+                            }
+                        }
+                    }
+                    if (writer && ok) {
+#pragma unroll
+                        for (int pp = 0; pp < NK; ++pp) st_granule(sm_out + RC * pp, tag, acc[pp] + mine[pp], fast);
+                    }
                 }
                 if (!ok) s.flags[0] = 1;
             };
