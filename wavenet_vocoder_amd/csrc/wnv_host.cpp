@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <thread>
+#include <pthread.h>
+#include <sched.h>
 #include <cmath>
 #include <cmath>
 #include <cstdarg>
@@ -154,16 +156,53 @@ extern "C" wnv_status wnv_pinned_free(void* host_ptr) {
     if (host_ptr) HIP_TRY(hipHostFree(host_ptr));
     return WNV_OK;
 }
+// The CPUs that share the last-level cache with `cpu` and that this process may run on (sysfs; empty when it cannot be read).
+// The transform's workers are kept there: its input was written by the calling thread a moment ago and is REWRITTEN by it for the
+// next chunk -- on the two-socket, 16-CCD host of the GPU box, workers scheduled anywhere left the staging buffer's lines in remote
+// caches and torch's uniform_ then ran at 9.6 ns per draw instead of 2.3 (61 ns per cache line of ownership transfers).
+static cpu_set_t llc_neighbours(int cpu, int* count) {
+    cpu_set_t set, allowed;
+    CPU_ZERO(&set);
+    *count = 0;
+    if (cpu < 0 || sched_getaffinity(0, sizeof allowed, &allowed) != 0) return set;
+    char path[128];
+    snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+    FILE* f = fopen(path, "r");
+    if (!f) return set;
+    char buf[512];
+    const bool got = fgets(buf, sizeof buf, f) != nullptr;
+    fclose(f);
+    if (!got) return set;
+    for (char* q = buf; *q;) {                                                  // "0-7,128-135"
+        char* end;
+        const long a = strtol(q, &end, 10);
+        if (end == q) break;
+        long b = a;
+        q = end;
+        if (*q == '-') { b = strtol(q + 1, &end, 10); q = end; }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (c >= 0 && CPU_ISSET((int)c, &allowed) && !CPU_ISSET((int)c, &set)) { CPU_SET((int)c, &set); ++*count; }
+        while (*q == ',' || *q == ' ' || *q == '\n') ++q;
+    }
+    return set;
+}
 extern "C" wnv_status wnv_exponential_from_uniform(const double* u, float* out, int64_t n, int32_t threads) {
     if ((!u || !out) && n > 0) return fail(WNV_ERR_INVALID_ARG, "NULL buffer");
     if (n < 0) return fail(WNV_ERR_INVALID_ARG, "n < 0");
     // ATen, CPU: static_cast<float>(-1.0 / lambda * log1p(-u)) with lambda = 1.0, in double (TransformationHelper.h, exponential<double>)
     auto work = [u, out](int64_t a, int64_t b) { for (int64_t i = a; i < b; ++i) out[i] = static_cast<float>(-1.0 / 1.0 * std::log1p(-u[i])); };
-    const int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(threads, 64), n / 4096));
+    int nt = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(threads, 64), n / 4096));
     if (nt <= 1) { work(0, n); return WNV_OK; }
+    int near = 0;
+    const cpu_set_t llc = llc_neighbours(sched_getcpu(), &near);
+    if (near >= 2) nt = std::min(nt, near);
     std::vector<std::thread> pool;
     const int64_t per = (n + nt - 1) / nt;
-    for (int k = 0; k < nt; ++k) pool.emplace_back(work, std::min<int64_t>(n, k * per), std::min<int64_t>(n, (k + 1) * per));
+    for (int k = 1; k < nt; ++k) {
+        pool.emplace_back(work, std::min<int64_t>(n, k * per), std::min<int64_t>(n, (k + 1) * per));
+        if (near >= 2) (void)pthread_setaffinity_np(pool.back().native_handle(), sizeof llc, &llc);
+    }
+    work(0, std::min<int64_t>(n, per));                                          // the caller takes the first share
     for (auto& th : pool) th.join();
     return WNV_OK;
 }

@@ -753,7 +753,7 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                     }
                 }
                 __syncthreads();                                                 // s.part is free for the next four utterances
-                TAP_STAMP(3 + u0 / 4);
+                TAP_STAMP(min(3 + u0 / 4, 4));
             }
             // every payload of the pass has been issued: ONE drain (the write-through stores' acknowledgements take ~1 us), then
             // the tag granules of all utterances

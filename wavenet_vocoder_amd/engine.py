@@ -118,11 +118,26 @@ class PinnedBuffer:
             _lib.lib().wnv_pinned_free(C.c_void_p(self.host))
             self.host = self.dev = 0
 
+    # a copy (copy.deepcopy / pickle of a module that caches one) owns nothing: the memory belongs to the original
+    def __deepcopy__(self, memo):
+        other = object.__new__(PinnedBuffer)
+        other.host = other.dev = other.nbytes = 0
+        return other
+
+    def __reduce__(self):
+        return (_empty_pinned, ())
+
     def __del__(self):  # pragma: no cover
         try:
             self.free()
         except Exception:
             pass
+
+
+def _empty_pinned():
+    b = object.__new__(PinnedBuffer)
+    b.host = b.dev = b.nbytes = 0
+    return b
 
 
 def _stream(device: torch.device) -> int:
