@@ -260,3 +260,22 @@ def test_streamed_replay_tape_equals_the_tape_drawn_up_front():
     torch.manual_seed(78)
     other = m.incremental_forward(c=c, T=T)
     assert not torch.equal(other, got)
+    # the pinned tape buffers stay with the module between calls (pinning costs ~0.4 ms per MB): reused for a shorter call, regrown for
+    # a longer one, and a deep copy of the module owns none of them (no double free; it pins its own on its first call)
+    import copy
+    tape0 = m._pinned_tape["tape"]
+    torch.manual_seed(77)
+    assert m.incremental_forward(c=c[:2], T=T).shape == (2, 256, T)                       # B = 2: another tape layout, same buffer
+    assert m._pinned_tape["tape"] is tape0 and tape0.host
+    twin = copy.deepcopy(m)
+    assert not twin._pinned_tape["tape"].host
+    torch.manual_seed(77)
+    assert torch.equal(twin.incremental_forward(c=c, T=T), want)
+    assert twin._pinned_tape["tape"].host and twin._pinned_tape["tape"].host != tape0.host
+    c2, _ = inputs(name, B, 2 * T)
+    torch.manual_seed(77)
+    longer = m.incremental_forward(c=c2.cuda(), T=2 * T)
+    assert m._pinned_tape["tape"].nbytes >= 2 * T * B * 256 * 4 and longer.shape == (B, 256, 2 * T)
+    del twin
+    torch.manual_seed(77)
+    assert torch.equal(m.incremental_forward(c=c, T=T), want)

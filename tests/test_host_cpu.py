@@ -374,3 +374,24 @@ def test_fast_exponential_draws_are_torchs_own():
         assert _lib.lib().wnv_exponential_from_uniform(u.data_ptr(), out.data_ptr(), u.numel(), th) == 0
         assert torch.equal(out, want)
     assert _lib.lib().wnv_exponential_from_uniform(None, None, 0, 4) == 0
+
+
+def test_native_handles_do_not_travel_with_copies():
+    """copy.deepcopy / pickle of a module that has already run (train.py keeps an EMA copy of the model, synthesis code pickles
+    models): the native handle and the pinned tape buffers stay with the original -- a copy that shared them would free them twice --
+    and the copy builds its own on first use (the engine cache is keyed on the parameters' storage)."""
+    import copy
+    import pickle
+    from wavenet_vocoder_amd.engine import Engine, GluLayer, PinnedBuffer, QueueConv, _empty_pinned
+    for cls in (Engine, QueueConv, GluLayer):
+        obj = object.__new__(cls)
+        assert copy.deepcopy(obj) is None and pickle.loads(pickle.dumps(obj)) is None
+    buf = _empty_pinned()
+    for twin in (copy.deepcopy(buf), pickle.loads(pickle.dumps(buf))):
+        assert isinstance(twin, PinnedBuffer) and twin.host == 0 and twin.nbytes == 0
+    import wavenet_vocoder_amd as wnv
+    m = wnv.WaveNet(out_channels=30, layers=2, stacks=1, residual_channels=8, gate_channels=16, skip_out_channels=8, scalar_input=True)
+    m.__dict__["_pinned_tape"] = {"tape": _empty_pinned(), "ready": _empty_pinned()}
+    twin = copy.deepcopy(m)
+    assert twin._engine is None and twin._pinned_tape["tape"].host == 0
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), twin.state_dict().values()))

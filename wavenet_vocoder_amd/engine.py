@@ -164,6 +164,14 @@ def check_checkpoint(cfg: Config, state: Dict[str, torch.Tensor], batch: int = 8
 class Engine:
     """One ``wnv_handle``: packed weights + scratch for one model on one device."""
 
+    # a deep copy / pickle of a module that holds an engine gets none: the handle belongs to the original, the copy packs its own
+    # weights on its first call (EngineHost._get_engine keys the cache on the parameters' storage)
+    def __deepcopy__(self, memo):
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
     def __init__(self, cfg: Config, device: torch.device):
         self.cfg = cfg
         self.device = torch.device(device)
@@ -289,6 +297,12 @@ class Engine:
 class QueueConv:
     """conv.Conv1d.incremental_forward state machine on the device (reference conv.py:17-49)."""
 
+    def __deepcopy__(self, memo):          # (as Engine: the handle stays with the original, the copy builds its own on first use)
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
+
     def __init__(self, cin: int, cout: int, kernel_size: int, dilation: int, device: torch.device):
         self.device = torch.device(device)
         self._h = C.c_void_p()
@@ -322,6 +336,12 @@ class QueueConv:
 
 class GluLayer:
     """ResidualConv1dGLU.incremental_forward state machine on the device (reference modules.py:112-169)."""
+
+    def __deepcopy__(self, memo):          # (as Engine: the handle stays with the original, the copy builds its own on first use)
+        return None
+
+    def __reduce__(self):
+        return (type(None), ())
 
     def __init__(self, *, residual_channels, gate_channels, kernel_size, skip_out_channels, cin_channels,
                  gin_channels, dilation, bias, device):
