@@ -228,6 +228,12 @@ class EngineHost:
         #  module, grow-only, and are unpinned when it goes away: PinnedBuffer.__del__)
         cache = self.__dict__.setdefault("_pinned_tape", {})
         need = T * B * nz * 4
+        if cache.get("device") != eng.device:                   # (the module moved to another GPU: the mapping was made for the old one)
+            for key in ("tape", "ready"):
+                if cache.get(key) is not None:
+                    cache[key].free()
+                cache[key] = None
+            cache["device"] = eng.device
         if cache.get("tape") is None or not cache["tape"].host or cache["tape"].nbytes < need:
             if cache.get("tape") is not None:
                 cache["tape"].free()
