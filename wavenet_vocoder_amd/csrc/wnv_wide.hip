@@ -82,19 +82,39 @@ struct WideParams {
     u64 seed;
     float *out, *params_out;
     unsigned int* status;
-    unsigned long long* trace;                            // optional [trace_n][L + 1][8] wall-clock stamps of utterance 0, slice 0 (debug)
+    unsigned long long* trace;                            // optional [trace_n][L + 1][16] wall-clock stamps of utterance 0, slice 0 (debug)
     int trace_t0, trace_n, trace_b;
 };
 
 // (timeline stamps exist in -DWNV_FINE_TRACE builds only: the run-time test sat on the chain of every group)
+constexpr int WTW = 16;            // stamp slots per (step, group)
 __device__ __forceinline__ void wstamp(const WideParams& p, int b, int t, int pos, int k, int who) {
 #ifdef WNV_FINE_TRACE
     if (p.trace && b == p.trace_b && (int)threadIdx.x == who && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n)
-        p.trace[((size_t)(t - p.trace_t0) * (p.L + 1) + pos) * 8 + k] = wall_clock64();
+        p.trace[((size_t)(t - p.trace_t0) * (p.L + 1) + pos) * WTW + k] = wall_clock64();
 #else
     (void)p; (void)b; (void)t; (void)pos; (void)k; (void)who;
 #endif
 }
+
+// The stamps ON the chain are deferred (as in wnv_ring.hip): noted in registers where something happens -- one s_memrealtime, no store
+// -- and written once per step behind everything that is timed; the immediate wstamp() above stays for the off-chain phases.
+#ifdef WNV_FINE_TRACE
+#define WTS_DECL unsigned long long wts[WTW] = {0}
+#define WTS(k) (wts[k] = __builtin_amdgcn_s_memrealtime())
+__device__ __forceinline__ void wts_flush(const WideParams& p, int b, int t, int pos, const unsigned long long (&wts)[WTW], unsigned mask) {
+    if ((threadIdx.x & 63) != 0 || !p.trace || b != p.trace_b || t < p.trace_t0 || t >= p.trace_t0 + p.trace_n) return;
+    unsigned long long* row = p.trace + ((size_t)(t - p.trace_t0) * (p.L + 1) + pos) * WTW;
+#pragma unroll
+    for (int k = 0; k < WTW; ++k)
+        if ((mask >> k) & 1u) row[k] = wts[k];
+}
+#define WTS_FLUSH(b, t, pos, mask) wts_flush(p, b, t, pos, wts, mask)
+#else
+#define WTS_DECL
+#define WTS(k) ((void)0)
+#define WTS_FLUSH(b, t, pos, mask) ((void)0)
+#endif
 
 __device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v, bool fast) {
     const u64 x = ((u64)tag << 32) | (u64)__float_as_uint(v);
@@ -151,6 +171,19 @@ __device__ __forceinline__ bool recv_lanes(const u64* g, int n, unsigned tag, fl
         }
     }
 }
+// init + x[0] + x[1] + ... (that order), x[i] = base[i * stride] in LDS.  Written as a loop the compiler waits for every load (pair)
+// before it issues the next one -- five LDS round trips for eight values, ~0.18 us behind the barrier of EVERY group on the chain
+// (profiles/r03_wide_timeline.txt: "sum_partials") --, so the loads are issued together and pinned before the first add.
+__device__ __forceinline__ float lds_sum8(float init, const float* base, int stride) {
+    float x0 = base[0], x1 = base[stride], x2 = base[2 * stride], x3 = base[3 * stride];
+    float x4 = base[4 * stride], x5 = base[5 * stride], x6 = base[6 * stride], x7 = base[7 * stride];
+    asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+    return (((((((init + x0) + x1) + x2) + x3) + x4) + x5) + x6) + x7;
+}
+__device__ __forceinline__ float lds_sum16(float init, const float* base, int stride) {
+    return lds_sum8(lds_sum8(init, base, stride), base + 8 * stride, stride);
+}
+
 __device__ __forceinline__ float wide_gate(float a, float g) {                 // tanh(a) sigmoid(g), hardware exp2 / rcp (as wnv_ring.hip)
     const float e = __builtin_amdgcn_exp2f(fabsf(a) * -2.8853900817779268f);
     const float f = __builtin_amdgcn_exp2f(g * -1.4426950408889634f);
@@ -354,6 +387,7 @@ __device__ void compute_pre(const WideParams& p, const StageLds& s, int l, int j
 }
 
 __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next, float* smem) {
+    WTS_DECL;
     const StageLds s = carve_stage(smem, p.kpre);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool first = l == 0;
@@ -385,14 +419,16 @@ __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next
             //      publish -- +3 % at B = 16, -3 % at B <= 8: the two-load poll is slower than the one-load poll.)
             if (wave < 2) {
                 if (!first && !recv128(x_in + 128 * wave, tag, s.ux + 128 * wave, p.status, 0x200u + (unsigned)l, lane)) s.flags[0] = 1;
+                WTS(7);                                            // this wave's half of u has arrived
             } else if (wave < 6) {
                 if (!recv128(x_in + GHD + 128 * (wave - 2), tag, s.hx + 128 * (wave - 2), p.status, 0x100u + (unsigned)l, lane)) s.flags[0] = 1;
+                WTS(8);                                            // this wave's quarter of h has arrived
             } else if (!first && b >= 2 && rows > 0) {
                 const u64* prev = x_out - (size_t)2 * (p.L + 1) * XW + GHD + 256 * (wave - 6);
                 if (!recv256(prev, tag, hist0 + (size_t)(b - 2) * p.hist_b_floats + hrow + 256 * (wave - 6), p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
             }
             __syncthreads();                                       // (a timed-out gather is noticed at the end of the step: off the chain)
-            if (j == 0) wstamp(p, b, t, l, 0, 0);                  // inputs gathered
+            WTS(0);                                                // inputs gathered
             // ---- one pass: z_l, conv1x1_out of layer l-1, conv1x1_skip of layer l-1 -----------------------------------------------
             const float hp = s.hx[RS * j + lane];                  // (wave 1 needs it after the barrier, when hx may be refilled)
             {
@@ -409,35 +445,41 @@ __device__ void run_wide_stage(const WideParams& p, int l, int j, bool fast_next
                     if (p.NB > 1) s.ps2[ps_at] = dot_skip(ws2, uq);
                 }
                 s.pz[wave * 64 + lane] = reduce_quads(az);
+                WTS(10);                                           // this wave's partial sums issued to LDS
             }
             if (first && rows > 0) hist0[(size_t)b * p.hist_b_floats + hrow + tid] = s.hx[tid];        // group 0: the input is its history row
             __syncthreads();
-            if (j == 0) wstamp(p, b, t, l, 1, 0);                  // partial sums in LDS
+            WTS(1);                                                // partial sums in LDS
             if (wave == 0) {                                       // u_l: lanes c and 32 + c hold the tanh / sigmoid rows of channel 32 j + c
-                float v = s.pre[b * 64 + lane] + (lane < GS ? cv_a : cv_g);
-#pragma unroll
-                for (int w = 0; w < 8; ++w) v += s.pz[w * 64 + lane];
+                float v = lds_sum8(s.pre[b * 64 + lane] + (lane < GS ? cv_a : cv_g), s.pz + lane, 64);
+#ifdef WNV_FINE_TRACE
+                asm volatile("" : "+v"(v));
+#endif
+                WTS(12);                                           // pre-activation summed
                 const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
                 if (lane < GS) st_granule(x_out + GS * j + lane, tag, wide_gate(__uint_as_float(r[0]), __uint_as_float(r[1])), fast_next);   // modules.py:152-154
-                if (j == 0) wstamp(p, b, t, l, 2, 0);              // u published
+                WTS(2);                                            // u published
             } else if (wave == 1) {                                // h_l = layer l's input (group 0 passes h_0 on)
-                float o = bo_r;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) o += s.po[w * 64 + lane];
+                const float o = lds_sum8(bo_r, s.po + lane, 64);
                 const float hv = first ? hp : (o + hp) * 0.70710678118654752440f;                                        // modules.py:157-162
                 st_granule(x_out + GHD + RS * j + lane, tag, hv, fast_next);
+                WTS(11);                                           // h published
             } else if ((wave == 2 || (wave == 3 && p.NB > 1)) && !first) {       // skip sum over layers 0 .. l-1 (wavenet.py:312) -> group l + 1 / the tail; one wave per bank
                 const float* psb = wave == 2 ? s.ps : s.ps2;
                 const size_t bank = wave == 2 ? 0 : KWD;
                 float sk = bs_r, acc = 0.f;
                 bool ok = true;
-                if (lane < KS) {
-#pragma unroll
-                    for (int h = 0; h < 16; ++h) sk += psb[h * 32 + lane];
-                }
+                if (lane < KS) sk = lds_sum16(sk, psb + lane, 32);
                 if (l > 1) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 2) + l) * p.KW + bank + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)l, lane);
                 if (!ok) s.flags[0] = 1;
                 else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 2) + l + 1) * p.KW + bank + KS * j + lane, tag, acc + sk, fast_next);
+            }
+            // slots: 0 inputs gathered | 1 partial sums in LDS | 2 u published | 7 u arrived (wave 0's half) | 8 h arrived (wave 2's quarter) |
+            // 10 wave 0's partial sums issued | 11 h published | 12 pre-activation summed
+            if (j == 0) {
+                if (wave == 0) WTS_FLUSH(b, t, l, 0x1487u);
+                else if (wave == 1) WTS_FLUSH(b, t, l, 0x0800u);
+                else if (wave == 2) WTS_FLUSH(b, t, l, 0x0100u);
             }
         }
         // ---- behind the chain: the full h_l of the last two utterances -> history (waves 6, 7), then pre_j[t + 1] for every utterance
@@ -490,10 +532,7 @@ __device__ void run_wide_tail(const WideParams& p, int j, bool fast_next, float*
                 const size_t bank = (size_t)KWD * wave;
                 float sk = bs_r, acc = 0.f;
                 bool ok = true;
-                if (lane < KS) {
-#pragma unroll
-                    for (int h = 0; h < 16; ++h) sk += psb[h * 32 + lane];
-                }
+                if (lane < KS) sk = lds_sum16(sk, psb + lane, 32);
                 if (p.L > 1) ok = recv_lanes(p.smail + ((size_t)b * (p.L + 2) + p.L) * p.KW + bank + KS * j, KS, tag, acc, p.status, 0x300u + (unsigned)p.L, lane);
                 if (!ok) flags[0] = 1;
                 else if (lane < KS) st_granule(p.smail + ((size_t)b * (p.L + 2) + p.L + 1) * p.KW + bank + KS * j + lane, tag, acc + sk, fast_next);
@@ -571,9 +610,7 @@ __device__ void run_wide_head(const WideParams& p, bool fast_first, float* smem)
             }
             __syncthreads();
             if (wave == 0 && lane < p.O) {
-                float o = b2;
-#pragma unroll
-                for (int w = 0; w < 8; ++w) o += s.pout[w * 64 + lane];
+                const float o = lds_sum8(b2, s.pout + lane, 64);
                 s.obuf[lane] = o;                                                                    // wavenet.py:319
                 if (lane < nmix) vbuf[lane] = o + s.nz[lane];
                 if (p.params_out) p.params_out[((size_t)b * p.O + lane) * p.T + t] = o;
@@ -700,10 +737,7 @@ __device__ void run_wide_head512(const WideParams& p, int q, bool fast_first, bo
             __syncthreads();
             if (wave == 0) {
                 float o = 0.f;
-                if (lane < p.O) {
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) o += s.pout[w * 64 + lane];
-                }
+                if (lane < p.O) o = lds_sum8(o, s.pout + lane, 64);
                 if (q > 0) {
                     if (lane < p.O) st_granule(p.omail + ((size_t)b * 4 + q) * 64 + lane, tag, o, fast_parts);
                 } else {
@@ -889,9 +923,7 @@ __device__ void run_wide_head_b(const WideParams& p, bool fast_first, int part, 
             __syncthreads();
             if (part > 0) {                                        // the other K half: partial logits -> part 0
                 if (tid < O) {
-                    float o = 0.f;
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) o += s.pout[w * 256 + tid];
+                    const float o = lds_sum8(0.f, s.pout + tid, 256);
                     st_granule(p.omail + (size_t)b * 256 + tid, tag, o, p.fast != 0);
                 }
                 __syncthreads();
@@ -899,10 +931,7 @@ __device__ void run_wide_head_b(const WideParams& p, bool fast_first, int part, 
             }
             {
                 float o = b2, other = 0.f;
-                if (tid < O) {
-#pragma unroll
-                    for (int w = 0; w < 8; ++w) o += s.pout[w * 256 + tid];
-                }
+                if (tid < O) o = lds_sum8(o, s.pout + tid, 256);
                 if (nparts > 1 && wave < 4 && 64 * wave < O) {
                     if (!recv_lanes(p.omail + (size_t)b * 256 + 64 * wave, min(64, O - 64 * wave), tag, other, p.status, 0x490u, lane)) s.ints[0] = 1;
                     o += other;
@@ -1353,7 +1382,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     const int trace_n = 8;
     size_t trace_words = 0;
     if (trace_path && *trace_path && p.T > 64) {
-        trace_words = (size_t)trace_n * (L + 1) * 8;
+        trace_words = (size_t)trace_n * (L + 1) * WTW;
         WIDE_HIP(hipMalloc((void**)&d_trace, trace_words * sizeof(unsigned long long)));
         WIDE_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
@@ -1372,12 +1401,12 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
         if (FILE* f = fopen(trace_path, "w")) {
             fprintf(f, "# step group(L = head) stamps in ns (100 MHz wall clock) relative to the head's send before the first traced step: group: inputs gathered | "
                        "partials in LDS | u published | own h gathered | next pre ready;  head: skip gathered | next input sent\n");
-            const unsigned long long t00 = tr[((size_t)0 * (L + 1) + L) * 8 + 1];
+            const unsigned long long t00 = tr[((size_t)0 * (L + 1) + L) * WTW + 1];
             for (int tt = 0; tt < trace_n; ++tt)
                 for (int pos = 0; pos <= L; ++pos) {
                     fprintf(f, "%d %d", p.trace_t0 + tt, pos);
-                    for (int k = 0; k < 8; ++k) {
-                        const unsigned long long v = tr[((size_t)tt * (L + 1) + pos) * 8 + k];
+                    for (int k = 0; k < WTW; ++k) {
+                        const unsigned long long v = tr[((size_t)tt * (L + 1) + pos) * WTW + k];
                         fprintf(f, " %lld", v ? (long long)(v - t00) * 10 : -1LL);
                     }
                     fprintf(f, "\n");
