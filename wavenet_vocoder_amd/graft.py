@@ -211,6 +211,7 @@ class EngineHost:
 
 
     stream_replay_tape = True     # one-hot models: draw the replay tape while the ring kernel runs (False: draw it first, as for the other kernels)
+    stream_replay_tape_max_bytes = 1 << 30   # ... unless the tape would need more pinned host memory than this
 
     def _generate_streamed(self, eng, B, T, c_up, g_feat, g_ids, init, test_inputs, softmax):
         """``rng = "replay"`` for one-hot models at kernel speed: the tape of B x out_channels exponentials per step -- the numbers
@@ -234,12 +235,18 @@ class EngineHost:
                     cache[key].free()
                 cache[key] = None
             cache["device"] = eng.device
-        if cache.get("tape") is None or not cache["tape"].host or cache["tape"].nbytes < need:
-            if cache.get("tape") is not None:
-                cache["tape"].free()
-            cache["tape"] = PinnedBuffer(need)
-        if cache.get("ready") is None or not cache["ready"].host:
-            cache["ready"] = PinnedBuffer(64)
+        if need > self.stream_replay_tape_max_bytes:            # (ten seconds of mu-law audio at B = 8 are 2 GB of tape: not pinned)
+            return None
+        try:
+            if cache.get("tape") is None or not cache["tape"].host or cache["tape"].nbytes < need:
+                if cache.get("tape") is not None:
+                    cache["tape"].free()
+                    cache["tape"] = None
+                cache["tape"] = PinnedBuffer(need)
+            if cache.get("ready") is None or not cache["ready"].host:
+                cache["ready"] = PinnedBuffer(64)
+        except RuntimeError:                                    # the host refuses to pin that much: draw the tape up front instead
+            return None
         tape_buf, ready_buf = cache["tape"], cache["ready"]
         try:
             tape = tape_buf.view(torch.float32, (T, B, nz))
