@@ -60,11 +60,25 @@ __device__ __noinline__ void matvec_partial(const float* __restrict__ Wt, int K,
     }
 }
 
+// init + part[0][n] + part[1][n] + ... in that order.  The reads are issued eight at a time and pinned before the first add: written
+// as a plain loop, the compiler waits for every LDS read (pair) before it issues the next one (found in the group-ring kernel with
+// deferred stamps: five LDS round trips for eight values; profiles/r03_wide_timeline.txt).
 template <int NW>
 __device__ __forceinline__ float reduce_part(const float* part, int pstride, int n, float init) {
     float v = init;
+    if constexpr (NW % 8 == 0) {
 #pragma unroll
-    for (int w = 0; w < NW; ++w) v += part[w * pstride + n];
+        for (int w0 = 0; w0 < NW; w0 += 8) {
+            const float* b = part + (size_t)w0 * pstride + n;
+            float x0 = b[0], x1 = b[pstride], x2 = b[2 * pstride], x3 = b[3 * pstride];
+            float x4 = b[4 * pstride], x5 = b[5 * pstride], x6 = b[6 * pstride], x7 = b[7 * pstride];
+            asm volatile("" : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+            v = (((((((v + x0) + x1) + x2) + x3) + x4) + x5) + x6) + x7;
+        }
+    } else {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += part[w * pstride + n];
+    }
     return v;
 }
 
