@@ -274,8 +274,9 @@ __device__ __forceinline__ bool rpoll_recv2(const u64* g2, unsigned tag, float& 
         WNV_HIT16(x)
         rpoll16_issue<2>(g2);
         if ((++spins & 255u) == 0u) {
-            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+            // (giving up: the poll just issued is taken first -- nothing is ever in flight outside a helper, on any path)
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { (void)rpoll16_take<2, 0>(); return false; }
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); (void)rpoll16_take<2, 0>(); return false; }
         }
     }
 #undef WNV_HIT16
@@ -304,8 +305,12 @@ __device__ __forceinline__ bool rpoll_recv(const u64* g, bool active, unsigned t
     for (;;) {
         WNV_RPOLL8(0, 0, true)
         if ((++spins & 255u) == 0u) {
-            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
-            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+            const bool abort = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (abort || spins > SPIN_LIMIT) {
+                if (!abort && lane == 0) atomicCAS(status, 0u, code);
+                if (active) { unsigned val, tg; rpoll8_take<0, 0>(val, tg); }     // (the poll just issued is taken before giving up)
+                return false;
+            }
         }
     }
 #undef WNV_RPOLL8
@@ -622,31 +627,21 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
 #define TAP_STAMP(k) ((void)0)
 #endif
             TAP_STAMP(0);
-            // ---- h_l[t] of utterances b0 .. b0+nb-1, forwarded by their stages: wave w takes utterance b0 + w, two granules
-            //      per lane (one 16-B load), and files the row in the history ring ------------------------------------------
-            if (t >= 0 && wave < nb) {
-                const int b = b0 + wave;
-                const float* rec = p.fmail + ((size_t)b * p.L + l) * (4 + RC);
-                if (!bulk_wait(reinterpret_cast<const u64*>(rec), p.tag_base + (unsigned)t + 1u, p.status, 0x600u + (unsigned)l, lane))
-                    s.flags[0] = 1;
-                if (lane < RC / 4 && rows > 0) {
-                    const float4 v = bulk_load16(rec + 4 + 4 * lane);
-                    float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
-                    *reinterpret_cast<float4*>(hist + (size_t)(t % rows) * RC + 4 * lane) = v;
-                }
-            }
-            __syncthreads();
-            if (s.flags[0]) return;
-            TAP_STAMP(1);
-            // ---- gather: the kw-1 older taps of step tp (zeros before t = 0: the rings start zeroed) and c[tp].  Wave u fetches
-            //      utterance b0 + u: a tap is one contiguous 512-B history row, the conditioning row 4 cin bytes: 16-byte loads,
-            //      all of a lane's loads in flight before the first LDS store (two loads per lane for kw = 3, cin = 80) ---------
+            // ---- wave w takes utterance b0 + w.  FIRST the loads that do not depend on this step's h: the kw-1 older taps of step tp
+            //      (zeros before t = 0: the rings start zeroed) and c[tp] -- a tap is one contiguous 512-B history row, the conditioning
+            //      row 4 cin bytes: 16-byte loads, all of a lane's loads in flight together (two per lane for kw = 3, cin = 80).  THEN
+            //      h_l[t], forwarded by the utterance's stage (two granules per lane, one 16-B load), which is filed in the history
+            //      ring.  (Until the end of round 3 the gather came behind the filing and a barrier: its global-load latency, ~1.4 us of
+            //      an ~8-us pass, was paid after the wait for h instead of under it; the passes of the tap workgroups are what bounds
+            //      the throughput beyond 16 utterances.)  Only a layer with dilation 1 reads the row that is being filed -- tap kw-2 of
+            //      step t + 1 IS h[t] -- and takes it from the record instead. ------------------------------------------------------
             if (wave < nb) {
                 const int b = b0 + wave;
                 const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
                 const float* cb = p.c_up + ((size_t)b * p.T + tp) * p.cin;
                 float* xu = s.xin + (size_t)wave * kx;
                 const int ntap4 = hoff / 4, ncin4 = (p.cin & 3) == 0 ? p.cin / 4 : 0;
+                const int kfresh = (d == 1 && t >= 0 && rows > 0) ? p.kw - 2 : -1;   // the tap that is h[t] itself
                 constexpr int GQ = 2;                                            // float4s per lane in flight (kw = 3, cin = 80: 84 float4s per utterance)
                 for (int i0 = 0; i0 < ntap4 + ncin4; i0 += 64 * GQ) {
                     float4 v[GQ];
@@ -656,7 +651,7 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                         v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                         if (i < ntap4) {
                             const int k = i >> 5, r4 = i & 31;                   // RC / 4 = 32 float4s per row
-                            v[q] = *reinterpret_cast<const float4*>(hb + (size_t)((tp + k * d) % rows) * RC + 4 * r4);
+                            if (k != kfresh) v[q] = *reinterpret_cast<const float4*>(hb + (size_t)((tp + k * d) % rows) * RC + 4 * r4);
                         } else if (i < ntap4 + ncin4) {
                             v[q] = *reinterpret_cast<const float4*>(cb + 4 * (i - ntap4));
                         }
@@ -664,13 +659,26 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
 #pragma unroll
                     for (int q = 0; q < GQ; ++q) {
                         const int i = i0 + 64 * q + lane;
-                        if (i < ntap4 + ncin4) *reinterpret_cast<float4*>(xu + 4 * i) = v[q];
+                        if (i < ntap4 + ncin4 && (i >= ntap4 || (i >> 5) != kfresh)) *reinterpret_cast<float4*>(xu + 4 * i) = v[q];
                     }
                 }
                 if (ncin4 == 0)                                                  // cin not a multiple of 4: scalar conditioning row
                     for (int e = lane; e < p.cin; e += 64) xu[hoff + e] = cb[e];
+                TAP_STAMP(1);
+                if (t >= 0) {
+                    const float* rec = p.fmail + ((size_t)b * p.L + l) * (4 + RC);
+                    if (!bulk_wait(reinterpret_cast<const u64*>(rec), p.tag_base + (unsigned)t + 1u, p.status, 0x600u + (unsigned)l, lane))
+                        s.flags[0] = 1;
+                    if (lane < RC / 4 && rows > 0) {
+                        const float4 v = bulk_load16(rec + 4 + 4 * lane);
+                        float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
+                        *reinterpret_cast<float4*>(hist + (size_t)(t % rows) * RC + 4 * lane) = v;
+                        if (kfresh >= 0) *reinterpret_cast<float4*>(xu + kfresh * RC + 4 * lane) = v;
+                    }
+                }
             }
             __syncthreads();
+            if (s.flags[0]) return;
             TAP_STAMP(2);
             // ---- mat-vec for all utterances of the pass, four at a time (accumulators + weights must fit the register file):
             //      VGPR rows, then LDS rows, then whatever streams -----------------------------------------------------------
