@@ -82,7 +82,7 @@ struct RingParams {
     unsigned long long *zmail;                   // head_l0: Z[b][256] = N_1 h_0[t] (affine in the sample: made by the head), read by stage 1
     unsigned long long *gmail;                   // layer inputs handed on: G[b][2 (t parity)][S+1][128], slot j = h_{j-1}[t] as stage j formed it (read by stage j + 1)
     unsigned long long *omail;                   // head parts j > 0 -> part 0: partial head outputs O[b][NH][Op]
-    float *fmail, *pmail;                        // bulk records: stage -> tap workgroup h_l[t]: F[b][L][4 + 128]; tap workgroup -> stage pre_l[t+1]: P[b][L][4 + 256]
+    float *fmail, *pmail;                        // bulk records: stage -> tap workgroup h_l[t]: F[b][L][step parity][4 + 128]; tap workgroup -> stage pre_l[t+1]: P[b][L][step parity][4 + 256]
     int ring_blocks, tap_parts;                  // blocks [0, ring_blocks) = rings, then tap_parts tap workgroups per layer (part q serves passes q, q + parts, ...)
     int kper, kreg_rows, klds_rows;              // tap workgroup: K rows per wave; of those resident in VGPRs / in LDS (the rest streams)
     unsigned int* xcc;                 // [grid] XCC id + 1 of every workgroup (placement handshake)
@@ -562,6 +562,19 @@ __device__ __forceinline__ StageLds carve_stage(float* smem) {
 }
 __host__ __device__ constexpr size_t stage_lds_floats(int NK) { return (size_t)32 * ES + 2 * GC + 16 + 512 + (size_t)lds_passes(NK) * 8 * RT * 4; }
 
+// pre_l[step] of utterance b: one record per STEP PARITY.  A tap workgroup of a layer with dilation >= 2 publishes pre_l[t + 1] before it
+// waits for h_l[t] (nothing in it depends on that row), i.e. while a ring that runs late may still be reading pre_l[t]: the two live in
+// different slots, and pre_l[t + 2] -- the next writer of pre_l[t]'s slot -- is only made after h_l[t + 1] arrived, which that ring files
+// at the end of its step t + 1 (the data flow orders it, not the timing).
+// ... and h_l[step] the other way: a ring does not wait for such a layer's taps any more, so it may file h_l[t] before the tap workgroup has
+// read h_l[t-1]; h_l[t+1] -- the next writer of h_l[t-1]'s slot -- needs pre_l[t+1], which that workgroup makes only after it has.
+__device__ __forceinline__ size_t h_rec(const RingParams& p, int b, int l, int step) {
+    return (((size_t)b * p.L + l) * 2 + (size_t)(step & 1)) * (4 + RC);
+}
+__device__ __forceinline__ size_t pre_rec(const RingParams& p, int b, int l, int step) {
+    return (((size_t)b * p.L + l) * 2 + (size_t)(step & 1)) * (4 + GC);
+}
+
 // ---- tap workgroup (one per layer, shared by all rings) -----------------------------------------------------------------
 // Everything of a layer that is known a step ahead -- the dilated conv's older taps and the local-conditioning 1x1,
 //   pre_l[t+1] = b_l (+ W_g g) + c_l + sum_{k<kw-1} W_l[:, :, k] h_l[t+1 - (kw-1-k) d] + W_c,l c[t+1]        (conv.py:33-45)
@@ -627,6 +640,12 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
 #define TAP_STAMP(k) ((void)0)
 #endif
             TAP_STAMP(0);
+            // A layer with dilation >= 2 needs NOTHING of this step's h for pre[t + 1] (its taps are h[t+1-d], h[t+1-2d], ...): its pass
+            // does not wait for h[t] -- the row is waited for and filed by the NEXT pass (tf = t - 1), a whole step later --, so the rings
+            // never wait for this layer's taps (pre_rec: why the records come in two slots).  With d = 2 the youngest tap of step t + 1 is
+            // h[t-1], the row this pass files: taken from the record, as a dilation-1 layer takes h[t].
+            const bool early = d >= 2 && rows > 0;
+            const int tf = early ? t - 1 : t;                                   // the step whose h this pass waits for and files
             // ---- wave w takes utterance b0 + w.  FIRST the loads that do not depend on this step's h: the kw-1 older taps of step tp
             //      (zeros before t = 0: the rings start zeroed) and c[tp] -- a tap is one contiguous 512-B history row, the conditioning
             //      row 4 cin bytes: 16-byte loads, all of a lane's loads in flight together (two per lane for kw = 3, cin = 80).  THEN
@@ -641,7 +660,7 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                 const float* cb = p.c_up + ((size_t)b * p.T + tp) * p.cin;
                 float* xu = s.xin + (size_t)wave * kx;
                 const int ntap4 = hoff / 4, ncin4 = (p.cin & 3) == 0 ? p.cin / 4 : 0;
-                const int kfresh = (d == 1 && t >= 0 && rows > 0) ? p.kw - 2 : -1;   // the tap that is h[t] itself
+                const int kfresh = ((d == 1 || (d == 2 && early)) && tf >= 0 && rows > 0) ? p.kw - 2 : -1;   // the tap that is h[tf] itself
                 constexpr int GQ = 2;                                            // float4s per lane in flight (kw = 3, cin = 80: 84 float4s per utterance)
                 for (int i0 = 0; i0 < ntap4 + ncin4; i0 += 64 * GQ) {
                     float4 v[GQ];
@@ -665,14 +684,14 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                 if (ncin4 == 0)                                                  // cin not a multiple of 4: scalar conditioning row
                     for (int e = lane; e < p.cin; e += 64) xu[hoff + e] = cb[e];
                 TAP_STAMP(1);
-                if (t >= 0) {
-                    const float* rec = p.fmail + ((size_t)b * p.L + l) * (4 + RC);
-                    if (!bulk_wait(reinterpret_cast<const u64*>(rec), p.tag_base + (unsigned)t + 1u, p.status, 0x600u + (unsigned)l, lane))
+                if (tf >= 0) {
+                    const float* rec = p.fmail + h_rec(p, b, l, tf);
+                    if (!bulk_wait(reinterpret_cast<const u64*>(rec), p.tag_base + (unsigned)tf + 1u, p.status, 0x600u + (unsigned)l, lane))
                         s.flags[0] = 1;
                     if (lane < RC / 4 && rows > 0) {
                         const float4 v = bulk_load16(rec + 4 + 4 * lane);
                         float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
-                        *reinterpret_cast<float4*>(hist + (size_t)(t % rows) * RC + 4 * lane) = v;
+                        *reinterpret_cast<float4*>(hist + (size_t)(tf % rows) * RC + 4 * lane) = v;
                         if (kfresh >= 0) *reinterpret_cast<float4*>(xu + kfresh * RC + 4 * lane) = v;
                     }
                 }
@@ -742,7 +761,7 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                     const int u = tid >> 6 >> 1, n4 = tid & 127;                // 128 threads x 4 outputs per utterance
                     const bool live = u0 + u < nb && n4 < GC / 4;
                     const int b = b0 + u0 + u;
-                    float* rec = p.pmail + ((size_t)b * p.L + l) * (4 + GC);
+                    float* rec = p.pmail + pre_rec(p, b, l, tp);
                     if (live) {
                         // the bias rows are the MODEL's gate rows (tanh rows [0, G/2), sigmoid rows [G/2, G)); this kernel's 256 outputs
                         // are tanh channels 0..127 then sigmoid channels 0..127, zero beyond G/2 (models narrower than 128 / 256 are padded)
@@ -769,7 +788,7 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
             __syncthreads();
             TAP_STAMP(5);
             if (tid < nb)
-                st_granule(reinterpret_cast<u64*>(p.pmail + ((size_t)(b0 + tid) * p.L + l) * (4 + GC)), p.tag_base + (unsigned)tp + 1u, 0.f, false);
+                st_granule(reinterpret_cast<u64*>(p.pmail + pre_rec(p, b0 + tid, l, tp)), p.tag_base + (unsigned)tp + 1u, 0.f, false);
 #undef TAP_STAMP
         }
     }
@@ -918,7 +937,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 else return wave_recv2(g2, tag, v0, v1, p.status, code, lane, false, u4v{0, 0, 0, 0});
             };
             if (wave == 0) {
-                const float* rec = p.pmail + ((size_t)b * p.L + l) * (4 + GC);
+                const float* rec = p.pmail + pre_rec(p, b, l, t);
                 if (!bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
                 const float4 pv = bulk_load16(rec + 4 + 4 * lane);
                 *reinterpret_cast<float4*>(s.pre + 4 * lane) = pv;
@@ -1081,7 +1100,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 // layer inputs to their tap workgroups (history ring, older taps of the next step): bulk records.  This stage knows
                 // h_{l-1}[t] (its N input); the last stage also forms h_l[t] of its own layer, which nobody else needs
                 auto file = [&](int layer, const float* vec) {
-                    float* rec = p.fmail + ((size_t)b * p.L + layer) * (4 + RC);
+                    float* rec = p.fmail + h_rec(p, b, layer, t);
                     if (lane < RC / 4) {
                         const float* src = vec + ES * (lane >> 2) + 4 * (lane & 3);  // channels 4 lane .. 4 lane + 3
                         bulk_store16(rec + 4 + 4 * lane, *reinterpret_cast<const float4*>(src));
@@ -1226,7 +1245,7 @@ __device__ void run_stage_split(const RingParams& p, int ring, int sidx, int hal
                 return rpoll_recv2<false>(g2, tag, v0, v1, p.status, code, lane);
             };
             if (wave == 0) {
-                const float* rec = p.pmail + ((size_t)b * p.L + l) * (4 + GC);
+                const float* rec = p.pmail + pre_rec(p, b, l, t);
                 if (!bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
                 *reinterpret_cast<float4*>(s.pre + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
                 if constexpr (ZMSG) {                                           // lane L: rows 64 half + L (tanh) and 128 + 64 half + L (sigmoid)
@@ -1306,7 +1325,7 @@ __device__ void run_stage_split(const RingParams& p, int ring, int sidx, int hal
             if (s.flags[0]) return;
             if (wave == 0 && half == 0) {                                       // history of layer l - 1 (and of the last layer): half 0 files it
                 auto file = [&](int layer, const float* vec) {
-                    float* rec = p.fmail + ((size_t)b * p.L + layer) * (4 + RC);
+                    float* rec = p.fmail + h_rec(p, b, layer, t);
                     if (lane < RC / 4) {
                         const float* src = vec + ES * (lane >> 2) + 4 * (lane & 3);
                         bulk_store16(rec + 4 + 4 * lane, *reinterpret_cast<const float4*>(src));
@@ -1566,7 +1585,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
     // wave 2 fetches pre_0 of the step whose input is about to be made (tag tg) into LDS; a barrier follows at the call sites
     auto fetch_pre0 = [&](int b, unsigned tg) {
         if (l0 && wave == 2) {
-            const float* rec = p.pmail + ((size_t)b * p.L) * (4 + GC);
+            const float* rec = p.pmail + pre_rec(p, b, 0, (int)(tg - p.tag_base - 1u));
             if (!bulk_wait(reinterpret_cast<const u64*>(rec), tg, p.status, 0x700u, lane)) s.flags[0] = 1;
             *reinterpret_cast<float4*>(s.pre0 + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
         }
@@ -1580,7 +1599,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
         a.x0 = p.xmail + ((size_t)b * S1) * RC + tid;
         a.x1 = a.x0 + RC;
         a.z = p.zmail + (size_t)b * GC + tid;
-        a.f = p.fmail + ((size_t)b * p.L) * (4 + RC) + 4 + tid;
+        a.f = p.fmail + h_rec(p, b, 0, parn) + 4 + tid;                 // (parn IS the parity of the step the input is made for)
         // (split rings: two partial vectors per slot; layer 0's terms are whole and go to half 0, half 1 of the residual slot gets zeros)
         a.q = p.hmail + ((((size_t)b * 2 + parn) * S1 + 1) * (SPLIT ? 2 : 1)) * RC + ch;
         a.sk = p.smail + (((size_t)b * S1 + 1) * (SPLIT ? 2 : 1)) * p.Kp + ch;
@@ -1619,7 +1638,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             if (writer) st_granule(ad.sk, tg, m, fast);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the h_0 payload of waves 0-1 has left the CU ...
             __syncthreads();
-            if (tid == 0) st_granule(reinterpret_cast<u64*>(p.fmail + ((size_t)b * p.L) * (4 + RC)), tg, 0.f, false);   // ... publish the record
+            if (tid == 0) st_granule(reinterpret_cast<u64*>(p.fmail + h_rec(p, b, 0, (int)(tg - p.tag_base - 1u))), tg, 0.f, false);   // ... publish the record
         }
     };
 
@@ -2398,7 +2417,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     //        [hist B*hist_floats f32]
     const size_t head_bytes = 64 + 4096;                           // status word, placement table
     const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
-    const size_t n_f = (size_t)B * st->L * (4 + RC), n_p = (size_t)B * st->L * (4 + GC);   // stage <-> tap-workgroup bulk records (floats)
+    const size_t n_f = (size_t)B * st->L * 2 * (4 + RC), n_p = (size_t)B * st->L * 2 * (4 + GC);   // stage <-> tap-workgroup bulk records (floats)
     const size_t n_o = (size_t)B * NK * p.Op;                      // partial head outputs of parts 1 .. NK-1
     const size_t n_z = (size_t)B * GC;                             // N_1 h_0 from the head (head_l0)
     const size_t qh = split ? 2 : 1;                               // split rings: two partial vectors per residual / skip slot
