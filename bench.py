@@ -50,6 +50,27 @@ HBM_PEAK_GBS = 8000.0
 LDS_PEAK_GBS = 256 * 256 * 2.4  # CUs x B/clk/CU (ds_read_b64/b128) x GHz = 157286 GB/s
 
 
+def numa_local_cpus(want):
+    """Up to `want` CPUs of the NUMA node this thread runs on, nearest ids first (the block of 8 that holds the current CPU -- one
+    CCD / last-level cache on the GPU box's host -- then its neighbours).  None when sysfs or the affinity API is unavailable."""
+    try:
+        import ctypes
+        import glob
+        cur = ctypes.CDLL(None).sched_getcpu()
+        allowed = os.sched_getaffinity(0)
+        for path in glob.glob("/sys/devices/system/node/node*/cpulist"):
+            cpus = []
+            for part in open(path).read().strip().split(","):
+                a, _, b = part.partition("-")
+                cpus += list(range(int(a), int(b or a) + 1))
+            if cur in cpus:
+                cpus = sorted(set(cpus) & allowed, key=lambda x: (abs(x // 8 - cur // 8), x))
+                return cpus[:max(1, want)] if cpus else None
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0):
     """Time the oracle on the host (checker used as the measured CPU path -- the one place that is allowed).
     Bounded: each thread setting gets at most `budget_s` seconds of wall time (the per-step cost is constant
@@ -69,13 +90,33 @@ def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0):
     c_up = o.upsample(c_cpu).contiguous()                 # upsampled once; the timed loop is the sample loop
     saved = o.cfg.upsample_conditional_features
     o.cfg.upsample_conditional_features = False
+    # Every thread setting runs on CPUs of ONE NUMA node, nearest first (round 3 measured 4 threads SLOWER than 1 on the GPU box's
+    # two-socket, 256-CPU host: the intra-op workers were scheduled anywhere and the 600-KB layer weights bounced between sockets).
+    affinity0 = None
+    try:
+        affinity0 = os.sched_getaffinity(0)
+    except Exception:
+        pass
+    pinned = {}
     for threads in sorted({1, 4, min(ncores, 16)}):       # 4 = the reference's own setting (synthesis.py:37)
+        local = numa_local_cpus(threads) if affinity0 is not None else None
+        if local:
+            try:
+                os.sched_setaffinity(0, local)
+                pinned[threads] = len(local)
+            except Exception:
+                pass
         torch.set_num_threads(threads)
         with torch.no_grad():
             o.incremental_forward(c=c_up[:, :, :32], T=32, noise=tape)                     # warm-up
             o.incremental_forward(c=c_up, T=T_cpu, noise=tape, max_seconds=budget_s)
         results[threads] = B * o.last_steps / o.last_seconds / 1e3
         steps[threads] = o.last_steps
+        if affinity0 is not None:
+            try:
+                os.sched_setaffinity(0, affinity0)
+            except Exception:
+                pass
     o.cfg.upsample_conditional_features = saved
     best = max(results, key=results.get)
     # the oracle is a little FASTER than the reference it restates (no module dispatch, no tqdm); the ratio was measured where both
@@ -91,7 +132,7 @@ def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0):
     return {"value": round(results[best], 4), "unit": "kSamples/s", "cores": best, "kind": "port",
             "sample": f"oracle/wavenet_oracle.py (torch-CPU restatement of the reference op sequence incl. its per-step "
                       f"queue shift), same weights/mel, B={B}, up to T={T_cpu} steps or {budget_s:.0f} s per thread setting "
-                      f"(steps done: {steps}); host has {ncores} cores; the oracle runs {ratio} x the real reference's speed by thread "
+                      f"(steps done: {steps}); host has {ncores} cores, each thread setting pinned to CPUs of one NUMA node ({pinned}); the oracle runs {ratio} x the real reference's speed by thread "
                       f"count (profiles/r02_cpu_reference_vs_oracle.txt), so the reference itself would measure ~{est} kSamples/s here",
             "oracle_over_reference_speed": ratio, "reference_estimate_kSamples_s": est,
             "all_threads_kSamples_s": {str(k): round(v, 4) for k, v in results.items()}}
@@ -220,6 +261,80 @@ def rank_report(dist, dev, kernel_ms, last_kernel):
             "last_kernel_by_rank": [names.get(int(r[1]), "?") for r in rows]}
 
 
+def job_mode(args, model, kw, dev, dist, world, rank):
+    """N utterances of different lengths through the scheduler the evaluate front end uses (wavenet_vocoder_amd/sharding.py;
+    reference evaluate.py:51-92,204-215 + egs/mol/run.sh:31): longest-first assignment to the ranks, groups of neighbouring length
+    (group size from the measured throughput curve unless --job-group fixes it), every group run to its longest member, waveforms
+    trimmed.  One "step" = the whole job.  `value` counts TRUE samples (padding excluded); the padding loss is reported beside it.
+    Strong scaling: the job is the same whatever the number of ranks."""
+    from wavenet_vocoder_amd import sharding
+    hop, pad = 256, int(kw.get("cin_pad", 0))
+    gen = torch.Generator().manual_seed(2024)
+    frames = torch.randint(94, 751, (args.job,), generator=gen).tolist()                      # 1.0 .. 8.0 s at 24 kHz, hop 256
+    mels = [torch.randn(kw["cin_channels"], f, generator=gen) for f in frames]
+    lengths = [f * hop for f in frames]
+    model.rng = "philox"                                                                      # in-kernel noise, as the fixed-batch line
+    launches = []
+
+    def synth(c, idx):
+        T = (c.shape[-1] - 2 * pad) * hop
+        launches.append((len(idx), T))
+        y = model.incremental_forward(c=c.to(dev), T=T)
+        return y[:, 0]
+
+    group = args.job_group if args.job_group > 0 else None
+
+    def run():
+        st = {}
+        launches.clear()
+        wavs = sharding.synthesize_sharded(mels, synth, hop_size=hop, cin_pad=pad, group_size=group, stats=st, gather_to=0)
+        return wavs, st
+
+    for _ in range(max(args.warmup, 1)):                                                     # engine, scratch, mailboxes exist
+        run()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wavs, st = run()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mine = [st["true_samples"], st["padded_samples"], len(st["groups"])]
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        rows = [torch.zeros(3, dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(rows, torch.tensor(mine, dtype=torch.float64, device=dev))
+        per_rank = [[int(x) for x in r.tolist()] for r in rows]
+    else:
+        per_rank = [mine]
+    if rank == 0:
+        assert wavs is not None and len(wavs) == args.job and all(w.numel() == n for w, n in zip(wavs, lengths))
+        assert all(torch.isfinite(w).all() and float(w.std()) > 1e-3 for w in wavs), "dead or non-finite waveform in the job"
+        true_total, padded_total = sum(lengths), sum(r[1] for r in per_rank)
+        value = true_total * args.steps / elapsed / 1e3
+        line = {"metric": "audio kSamples/sec (24 kHz MoL egs/mol), whole job, TRUE samples of a variable-length job", "value": round(value, 3),
+                "unit": "kSamples/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+                "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic (seeded N(0,1) mels of seeded lengths 1-8 s, random-init weights, in-kernel Philox noise)",
+                "config": {"workload": f"{args.workload}: {describe(kw)}; JOB of {args.job} utterances, {min(frames)}-{max(frames)} frames "
+                                       f"({true_total / 24000.0:.1f} s of audio), scheduler = lpt_assign + pack_groups("
+                                       f"{'auto' if group is None else group})",
+                           "parallelism": f"utterance-sharded x{world}"},
+                "job": {"utterances": args.job, "true_samples": true_total, "padded_samples": padded_total,
+                        "padding_loss": round(1.0 - true_total / padded_total, 4),
+                        "kSamples_per_s_incl_padding": round(padded_total * args.steps / elapsed / 1e3, 1),
+                        "rank0_launches_B_x_T": launches, "per_rank_true_padded_groups": per_rank,
+                        "load_imbalance": round(max(r[1] for r in per_rank) / (padded_total / world), 4),
+                        "x_real_time_24k_whole_job": round(true_total / 24000.0 / (elapsed / args.steps), 2)}}
+        print(json.dumps(line), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,6 +347,10 @@ def main():
     ap.add_argument("--workload", default=WORKLOAD)
     ap.add_argument("--dry-run", action="store_true",
                     help="launch / rendezvous / reduce / print plumbing only, on CPU with gloo (no engine, no GPU)")
+    ap.add_argument("--job", type=int, default=0,
+                    help="JOB MODE: synthesise N utterances of seeded lengths 1-8 s through the scheduler (sharding.lpt_assign + "
+                         "pack_groups) instead of one fixed batch; reports true kSamples/s and the padding loss")
+    ap.add_argument("--job-group", type=int, default=0, help="job mode: utterances per launch (0 = sharding.auto_group_size)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (no throughput_mode, no cpu_baseline): what the rocprofv3 summaries are taken with")
     args = ap.parse_args()
@@ -264,6 +383,12 @@ def main():
     c_dev = c.to(dev)
     g_dev = None if gids is None else gids[:, 0].to(dev)
 
+    if args.job > 0:
+        rc = job_mode(args, model, kw, dev, dist, world, rank)
+        if dist is not None:
+            dist.destroy_process_group()
+        return rc
+
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * (args.steps + args.warmup))]
     kern_ms = []
 
@@ -290,6 +415,7 @@ def main():
     for i in range(args.warmup, args.warmup + args.steps):
         kern_ms.append(ev[2 * i].elapsed_time(ev[2 * i + 1]))
     assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0 + 1e-6
+    assert float(out.float().std()) > 1e-3, "the timed kernel wrote a constant waveform: a dead kernel must not post a number"
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -314,6 +440,17 @@ def main():
             except Exception:
                 traffic, traffic_src = None, None
         us_step = kdur / T * 1e6
+        # the MEASURED LDS read peak of this box next to the nominal one (csrc/wnv_ubench.hip, ~5 ms)
+        peak_meas, peak_cus = None, None
+        try:
+            import ctypes
+            from wavenet_vocoder_amd import _lib
+            gbs, ncu = ctypes.c_double(0.0), ctypes.c_int32(0)
+            _lib.check(_lib.lib().wnv_measure_lds_read_peak(local_rank, ctypes.byref(gbs), ctypes.byref(ncu)))
+            peak_meas, peak_cus = round(gbs.value, 1), int(ncu.value)
+        except Exception as e:
+            peak_meas = None
+            print(f"[bench] LDS peak microbenchmark failed: {e}", file=sys.stderr)
         nparts = max(kw["skip_out_channels"] // 128, 1)
         floor, floor_hop2 = latency_floor_us(kw, nparts), latency_floor_us(kw, nparts, hop=0.444)
         line = {
@@ -330,6 +467,9 @@ def main():
             "rtf_24k": round(per_utt / 24000.0, 4), "rtf_22k05": round(per_utt / 22050.0, 4),
             "roofline": {"bound": "lds", "peak_name": "LDS read bandwidth, 256 CU x 256 B/clk x 2.4 GHz (BASELINE.json / SURVEY.md 8d: weights resident on chip)",
                          "achieved": round(ach, 2), "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": round(ach / LDS_PEAK_GBS, 6),
+                         "peak_measured": peak_meas, "frac_of_peak_measured": None if not peak_meas else round(ach / peak_meas, 6),
+                         "peak_measured_how": f"wnv_measure_lds_read_peak on this box: {peak_cus} CUs x 16 waves of conflict-free ds_read_b128 "
+                                              "(csrc/wnv_ubench.hip), bytes read / HIP-event time, best of 5 launches",
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel_ms": round(kdur * 1e3, 3), "algorithmic_bytes_per_launch": alg_bytes},
             "roofline_hbm": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -192,6 +192,9 @@ wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* args);
 wnv_status wnv_wait(wnv_handle h);
 /* Which kernel served the last wnv_generate of this handle: 1 generic, 2 ring, 3 group ring (wide models), 0 none yet. */
 int32_t wnv_last_kernel(wnv_handle h);
+/* Test hook: the next n persistent (ring) launches this handle would make in auto mode (kernel = 0) report WNV_ERR_TIMEOUT
+ * without being launched -- drives the retry policy described at wnv_reset without a device that loses its CUs.  n = 0 clears. */
+wnv_status wnv_debug_inject_timeouts(wnv_handle h, int32_t n);
 
 /* WaveNet.clear_buffer (wavenet.py:345-353): the engine re-zeroes its history at the start of every
  * wnv_generate (as incremental_forward does at :241), so this only releases scratch. */
@@ -307,7 +310,8 @@ wnv_status wnv_logmel(wnv_mel_handle h, const wnv_logmel_args* args);
  * The reference draws its sampling noise from torch's CPU generator inside the loop (wavenet.py:334-335: OneHotCategorical ->
  * torch.multinomial's exponential race, B x 256 values per step); a replay of that stream is 49 M values for the benchmark batch
  * of a mu-law model -- longer to draw than the kernel takes to run.  These helpers let the host draw it WHILE the kernel runs. */
-/* Coherent, device-mapped host memory (hipHostMalloc, coherent + mapped): *host_ptr for the CPU, *device_ptr for wnv_generate_args. */
+/* Coherent, device-mapped host memory (hipHostMalloc, coherent + mapped + portable: valid on every device of the process, whichever
+ * is current on the calling thread): *host_ptr for the CPU, *device_ptr for wnv_generate_args. */
 wnv_status wnv_pinned_alloc(size_t bytes, void** host_ptr, void** device_ptr);
 wnv_status wnv_pinned_free(void* host_ptr);
 /* out[i] = (float)(-log1p(-u[i])), u in [0, 1) double: the transform ATen's CPU exponential_ applies to its uniform draw
@@ -323,6 +327,10 @@ int32_t wnv_abi_version(void);
  * group (weights once + ring taps + conditioning row + output) and MACs per sample. */
 int64_t wnv_bytes_per_step(wnv_handle h, int32_t B);
 int64_t wnv_macs_per_sample(wnv_handle h);
+/* The MEASURED on-chip peak the sample loop's roofline is priced against: LDS read bandwidth of the whole device in
+ * GB/s from a microbenchmark launch (every CU: 16 waves of conflict-free ds_read_b128; csrc/wnv_ubench.hip), ~5 ms.  *n_cu (optional)
+ * receives the CU count the figure covers.  Synchronous; needs a GPU. */
+wnv_status wnv_measure_lds_read_peak(int32_t device, double* gb_per_s, int32_t* n_cu);
 
 #ifdef __cplusplus
 }

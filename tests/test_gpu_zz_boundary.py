@@ -95,11 +95,11 @@ def test_cu_mask_clean_timeout_then_fallback():
         assert res["forced"] == "ran" and res["forced_vs_generic"] < 1e-3, res
 
 
-def test_fast_path_comes_back_after_a_transient_timeout(monkeypatch):
+def test_fast_path_comes_back_after_a_transient_timeout():
     """A handle whose ring launch timed out ONCE must not stay on the generic kernel for the rest of its life.
     Policy (wnv_host.cpp, persist_cooldown): the call that timed out and the next 2 are served by the generic kernel, then the
     persistent kernel is tried again (4, 8, ... 32 calls of pause after consecutive time-outs); wnv_reset() makes the next call try
-    at once.  The time-out itself is injected (WNV_INJECT_TIMEOUT: a real one needs CUs that stay away for as long as the bounded
+    at once.  The time-out itself is injected (wnv_debug_inject_timeouts: a real one needs CUs that stay away for as long as the bounded
     spins last -- the CU-mask tests above; a second process or stream merely time-slices / queues: scripts/hog_probe.py)."""
     name, B, T = "cfg2_mol", 8, 256
     m = build(name).to("cuda")
@@ -114,24 +114,21 @@ def test_fast_path_comes_back_after_a_transient_timeout(monkeypatch):
         return eng.last_kernel(), out
 
     assert auto()[0] == 2
-    monkeypatch.setenv("WNV_INJECT_TIMEOUT", "1")
+    eng.inject_timeouts(1)
     k, out = auto()
     assert k == 1 and torch.equal(out, ref)                                          # served by the generic kernel
-    monkeypatch.delenv("WNV_INJECT_TIMEOUT")
     ks = [auto()[0] for _ in range(3)]
     assert ks == [1, 1, 2], ks                                                       # two calls of pause, then the ring is back ...
     assert torch.equal(auto()[1], want)                                              # ... with the ring's samples
     # consecutive time-outs double the pause; a launch that completes clears it
-    monkeypatch.setenv("WNV_INJECT_TIMEOUT", "1")
+    eng.inject_timeouts(2)
     assert auto()[0] == 1                                                            # time-out: pause 2
     assert [auto()[0] for _ in range(2)] == [1, 1]                                   # (paused: no launch, no injection)
     assert auto()[0] == 1                                                            # tried again, timed out again: pause 4
-    monkeypatch.delenv("WNV_INJECT_TIMEOUT")
     assert [auto()[0] for _ in range(5)] == [1, 1, 1, 1, 2]
     # wnv_reset: the next call tries at once
-    monkeypatch.setenv("WNV_INJECT_TIMEOUT", "1")
+    eng.inject_timeouts(1)
     assert auto()[0] == 1
-    monkeypatch.delenv("WNV_INJECT_TIMEOUT")
     eng.reset_buffers()
     assert auto()[0] == 2
 

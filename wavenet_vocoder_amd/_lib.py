@@ -126,6 +126,8 @@ _PROTOS = {
     "wnv_reset": (C.c_int, [C.c_void_p]),
     "wnv_wait": (C.c_int, [C.c_void_p]),
     "wnv_last_kernel": (C.c_int32, [C.c_void_p]),
+    "wnv_debug_inject_timeouts": (C.c_int, [C.c_void_p, C.c_int32]),
+    "wnv_measure_lds_read_peak": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     "wnv_qconv_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "wnv_qconv_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "wnv_qconv_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),

@@ -13,7 +13,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libwnv_hip.so")
-SOURCES = ["wnv_host.cpp", "wnv_layers.cpp", "wnv_generic.hip", "wnv_upsample.hip", "wnv_ring.hip", "wnv_wide.hip", "wnv_post.hip", "wnv_forward.hip", "wnv_mel.hip"]
+SOURCES = ["wnv_host.cpp", "wnv_layers.cpp", "wnv_generic.hip", "wnv_upsample.hip", "wnv_ring.hip", "wnv_wide.hip", "wnv_post.hip", "wnv_forward.hip", "wnv_mel.hip", "wnv_ubench.hip"]
 ARCH = "gfx950"
 
 

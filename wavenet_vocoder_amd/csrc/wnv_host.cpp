@@ -53,6 +53,7 @@ struct wnv_engine {
     // the next `cooldown` calls are served by the generic kernel, then the persistent kernel is tried again; every further time-out
     // doubles the pause (2, 4, ... 32 calls), a launch that completes clears it, wnv_reset() makes the next call try at once
     int persist_cooldown = 0, persist_backoff = 0;
+    int inject_timeouts = 0;              // wnv_debug_inject_timeouts: auto-mode ring launches still to be reported as timed out (tests)
     int last_kernel = 0;                  // 1 generic, 2 ring: what served the last wnv_generate
 };
 
@@ -145,7 +146,9 @@ extern "C" int32_t wnv_abi_version(void) { return WNV_ABI_VERSION; }
 extern "C" wnv_status wnv_pinned_alloc(size_t bytes, void** host_ptr, void** device_ptr) {
     if (!host_ptr || !device_ptr || bytes == 0) return fail(WNV_ERR_INVALID_ARG, "bad arguments to wnv_pinned_alloc");
     void* hp = nullptr;
-    HIP_TRY(hipHostMalloc(&hp, bytes, hipHostMallocCoherent | hipHostMallocMapped));
+    // portable: pinned for and mapped into EVERY device's address space, whichever device is current on the calling thread -- a
+    // handle on another GPU than the thread's current one reads the same address (one unified virtual address space on ROCm)
+    HIP_TRY(hipHostMalloc(&hp, bytes, hipHostMallocCoherent | hipHostMallocMapped | hipHostMallocPortable));
     void* dp = nullptr;
     hipError_t e = hipHostGetDevicePointer(&dp, hp, 0);
     if (e != hipSuccess) { (void)hipHostFree(hp); return fail(WNV_ERR_HIP, "hipHostGetDevicePointer: %s", hipGetErrorString(e)); }
@@ -285,6 +288,11 @@ extern "C" wnv_status wnv_wait(wnv_handle h) {
 }
 
 extern "C" int32_t wnv_last_kernel(wnv_handle h) { return h ? h->last_kernel : 0; }
+extern "C" wnv_status wnv_debug_inject_timeouts(wnv_handle h, int32_t n) {
+    if (!h || n < 0) return fail(WNV_ERR_INVALID_ARG, "bad arguments to wnv_debug_inject_timeouts");
+    h->inject_timeouts = n;
+    return WNV_OK;
+}
 
 extern "C" wnv_status wnv_reset(wnv_handle h) {
     if (!h) return fail(WNV_ERR_INVALID_ARG, "handle is NULL");
@@ -667,9 +675,10 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         HIP_TRY(zero_onehot_out());
         std::string err;
         wnv_status st;
-        if (a->kernel == 0 && std::getenv("WNV_INJECT_TIMEOUT")) {   // diagnostic knob: exercises the time-out policy below without
-            st = WNV_ERR_TIMEOUT;                                     // a device that cannot keep the launch resident
-            err = "injected by WNV_INJECT_TIMEOUT";                   // (tests/test_gpu_zz_boundary.py; the real thing: the CU-mask tests)
+        if (a->kernel == 0 && h->inject_timeouts > 0) {              // test hook (wnv_debug_inject_timeouts): exercises the time-out policy
+            --h->inject_timeouts;                                     // below without a device that cannot keep the launch resident
+            st = WNV_ERR_TIMEOUT;                                     // (tests/test_gpu_zz_boundary.py; the real thing: the CU-mask tests)
+            err = "injected by wnv_debug_inject_timeouts";
         } else {
             TurnGuard turn(h->device, s);
             st = wnv_ring_generate(&h->ring_state, h->device, c, h->store, ga, s, err);

@@ -84,6 +84,7 @@ struct RingParams {
     unsigned long long *omail;                   // head parts j > 0 -> part 0: partial head outputs O[b][NH][Op]
     float *fmail, *pmail;                        // bulk records: stage -> tap workgroup h_l[t]: F[b][L][step parity][4 + 128]; tap workgroup -> stage pre_l[t+1]: P[b][L][step parity][4 + 256]
     int ring_blocks, tap_parts;                  // blocks [0, ring_blocks) = rings, then tap_parts tap workgroups per layer (part q serves passes q, q + parts, ...)
+    int tb;                                      // utterances per tap pass (<= TB)
     int kper, kreg_rows, klds_rows;              // tap workgroup: K rows per wave; of those resident in VGPRs / in LDS (the rest streams)
     unsigned int* xcc;                 // [grid] XCC id + 1 of every workgroup (placement handshake)
     float* hist;
@@ -602,7 +603,14 @@ __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
     return (size_t)TB * RW * kper + (size_t)4 * RW * GC + 16 + (size_t)RW * klds_rows * 64 * 4;
 }
 
+// EXPERIMENT BUILDS ONLY (-DWNV_EXP_NOPRE=1|2; results are WRONG on purpose, timing only): 1 = stages and head do not wait for the tap
+// workgroups' records (what would a zero-latency tap path buy?), 2 = the tap workgroups also exit at once (... and what do they cost
+// the chain's hops by sharing the fabric?).  profiles/r04_tap_bound_experiment.txt.
+#ifndef WNV_EXP_NOPRE
+#define WNV_EXP_NOPRE 0
+#endif
 __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
+    if (WNV_EXP_NOPRE >= 2) return;
     const TapLds s = carve_tap(smem, p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = p.lay_dil[l];
@@ -631,8 +639,8 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
 
     for (int t = -1; t + 1 < p.T; ++t) {                           // consumes h_l[t] (t >= 0), produces pre_l[t + 1]
         const int tp = t + 1;
-        for (int b0 = part * TB; b0 < p.B; b0 += p.tap_parts * TB) {
-            const int nb = min(TB, p.B - b0);
+        for (int b0 = part * p.tb; b0 < p.B; b0 += p.tap_parts * p.tb) {
+            const int nb = min(p.tb, p.B - b0);
 #ifdef WNV_FINE_TRACE
 #define TAP_STAMP(k) do { if (p.trace_tap && l == 0 && part == 0 && b0 == 0 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
                               p.trace_tap[(size_t)(t - p.trace_t0) * TRW + (k)] = wall_clock64(); } while (0)
@@ -938,7 +946,7 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             };
             if (wave == 0) {
                 const float* rec = p.pmail + pre_rec(p, b, l, t);
-                if (!bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                if (!WNV_EXP_NOPRE && !bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
                 const float4 pv = bulk_load16(rec + 4 + 4 * lane);
                 *reinterpret_cast<float4*>(s.pre + 4 * lane) = pv;
                 if constexpr (zmsg) {                                           // rows 4 lane .. 4 lane + 3 of N_1 h_0, plus pre_1: zin is complete;
@@ -1381,17 +1389,25 @@ __device__ __forceinline__ HeadLds carve_head(float* smem, int NK) {
 __host__ __device__ constexpr size_t head_lds_floats(int NK) { return (size_t)GC + 8 * ES + (size_t)(4 * NK + 4) * QS + 256 + 48 + 16; }
 
 // noise value `idx` of (t, b): from the tape (rng = "replay") or the in-kernel Philox stream
+// (a STREAMED tape is host memory the CPU is still writing: its values are read with system-scope loads that bypass the vector L1 and
+//  the L2 -- a line fetched for the last published step also holds the start of the next, unpublished one -- behind wait_noise's
+//  acquire; a tape in device memory is complete before the launch and is read with plain loads)
 __device__ __forceinline__ float head_noise(const RingParams& p, int t, int b, int idx, int kind) {
-    return p.noise ? p.noise[((size_t)t * p.noise_B + p.b0 + b) * p.nz + idx] : wnv_noise_gen(p.seed, t, p.b0 + b, idx, kind);
+    if (!p.noise) return wnv_noise_gen(p.seed, t, p.b0 + b, idx, kind);
+    const float* src = p.noise + ((size_t)t * p.noise_B + p.b0 + b) * p.nz + idx;
+    if (p.noise_ready) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    return *src;
 }
 // STREAMED TAPE: the host is still drawing the tape while the kernel runs (coherent host memory; wnv_generate_args.noise_ready).
 // Every wave that is about to read step t waits until the counter has passed it -- one PCIe read per tape chunk, the value seen is
-// kept in `seen`.  Bounded like every wait (the host draws ~1e5 steps per second: the budget is seconds).  Returns false on abort.
+// kept in `seen`.  Bounded like every wait (the host draws ~1e5 steps per second: the budget is seconds).  Returns false on abort
+// -- the caller must not read the step then.  The counter is loaded with ACQUIRE semantics at system scope: the tape reads that
+// follow are ordered behind it and cannot be served from a line cached before the host published the step.
 __device__ __forceinline__ bool wait_noise(const RingParams& p, int t, unsigned& seen) {
     if (!p.noise_ready || (unsigned)t < seen) return true;
     unsigned spins = 0;
     for (;;) {
-        seen = __hip_atomic_load(p.noise_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        seen = __hip_atomic_load(p.noise_ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
         if ((unsigned)t < seen) return true;
         if ((++spins & 63u) == 0u) {
             if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
@@ -1586,7 +1602,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
     auto fetch_pre0 = [&](int b, unsigned tg) {
         if (l0 && wave == 2) {
             const float* rec = p.pmail + pre_rec(p, b, 0, (int)(tg - p.tag_base - 1u));
-            if (!bulk_wait(reinterpret_cast<const u64*>(rec), tg, p.status, 0x700u, lane)) s.flags[0] = 1;
+            if (!WNV_EXP_NOPRE && !bulk_wait(reinterpret_cast<const u64*>(rec), tg, p.status, 0x700u, lane)) s.flags[0] = 1;
             *reinterpret_cast<float4*>(s.pre0 + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
         }
     };
@@ -1659,11 +1675,12 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             const int b = ring + j * p.n_rings;
             if (b >= p.B) continue;
             // ---- everything that does not depend on the network, while the ring works ---------------------------
-            if (!wait_noise(p, t, noise_seen)) s.flags[0] = 1;
+            const bool nz_ok = wait_noise(p, t, noise_seen);                        // (false: draining -- the step's noise is not read)
+            if (!nz_ok) s.flags[0] = 1;
             float gum = 0.f, lr = 0.f, forced = 0.f;
-            if (i < nmix) gum = -logf(-logf(head_noise(p, t, b, i, 0)));          // Gumbel noise (mixture.py:138-140)
+            if (i < nmix && nz_ok) gum = -logf(-logf(head_noise(p, t, b, i, 0)));   // Gumbel noise (mixture.py:138-140)
             if (wave < 2) {
-                const float r = head_noise(p, t, b, nmix, p.dist == 2 ? 1 : 0);
+                const float r = nz_ok ? head_noise(p, t, b, nmix, p.dist == 2 ? 1 : 0) : 0.5f;
                 lr = p.dist == 1 ? logf(r) - logf(1.0f - r) : r;                     // mixture.py:151-152 / :265-267
                 if (t + 1 < p.Tt) forced = p.teacher[(size_t)b * p.Tt + t + 1];
             }
@@ -1815,8 +1832,9 @@ __device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
             const int b = ring + j * p.n_rings;
             if (b >= p.B) continue;
             // noise of this step, while the ring works: e ~ Exp(1) per class
-            if (!wait_noise(p, t, noise_seen)) s.ints[0] = 1;
-            if (tid < O) s.nzb[tid] = head_noise(p, t, b, tid, 2);
+            const bool nz_ok = wait_noise(p, t, noise_seen);                        // (false: draining -- the step's noise is not read)
+            if (!nz_ok) s.ints[0] = 1;
+            if (tid < O) s.nzb[tid] = nz_ok ? head_noise(p, t, b, tid, 2) : 1.0f;
             if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.ints[0] = 1;
             __syncthreads();
             WNV_TS(1);
@@ -2366,6 +2384,12 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         return 0;
     };
     int tap_parts = B > TB ? 2 : 1;
+    int tb = TB;                                                   // utterances per tap pass
+    // WNV_RING_TAP=<parts>,<utterances per pass>: measurement knob (profiles/r04_tap_parts.txt)
+    if (const char* e = getenv("WNV_RING_TAP")) {
+        int a = 0, b = 0;
+        if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= 4 && b >= 1 && b <= TB) { tap_parts = a; tb = b; }
+    }
     int n_rings = rings_that_fit(tap_parts);
     if (tap_parts == 2 && n_rings < std::min(B, 8) && rings_that_fit(1) > n_rings) {   // rather more rings than the second tap part
         tap_parts = 1;
@@ -2474,7 +2498,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
                     : NK == 1 ? (head_l0 ? (const void*)wnv_ring_kernel<1, true> : (const void*)wnv_ring_kernel<1, false>)
                               : NK == 2 ? (const void*)wnv_ring_kernel<2, false> : (const void*)wnv_ring_kernel_k512;
     RING_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    p.tap_parts = tap_parts;
+    p.tap_parts = tap_parts; p.tb = tb;
     const int grid = split ? p.ring_blocks + tap_parts * st->L : p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);
     if (p.ring_blocks > ncu) { err = "ring kernel: too many layers for one ring per XCD"; return WNV_ERR_UNSUPPORTED; }
     // every LIVE workgroup must be resident at once (they wait for each other): ask the runtime how many fit a CU with this

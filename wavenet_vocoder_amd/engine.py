@@ -293,6 +293,10 @@ class Engine:
         """1 = generic kernel, 2 = pipelined ring kernel served the last ``generate`` (0: none yet)."""
         return int(_lib.lib().wnv_last_kernel(self._h))
 
+    def inject_timeouts(self, n: int) -> None:
+        """Test hook (``wnv_debug_inject_timeouts``): the next ``n`` ring launches of auto mode report a time-out unlaunched."""
+        check(_lib.lib().wnv_debug_inject_timeouts(self._h, int(n)))
+
 
 class QueueConv:
     """conv.Conv1d.incremental_forward state machine on the device (reference conv.py:17-49)."""

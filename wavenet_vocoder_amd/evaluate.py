@@ -97,7 +97,9 @@ def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterance
                    synth_group: Optional[Callable[[torch.Tensor, List[int]], torch.Tensor]] = None) -> List[str]:
     """The main loop of evaluate.py (:155-251) without reference wavs: every ``*-feats.npy`` under ``data_dir`` becomes
     ``dst_dir/{name}_gen.wav``.  Utterances are sharded over the ranks of ``group`` (one process per GPU); rank 0
-    writes the files and returns their paths (other ranks return [])."""
+    writes the files and returns their paths (other ranks return []).  Utterances per launch: ``hparams.batch_size`` when it is
+    set (the reference's recipes pass 32, egs/mol/run.sh:31), otherwise from the measured throughput curve
+    (``sharding.auto_group_size``: up to 32 per GPU)."""
     from . import synthesis
     utts = collect_features(data_dir, speaker_id=speaker_id, num_utterances=num_utterances)
     assert len(utts) > 0, f"no *-feats.npy under {data_dir}"
@@ -111,7 +113,7 @@ def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterance
         return torch.from_numpy(np.clip(wav, -1.0, 1.0))                         # evaluate.py:238
 
     wavs = sharding.synthesize_sharded(mels, synth_group or default_group, hop_size=hparams.hop_size,
-                                       cin_pad=hparams.cin_pad, group_size=getattr(hparams, "batch_size", 8), group=group)
+                                       cin_pad=hparams.cin_pad, group_size=getattr(hparams, "batch_size", None), group=group)
     if wavs is None:
         return []
     os.makedirs(dst_dir, exist_ok=True)

@@ -193,9 +193,17 @@ class EngineHost:
             if not self.scalar_input and quantize and self.kernel in (0, 2) and self.stream_replay_tape and T >= 1024:
                 # a mu-law model draws B x out_channels exponentials per step (wavenet.py:334-335): the tape takes longer to draw than
                 # the kernel runs -- so it is drawn WHILE the kernel runs (ring kernel only; anything else takes the path below)
-                out = self._generate_streamed(eng, B, T, c_up, g_feat, g_ids, init, test_inputs, softmax)
-                if out is not None:
-                    return out
+                skip = self.__dict__.get("_stream_cooldown", 0)
+                if skip > 0 and self.kernel == 0:
+                    # auto mode, and the last streamed launch timed out: the device does not keep the ring co-resident right now.  The
+                    # streamed path names the ring kernel explicitly (it has to: WNV_GEN_ASYNC), which would bypass the handle's own
+                    # pause after a time-out -- so it pauses the same way (2, 4 ... 32 calls) and the ordinary path, which honours the
+                    # handle's state, serves these calls.
+                    self.__dict__["_stream_cooldown"] = skip - 1
+                else:
+                    out = self._generate_streamed(eng, B, T, c_up, g_feat, g_ids, init, test_inputs, softmax)
+                    if out is not None:
+                        return out
             tape = make_noise_tape(T, B, scalar_input=self.scalar_input,
                                    output_distribution=self.output_distribution, out_channels=self.out_channels)
             noise = tape.to(dev, non_blocking=False).contiguous()
@@ -212,6 +220,7 @@ class EngineHost:
 
     stream_replay_tape = True     # one-hot models: draw the replay tape while the ring kernel runs (False: draw it first, as for the other kernels)
     stream_replay_tape_max_bytes = 1 << 30   # ... unless the tape would need more pinned host memory than this
+    stream_replay_max_batch = 64             # ... or the batch is more than one ring launch pipelines (WNV_GEN_ASYNC: wnv.h)
 
     def _generate_streamed(self, eng, B, T, c_up, g_feat, g_ids, init, test_inputs, softmax):
         """``rng = "replay"`` for one-hot models at kernel speed: the tape of B x out_channels exponentials per step -- the numbers
@@ -220,6 +229,8 @@ class EngineHost:
         advances as it draws the tape chunk by chunk (same draws, same order, same generator: ``exponential_draws``).  Returns None
         -- with the generator untouched -- when the ring kernel does not take the call (other kernels get their tape up front)."""
         nz = self.out_channels
+        if B > self.stream_replay_max_batch:                    # an asynchronous launch is ONE launch: larger batches run in slices (tape up front)
+            return None
         probe = torch.empty(1)
         state = torch.get_rng_state()
         if not exponential_draws(probe):                        # the fast draw is unavailable on this build: let the caller draw as before
@@ -252,11 +263,16 @@ class EngineHost:
             tape = tape_buf.view(torch.float32, (T, B, nz))
             ready = ready_buf.view(torch.int32, (1,))
             ready[0] = 0
+            timed_out = False
             try:
                 out, params, _ = eng.generate(B=B, T=T, c_up=c_up, g=g_feat, g_ids=g_ids, initial=init, teacher=test_inputs, noise=tape_buf.dev,
                                               noise_ready=ready_buf.dev, softmax=softmax, quantize=True, want_params=self.capture_params,
                                               kernel=2, asynchronous=True)
-            except (NotImplementedError, TimeoutError):         # not a ring configuration / no room for the ring: nothing was drawn
+            except (NotImplementedError, TimeoutError, ValueError) as e:
+                # not a ring configuration / no room for the ring / an argument the asynchronous launch refuses: nothing was drawn, the
+                # generator is untouched -- the caller takes the ordinary path (which reports a real argument error itself)
+                if isinstance(e, TimeoutError):
+                    self._note_stream_timeout()
                 return None
             step = max(64, (1 << 19) // (B * nz))               # ~0.5 M values per chunk: a few milliseconds of drawing
             for t0 in range(0, T, step):
@@ -267,13 +283,26 @@ class EngineHost:
                 eng.wait()
             except TimeoutError:
                 # the launch lost its CUs on the way: the tape is complete by now -- serve the call through the ordinary path with it
+                self._note_stream_timeout()
+                timed_out = True
                 noise = tape.clone().to(eng.device)
                 out, params, _ = eng.generate(B=B, T=T, c_up=c_up, g=g_feat, g_ids=g_ids, initial=init, teacher=test_inputs, noise=noise,
                                               softmax=softmax, quantize=True, want_params=self.capture_params, kernel=1)
+            if not timed_out:
+                self.__dict__["_stream_backoff"] = 0
             self.last_params = params
             return out
         finally:
             torch.cuda.synchronize(eng.device)                   # nothing on the device reads the buffers any more
+
+    def _note_stream_timeout(self):
+        """A streamed launch gave up its bounded waits: pause the streamed path for 2, 4 ... 32 calls (the handle's own policy for
+        auto mode, wnv_host.cpp ``persist_cooldown``), so that a device that cannot keep the ring resident does not cost every
+        one-hot call a time-out before the fallback."""
+        back = self.__dict__.get("_stream_backoff", 0)
+        back = min(2 * back, 32) if back else 2
+        self.__dict__["_stream_backoff"] = back
+        self.__dict__["_stream_cooldown"] = back
 
 
 def make_wavenet_amd(reference_wavenet_cls):

@@ -53,7 +53,10 @@ def _bulk_matches_per_step(kind: str) -> bool:
     return ok
 
 
-_U_SCRATCH = {}
+import threading
+
+_U_SCRATCH = threading.local()     # per thread: uniform_ and the ctypes call release the GIL, two callers must not share the staging buffer
+_U_CHUNK = 1 << 21                 # values per staging pass: 16 MB of float64, whatever the size of the request
 
 
 def exponential_draws(out: torch.Tensor, generator: Optional[torch.Generator] = None) -> bool:
@@ -86,12 +89,19 @@ def exponential_draws(out: torch.Tensor, generator: Optional[torch.Generator] = 
     n = out.numel()
     kw = {} if generator is None else {"generator": generator}
     # (the float64 staging buffer is kept: a fresh 4-MB tensor per chunk costs more in page faults than the draw itself -- measured
-    #  on the GPU box, inside a process with a HIP context: 4.8 ms per chunk against 1.2 ms for uniform_ alone)
-    u = _U_SCRATCH.get("u")
-    if u is None or u.numel() < n:
-        u = _U_SCRATCH["u"] = torch.empty(max(n, 1 << 19), dtype=torch.float64)
-    u = u[:n].uniform_(0.0, 1.0, **kw)
-    _lib.check(_lib.lib().wnv_exponential_from_uniform(u.data_ptr(), out.data_ptr(), n, min(os.cpu_count() or 1, 16)))
+    #  on the GPU box, inside a process with a HIP context: 4.8 ms per chunk against 1.2 ms for uniform_ alone.  It is bounded --
+    #  a large request is staged in passes of _U_CHUNK values: uniform_ walks the generator element by element, so consecutive
+    #  passes see the stream one bulk call would -- and belongs to the calling thread.)
+    u = getattr(_U_SCRATCH, "u", None)
+    need = min(n, _U_CHUNK)
+    if u is None or u.numel() < need:
+        u = _U_SCRATCH.u = torch.empty(max(need, 1 << 19), dtype=torch.float64)
+    flat = out.view(-1)
+    nthreads = min(os.cpu_count() or 1, 16)
+    for a in range(0, n, _U_CHUNK):
+        m = min(_U_CHUNK, n - a)
+        uu = u[:m].uniform_(0.0, 1.0, **kw)
+        _lib.check(_lib.lib().wnv_exponential_from_uniform(uu.data_ptr(), flat[a:a + m].data_ptr(), m, nthreads))
     return True
 
 

@@ -5,8 +5,10 @@ the path shards with NO data-path collective: one process per GPU (torch.distrib
 RCCL over xGMI on the GPU box, "gloo" in the CPU tests), every rank
   1. holds a replica of the weights (loaded from the checkpoint, or broadcast once from rank 0),
   2. takes its share of the utterances (longest-processing-time-first over total samples),
-  3. packs them into groups of ``group_size`` of similar length (a group runs to its longest member,
-     exactly like the reference's zero-padded batches, evaluate.py:55-57,215),
+  3. packs them into groups of similar length (a group runs to its longest member, exactly like the reference's
+     zero-padded batches, evaluate.py:55-57,215); the group size comes from the MEASURED throughput curve of the ring
+     kernel unless the caller fixes it (``auto_group_size``: the reference's recipes synthesise 32 utterances per batch,
+     egs/mol/run.sh:31),
   4. synthesises group by group, trims every waveform to its true length,
 and the results are gathered to rank 0 (variable-length, one object gather at the very end).
 """
@@ -16,7 +18,28 @@ from typing import Callable, List, Optional, Sequence
 
 import torch
 
-__all__ = ["lpt_assign", "pack_groups", "pad_group", "broadcast_weights", "synthesize_sharded"]
+__all__ = ["lpt_assign", "pack_groups", "pad_group", "broadcast_weights", "synthesize_sharded", "auto_group_size",
+           "padding_loss", "THROUGHPUT_GROUP"]
+
+# Utterances per launch at which the ring kernel's aggregate rate stops growing (profiles/r03_ring_v14_batches_and_configs.txt and the
+# round-4 rows of profiles/README.md: kSamples/s per GPU 496 / 954 / 1903 / 1984 / 1980 at B = 8 / 16 / 32 / 48 / 64).  Up to here every
+# utterance of a group advances at the chain latency (~2.5x real time at 24 kHz), so a larger group costs no more wall time than a
+# smaller one; beyond it the per-utterance rate drops and nothing is gained.
+THROUGHPUT_GROUP = 32
+
+
+def auto_group_size(n_pending: int) -> int:
+    """Group size for ``n_pending`` utterances waiting on ONE GPU when the caller did not fix one: everything in one launch while it
+    fits the plateau (few utterances: a group of <= 8 is one utterance per ring, the lowest latency), groups of ``THROUGHPUT_GROUP``
+    otherwise -- 40 pending utterances run as 32 + 8."""
+    return max(1, min(int(n_pending), THROUGHPUT_GROUP))
+
+
+def padding_loss(groups: Sequence[Sequence[int]], lengths: Sequence[int]) -> float:
+    """Fraction of the synthesised samples that is padding: a group runs to its longest member (evaluate.py:55-57,215)."""
+    padded = sum(len(g) * max(int(lengths[i]) for i in g) for g in groups if len(g))
+    true = sum(int(lengths[i]) for g in groups for i in g)
+    return 0.0 if padded == 0 else 1.0 - true / padded
 
 
 def lpt_assign(lengths: Sequence[int], n_bins: int) -> List[List[int]]:
@@ -30,9 +53,15 @@ def lpt_assign(lengths: Sequence[int], n_bins: int) -> List[List[int]]:
     return bins
 
 
-def pack_groups(indices: Sequence[int], lengths: Sequence[int], group_size: int) -> List[List[int]]:
-    """Groups of at most ``group_size`` utterances of neighbouring length (descending)."""
+def pack_groups(indices: Sequence[int], lengths: Sequence[int], group_size: Optional[int] = None) -> List[List[int]]:
+    """Groups of at most ``group_size`` utterances of neighbouring length (descending).  ``group_size=None``: chosen from the
+    measured throughput curve (``auto_group_size``)."""
     order = sorted(indices, key=lambda i: (-int(lengths[i]), i))
+    if group_size is None:
+        group_size = auto_group_size(len(order))
+    if int(group_size) < 1:
+        raise ValueError(f"group_size must be >= 1, got {group_size}")
+    group_size = int(group_size)
     return [order[k:k + group_size] for k in range(0, len(order), group_size)]
 
 
@@ -69,14 +98,16 @@ def broadcast_weights(model: torch.nn.Module, src: int = 0, group=None) -> None:
 
 
 def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torch.Tensor, List[int]], torch.Tensor],
-                       *, hop_size: int, cin_pad: int, group_size: int = 8, group=None,
-                       gather_to: Optional[int] = 0) -> Optional[List[torch.Tensor]]:
+                       *, hop_size: int, cin_pad: int, group_size: Optional[int] = None, group=None,
+                       gather_to: Optional[int] = 0, stats: Optional[dict] = None) -> Optional[List[torch.Tensor]]:
     """Distribute ``mels`` (list of (cin, frames) tensors, identical on every rank) over the ranks.
 
     ``synth_group(c, idx)`` receives the padded batch ``c`` (B, cin, frames + 2*cin_pad) and the global utterance
     indices, and returns the waveforms (B, T) -- on the GPU box that is
     ``model.incremental_forward(c=c.cuda(), T=frames*hop)[:, 0]``.  Returns the list of trimmed waveforms in the
-    original order on rank ``gather_to`` (on every rank if ``gather_to`` is None), None elsewhere."""
+    original order on rank ``gather_to`` (on every rank if ``gather_to`` is None), None elsewhere.
+    ``group_size=None`` (default): from the measured throughput curve, ``auto_group_size`` -- up to 32 utterances per launch; a
+    number (``hparams.batch_size`` of the caller) wins.  ``stats``: filled with this rank's groups, true / padded samples."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if distributed else 0
@@ -84,7 +115,12 @@ def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torc
     lengths = [int(m.shape[-1]) * hop_size for m in mels]
     mine = lpt_assign(lengths, world)[rank]
     local = {}
-    for grp in pack_groups(mine, lengths, group_size):
+    groups = pack_groups(mine, lengths, group_size)
+    if stats is not None:
+        stats.update(groups=[list(g) for g in groups], true_samples=sum(lengths[i] for i in mine),
+                     padded_samples=sum(len(g) * max(lengths[i] for i in g) for g in groups if len(g)),
+                     padding_loss=padding_loss(groups, lengths))
+    for grp in groups:
         c = pad_group([mels[i] for i in grp], cin_pad)
         wav = synth_group(c, list(grp))
         for row, i in enumerate(grp):

@@ -29,7 +29,9 @@ def default_hparams(**over) -> SimpleNamespace:
     h = SimpleNamespace(input_type="raw", quantize_channels=65536, upsample_conditional_features=True, cin_pad=2,
                         hop_size=256, log_scale_min=-32.23619130191664, postprocess="inv_preemphasis",
                         global_gain_scale=0.55, preemphasis_coef=0.85,
-                        cin_channels=80, sample_rate=22050, batch_size=8)        # read by evaluate.synthesize_dir
+                        cin_channels=80, sample_rate=22050,
+                        batch_size=None)        # read by evaluate.synthesize_dir: utterances per launch; None = from the measured
+                                                # throughput curve (sharding.auto_group_size; the reference's recipes pass 32)
     h.__dict__.update(over)
     return h
 
