@@ -19,6 +19,12 @@ class Case:
         self.kwargs = self.meta["kwargs"]
         self.wn = {k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("wn/")}
         self.fused = {k[6:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("fused/")}
+        self.stress = self.meta.get("extras", {}).get("stress")
+        if self.stress:                # trained-magnitude cases: the weights are re-made from the spec make_golden.py used
+            from tests._stress import stress_state
+            self.wn = stress_state(self.meta["keys_shapes"], self.stress, scalar_input=self.kwargs.get("scalar_input", False),
+                                   out_channels=self.kwargs["out_channels"],
+                                   output_distribution=self.kwargs.get("output_distribution", "Logistic"))
         self.fused_is_derived = not self.fused
         if self.fused_is_derived:      # large cases store only the reference's weight-normed state_dict; make_golden.py proved
             from wavenet_vocoder_amd.conv import fold_weight_norm_     # this fold equal to make_generation_fast_ when it wrote them

@@ -12,13 +12,28 @@ import wavenet_vocoder_amd as wnv
 from wavenet_vocoder_amd.conv import Conv1d
 from wavenet_vocoder_amd.modules import ResidualConv1dGLU
 from tests._golden import CASE_NAMES, Case, load_layers
-from tests._margins import assert_match_or_near_tie
+from tests._margins import assert_free_run_agrees_until_near_tie, assert_match_or_near_tie
+from tests._stress import close_enough
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 # (case, kernel) pairs: 1 = the generic single-workgroup kernel covers every case; 2 = the pipelined ring kernel takes the cases
 # of its geometry (residual 128 / gate 256 / skip 128: the reference-made ring_* fixtures)
-CASE_KERNELS = [(n, 1) for n in CASE_NAMES] + [(n, 2) for n in CASE_NAMES if n.startswith("ring_")]
+# stress_*: trained-magnitude weights (tests/_stress.py; round 4) -- the two R128 cases on the ring kernel too, the wide one on
+# the group ring (kernel 3)
+CASE_KERNELS = [(n, 1) for n in CASE_NAMES] + [(n, 2) for n in CASE_NAMES if n.startswith("ring_") or n.endswith("_r128")] \
+    + [(n, 3) for n in CASE_NAMES if n.startswith("stress_wide")]
+
+
+def params_close(got, want, stress):
+    """1e-4 absolute on the reference's random-init cases (tests/test_model.py:361-366); trained-magnitude cases: 1e-4 absolute
+    + 1e-5 relative (head outputs reach 10-20 there; the reference's own online / offline gap is recorded in the fixture)."""
+    if stress:
+        ok, excess, worst = close_enough(got, want)
+        assert ok, f"head outputs differ by {worst:.3e} (beyond 1e-4 + 1e-5 |x| by {excess:.3e})"
+    else:
+        err = (got - want).abs().max().item()
+        assert err < TOL, f"distribution parameters differ by {err}"
 
 
 def model_on_gpu(c, layout="wn"):
@@ -46,12 +61,17 @@ def test_teacher_forced_matches_reference(name, kernel):
     assert m._get_engine().last_kernel() == kernel
     if scalar:
         p = m.last_params.cpu()
-        err = (p - c.get("tf_params")).abs().max().item()
-        assert err < TOL, f"distribution parameters differ by {err}"
+        params_close(p, c.get("tf_params"), c.stress)
         # samples: same noise, so they agree -- except where the Gumbel-max pick is a near tie in the reference's own numbers
         assert_match_or_near_tie(y, c.get("tf_out"), c.get("tf_params"), c.get("tf_tape"), c.kwargs, tol=TOL)
-        # batch forward of the reference == our incremental parameters (online == offline)
-        assert (p - c.get("fwd")).abs().max().item() < TOL
+        # batch forward of the reference == our incremental parameters (online == offline; trained-magnitude cases: the reference's
+        # own two paths part by io/ref_online_offline_err there, which comes on top)
+        if c.stress:
+            gap = float(c.get("ref_online_offline_err")[0])
+            d = (p.double() - c.get("fwd").double()).abs() - (1e-4 + 1e-5 * c.get("fwd").double().abs())
+            assert float(d.max()) <= gap, (float(d.max()), gap)
+        else:
+            assert (p - c.get("fwd")).abs().max().item() < TOL
     else:
         err = (y - c.get("tf_out")).abs().max().item()
         assert err < TOL, f"probabilities differ by {err}"
@@ -68,7 +88,10 @@ def test_free_running_with_shared_tape(name, kernel):
     y = m.incremental_forward(initial_input=cuda(c.get("fr_init")), c=cuda(c.get("c_fr")), g=cuda(c.get("g_fr")),
                               T=want.size(-1), softmax=True, quantize=True).cpu()
     assert y.shape == want.shape
-    if c.kwargs.get("scalar_input", False):
+    if c.kwargs.get("scalar_input", False) and c.stress:
+        # trained magnitudes: the trajectories may part only through a flipped mixture pick at a near tie (tests/_margins.py)
+        assert_free_run_agrees_until_near_tie(y, want, m.last_params.cpu(), c.get("fr_params"), c.get("fr_tape"), c.kwargs)
+    elif c.kwargs.get("scalar_input", False):
         # free running is chaotic in principle; on these short horizons the trajectories must still agree
         err = (y - want).abs().max().item()
         assert err < 5e-4, err

@@ -28,14 +28,22 @@ def test_teacher_forced(name, layout):
     o = Oracle(oracle_config(c.kwargs), getattr(c, layout))
     scalar = c.kwargs.get("scalar_input", False)
     x = c.get("x")
+    # trained-magnitude cases (tests/_stress.py): head outputs of 10-20 instead of O(1) -- the last-bit differences of the fused
+    # layout's fold (g v / |v| evaluated once, up front) scale with them; relative tolerance 1e-6 of the magnitude on top
+    k = 1.0 + (float(c.get("fwd").abs().max()) if c.stress else 0.0)
     fwd = o.forward(x, c=c.get("c_tf"), g=c.get("g_tf"), softmax=not scalar)
-    assert torch.allclose(fwd, c.get("fwd"), atol=2e-6), (fwd - c.get("fwd")).abs().max()
+    assert torch.allclose(fwd, c.get("fwd"), atol=2e-6 * k), (fwd - c.get("fwd")).abs().max()
     y, p = o.incremental_forward(test_inputs=x, c=c.get("c_tf"), g=c.get("g_tf"), T=x.size(-1),
                                  softmax=True, quantize=False, noise=c.get("tf_tape"),
                                  return_params=True)
     if scalar:
-        assert torch.allclose(p, c.get("tf_params"), atol=2e-6), (p - c.get("tf_params")).abs().max()
-    assert torch.allclose(y, c.get("tf_out"), atol=5e-6), (y - c.get("tf_out")).abs().max()
+        assert torch.allclose(p, c.get("tf_params"), atol=2e-6 * k), (p - c.get("tf_params")).abs().max()
+    if c.stress and scalar:
+        # (a sample is mean + exp(log_scale) * noise, clamped: the same function of the parameters; a Gumbel pick may flip at a near tie)
+        from tests._margins import assert_match_or_near_tie
+        assert_match_or_near_tie(y, c.get("tf_out"), c.get("tf_params"), c.get("tf_tape"), c.kwargs, tol=1e-4)
+    else:
+        assert torch.allclose(y, c.get("tf_out"), atol=5e-6 * k), (y - c.get("tf_out")).abs().max()
 
 
 @pytest.mark.parametrize("name", CASE_NAMES)
