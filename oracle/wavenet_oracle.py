@@ -176,9 +176,9 @@ def sample_categorical(p: torch.Tensor, noise: torch.Tensor) -> torch.Tensor:
 class _QueueConv:
     """conv.py:7-65 : nn.Conv1d evaluated one step at a time from a shifted history buffer."""
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], dilation: int = 1):
-        self.weight = weight.float().contiguous()          # (Cout, Cin, kw)
-        self.bias = None if bias is None else bias.float().contiguous()
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], dilation: int = 1, dtype=torch.float32):
+        self.weight = weight.to(dtype).contiguous()         # (Cout, Cin, kw)
+        self.bias = None if bias is None else bias.to(dtype).contiguous()
         self.kw = weight.size(2)
         self.dilation = int(dilation)
         # conv.py:51-62 : [o, k*Cin + i] = W[o, i, k]
@@ -211,15 +211,15 @@ class _QueueConv:
 class _Layer:
     """modules.py:52-169 ResidualConv1dGLU (eval mode, dropout = identity)."""
 
-    def __init__(self, st: Dict[str, torch.Tensor], prefix: str, dilation: int, kw: int):
+    def __init__(self, st: Dict[str, torch.Tensor], prefix: str, dilation: int, kw: int, dtype=torch.float32):
         g = lambda n: st.get(prefix + n)
         self.dilation = dilation
         self.kw = kw
-        self.conv = _QueueConv(g("conv.weight"), g("conv.bias"), dilation)
-        self.c1 = _QueueConv(g("conv1x1c.weight"), None) if g("conv1x1c.weight") is not None else None
-        self.g1 = _QueueConv(g("conv1x1g.weight"), None) if g("conv1x1g.weight") is not None else None
-        self.out = _QueueConv(g("conv1x1_out.weight"), g("conv1x1_out.bias"))
-        self.skip = _QueueConv(g("conv1x1_skip.weight"), g("conv1x1_skip.bias"))
+        self.conv = _QueueConv(g("conv.weight"), g("conv.bias"), dilation, dtype)
+        self.c1 = _QueueConv(g("conv1x1c.weight"), None, 1, dtype) if g("conv1x1c.weight") is not None else None
+        self.g1 = _QueueConv(g("conv1x1g.weight"), None, 1, dtype) if g("conv1x1g.weight") is not None else None
+        self.out = _QueueConv(g("conv1x1_out.weight"), g("conv1x1_out.bias"), 1, dtype)
+        self.skip = _QueueConv(g("conv1x1_skip.weight"), g("conv1x1_skip.bias"), 1, dtype)
 
     def clear(self):
         for c in (self.conv, self.c1, self.g1, self.out, self.skip):
@@ -256,19 +256,26 @@ class _Layer:
 # the model
 # ----------------------------------------------------------------------------------------------
 class Oracle:
-    """Reference ``WaveNet`` restated; weights from a reference ``state_dict`` (either layout)."""
+    """Reference ``WaveNet`` restated; weights from a reference ``state_dict`` (either layout).
 
-    def __init__(self, cfg: OracleConfig, state: Dict[str, torch.Tensor]):
+    ``dtype``: float32 is the reference's arithmetic and what every parity test compares with.  float64 evaluates the SAME float32
+    weights (folded in float32, then widened) in double: the exact answer an f32 evaluation order -- ATen's or a HIP kernel's -- is an
+    approximation of; tests/test_gpu_stress.py uses it to tell an inaccurate kernel from an ill-conditioned model."""
+
+    def __init__(self, cfg: OracleConfig, state: Dict[str, torch.Tensor], dtype=torch.float32):
         self.cfg = cfg
+        self.dtype = dtype
         st = fold_weight_norm({k: (v if torch.is_tensor(v) else torch.as_tensor(np.asarray(v)))
                                for k, v in state.items()})
         self.st = st
-        self.first = _QueueConv(st["first_conv.weight"], st["first_conv.bias"])
-        self.layers = [_Layer(st, f"conv_layers.{i}.", d, cfg.kernel_size)
+        self.first = _QueueConv(st["first_conv.weight"], st["first_conv.bias"], 1, dtype)
+        self.layers = [_Layer(st, f"conv_layers.{i}.", d, cfg.kernel_size, dtype)
                        for i, d in enumerate(cfg.dilations)]
-        self.last1 = _QueueConv(st["last_conv_layers.1.weight"], st["last_conv_layers.1.bias"])
-        self.last3 = _QueueConv(st["last_conv_layers.3.weight"], st["last_conv_layers.3.bias"])
+        self.last1 = _QueueConv(st["last_conv_layers.1.weight"], st["last_conv_layers.1.bias"], 1, dtype)
+        self.last3 = _QueueConv(st["last_conv_layers.3.weight"], st["last_conv_layers.3.bias"], 1, dtype)
         self.embed = st.get("embed_speakers.weight")
+        if self.embed is not None:
+            self.embed = self.embed.to(dtype)
         self.receptive_field = receptive_field_size(cfg.layers, cfg.stacks, cfg.kernel_size)
 
     # -- upsample.py ---------------------------------------------------------------------------
@@ -304,7 +311,7 @@ class Oracle:
             return None
         if self.embed is not None:                                           # wavenet.py:264-268
             g = F.embedding(g.view(B, -1).long(), self.embed).transpose(1, 2)
-        g = g.float()
+        g = g.to(self.dtype)
         return g.unsqueeze(-1) if g.dim() == 2 else g                        # (B, gin, 1)
 
     def clear_buffer(self):
@@ -322,6 +329,8 @@ class Oracle:
         if c is not None and self.cfg.upsample_conditional_features:
             c = self.upsample(c)
             assert c.size(-1) == T
+        x = x.to(self.dtype)
+        c = None if c is None else c.to(self.dtype)
         h = self.first.full(x, 0)
         skips = 0
         for f in self.layers:
@@ -370,7 +379,9 @@ class Oracle:
                 initial_input[:, :, 127] = 1
         elif initial_input.size(1) == cfg.out_channels:                      # wavenet.py:291-292
             initial_input = initial_input.transpose(1, 2).contiguous()
-        cur = initial_input.float()
+        cur = initial_input.to(self.dtype)
+        if c is not None:
+            c = c.to(self.dtype)
         outs, params = [], []
         scale = math.sqrt(1.0 / len(self.layers))
         self.last_steps, self.last_seconds = 0, 0.0
@@ -381,7 +392,7 @@ class Oracle:
                     break
             self.last_steps = t + 1
             if test_inputs is not None and t < test_inputs.size(1):          # wavenet.py:297-301
-                cur = test_inputs[:, t, :].unsqueeze(1).float()
+                cur = test_inputs[:, t, :].unsqueeze(1).to(self.dtype)
             elif t > 0:
                 cur = outs[-1]
             ct = None if c is None else c[:, t, :].unsqueeze(1)

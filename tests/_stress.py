@@ -8,9 +8,17 @@ numerical regime is produced by rule: `stress_state` maps a list of (key, shape)
 tests/golden/make_golden.py (which stores only the reference's outputs; the weights are re-made here, bit for bit, from the spec
 in the fixture's meta) and the models under test.
 
-spec = {"gain": g, "seed": s}:  weight_g of the dilated / 1x1 convolutions ~ U(0.6 g, 1.4 g) per output channel (a row of the
-folded weight then has that 2-norm: |z| ~ g |h|), biases ~ U(-2, 2); the head's last 1x1: mixture logits / means modest, log-scale
-biases ~ U(-14, -5) (scalar-input models) or logit biases ~ N(0, 2) (one-hot models)."""
+spec = {"gain": g, "seed": s, "mode": "all" | "drive"}:
+  mode "all" (default): weight_g of the dilated / 1x1 convolutions ~ U(0.6 g, 1.4 g) per output channel (a row of the folded weight
+      then has that 2-norm: |z| ~ g |h|; the reference's initialisation has row norms of ~2, so g = 2 / 4 / 8 are x1 / x2 / x4),
+      conv1x1_out / conv1x1_skip ~ U(0.3 g, 0.8 g), biases ~ U(-2, 2).  Scaling the RECURRENT path makes the 24-layer map itself
+      ill-conditioned (a perturbation grows ~g-fold per layer: at g = 8 ANY two f32 evaluation orders differ by O(1), ATen's own
+      online and offline paths included) -- tests/test_gpu_stress.py therefore measures against the float64 answer;
+  mode "drive": the recurrent path keeps the initialisation's norms (dilated conv ~2, conv1x1_out / skip ~1) and the SATURATION comes
+      from what drives the gates of a trained vocoder -- the conditioning 1x1s ~ U(0.6 g, 1.4 g) and biases ~ U(-g, g): gate
+      pre-activations of +-10 ... +-60 on a well-conditioned map, where the strict tolerance applies.
+The head's last 1x1: mixture logits / means modest, log-scale biases ~ U(-14, -5) (scalar-input models) or logit biases ~ N(0, 2)
+(one-hot models)."""
 import hashlib
 
 import torch
@@ -28,6 +36,7 @@ def _u(shape, lo, hi, g):
 def stress_state(keys_shapes, spec, *, scalar_input, out_channels, output_distribution="Logistic"):
     """{key: tensor} in the reference's WEIGHT-NORMED layout for the given [(key, shape), ...]."""
     gain, seed = float(spec["gain"]), int(spec["seed"])
+    drive = spec.get("mode", "all") == "drive"
     sd = {}
     for key, shape in keys_shapes:
         shape = tuple(int(x) for x in shape)
@@ -40,8 +49,12 @@ def stress_state(keys_shapes, spec, *, scalar_input, out_channels, output_distri
         elif leaf == "weight_g":
             if mod == "first_conv":
                 t = _u(shape, 0.5, 2.0, g)
+            elif mod.endswith(".conv") and drive:
+                t = _u(shape, 1.2, 2.8, g)
             elif mod.endswith(".conv") or mod.endswith("conv1x1c") or mod.endswith("conv1x1g"):
                 t = _u(shape, 0.6 * gain, 1.4 * gain, g)
+            elif (mod.endswith("conv1x1_out") or mod.endswith("conv1x1_skip")) and drive:
+                t = _u(shape, 0.6, 1.4, g)
             elif mod.endswith("conv1x1_out") or mod.endswith("conv1x1_skip"):
                 t = _u(shape, 0.3 * gain, 0.8 * gain, g)
             elif mod == "last_conv_layers.1":
@@ -65,6 +78,8 @@ def stress_state(keys_shapes, spec, *, scalar_input, out_channels, output_distri
                 t = torch.randn(shape, generator=g) * 2.0
             elif mod == "first_conv":
                 t = _u(shape, -1.0, 1.0, g)
+            elif drive and mod.endswith(".conv"):
+                t = _u(shape, -gain, gain, g)
             else:
                 t = _u(shape, -2.0, 2.0, g)
         elif leaf == "weight":                                   # embed_speakers.weight, plain (un-normed) convolutions
