@@ -20,8 +20,8 @@
 //     incl. LDS write + barrier, scripts/ubench_hop.hip); otherwise write-through (sc1) stores, placement-independent
 //     (~0.65-0.8 us).  Tags are launch-unique, mailboxes are never re-zeroed;
 //   * tap workgroup (run_tap): the dilated conv's older taps + the local-conditioning 1x1 of its layer for EVERY
-//     utterance, matrix resident in VGPRs + LDS, history rings owned here; bulk records (16-B write-through payload,
-//     drained, one tag granule) carry h_l[t] in and pre_l[t+1] out with a whole step of slack;
+//     utterance, matrix resident in VGPRs + LDS, history rings owned here; records of write-through tagged granules carry
+//     h_l[t] in and pre_l[t+1] out with a whole step of slack;
 //   * head (run_head): skip sum -> output MLP (registers) -> sampler -> first_conv of the next step.
 //
 // Every wait is bounded: a spin that exceeds its budget writes a code to `status` and every workgroup drains out
@@ -82,7 +82,7 @@ struct RingParams {
     unsigned long long *zmail;                   // head_l0: Z[b][256] = N_1 h_0[t] (affine in the sample: made by the head), read by stage 1
     unsigned long long *gmail;                   // layer inputs handed on: G[b][2 (t parity)][S+1][128], slot j = h_{j-1}[t] as stage j formed it (read by stage j + 1)
     unsigned long long *omail;                   // head parts j > 0 -> part 0: partial head outputs O[b][NH][Op]
-    float *fmail, *pmail;                        // bulk records: stage -> tap workgroup h_l[t]: F[b][L][step parity][4 + 128]; tap workgroup -> stage pre_l[t+1]: P[b][L][step parity][4 + 256]
+    unsigned long long *fmail, *pmail;           // records: stage -> tap workgroup h_l[t]: F[b][L][step parity][128] granules; tap workgroup -> stage pre_l[t+1]: P[b][L][step parity][256]
     int ring_blocks, tap_parts;                  // blocks [0, ring_blocks) = rings, then tap_parts tap workgroups per layer (part q serves passes q, q + parts, ...)
     int tb;                                      // utterances per tap pass (<= TB)
     int kper, kreg_rows, klds_rows;              // tap workgroup: K rows per wave; of those resident in VGPRs / in LDS (the rest streams)
@@ -121,43 +121,63 @@ __device__ __forceinline__ void st_granule2(u64* p, unsigned tag, float v0, floa
     else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
 }
 
-// BULK hand-off for the traffic nobody waits for (stage <-> tap workgroup, any XCD): raw floats in 16-B write-through
-// stores, the producer drains them (vmcnt(0)) and then publishes ONE tag granule; the consumer polls that granule from a
-// single lane at a relaxed cadence and reads the payload with L1-bypassing loads.  A quarter of the fabric writes of the
-// per-value granules and one polled word instead of hundreds (MI355X_MICROARCH.md: handoff-flag, "16-B sc1 stores and
-// sc1 loads").  Layout of one record: [flag granule, pad to 16 B][payload floats].
-typedef float f4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void bulk_store16(float* dst, float4 v) {
-    const f4v x = {v.x, v.y, v.z, v.w};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(dst), "v"(x) : "memory");
+// RECORDS: the vectors nobody on the chain waits for -- stage -> tap workgroup h_l[t] (128 values), tap workgroup -> stage pre_l[t+1]
+// (256 values), any XCD -- travel as data-tagged granules like everything else: 16-byte WRITE-THROUGH stores of two granules each,
+// no drain, no flag.  (Until round 4 these were "bulk records": raw floats, the producer drained its write-through stores --
+// s_waitcnt vmcnt(0), ~1 us -- and then published one tag granule.  Nobody on the chain waited for that drain, but with several
+// utterances per ring the stage's wave 0 spent it once per utterance INSIDE the stage's occupancy, and a tap pass once per pass:
+// profiles/r04_tap_bound_experiment.txt -- the rings alone saturated at 2.77 MSamples/s, 2.9 us per utterance and stage.)
+// The reader first polls the record's FIRST 16 bytes from every lane (one request) at a relaxed cadence -- a record can be most of a
+// step away, and hundreds of waves polling whole records would load the fabric the chain's hops share -- and, once that tag shows,
+// the whole record until every tag matches.
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u4v ld16_sc1(const u64* p) {
+    u4v x;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
+    return x;
 }
-__device__ __forceinline__ float4 bulk_load16(const float* src) {
-    f4v x;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(src) : "memory");
-    return make_float4(x.x, x.y, x.z, x.w);
+__device__ __forceinline__ void ld16x2_sc1(const u64* p, u4v& a, u4v& b) {                  // granules p[0..1] and p[2..3]: one round trip
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
 }
-__device__ __forceinline__ void bulk_publish(u64* flag, unsigned tag, int lane) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's payload stores have left the CU
-    if (lane == 0) st_granule(flag, tag, 0.f, false);
-}
-// one wave; returns false on abort / timeout
-__device__ __forceinline__ bool bulk_wait(const u64* flag, unsigned tag, unsigned int* status, unsigned code, int lane) {
+// one wave receives a record of 128 NG values: lane holds granules 2 NG lane .. 2 NG lane + 2 NG - 1; returns false on abort / timeout
+template <int NG>
+__device__ __forceinline__ bool rec_recv(const u64* rec, unsigned tag, float (&v)[2 * NG], unsigned int* status, unsigned code, int lane) {
+    static_assert(NG == 1 || NG == 2, "");
     unsigned spins = 0;
     for (;;) {
-        const u64 x = ld_granule(flag);                            // every lane the same word: one request
-        if ((unsigned)(x >> 32) == tag) return true;
+        const u4v x = ld16_sc1(rec);                               // every lane the same 16 bytes: one request
+        if (x.y == tag) break;
         if ((++spins & 63u) == 0u) {
             if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             if (spins > (SPIN_LIMIT >> 3)) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
         }
         __builtin_amdgcn_s_sleep(8);
     }
+    spins = 0;
+    for (;;) {
+        bool ok;
+        if constexpr (NG == 1) {
+            const u4v x = ld16_sc1(rec + 2 * lane);
+            v[0] = __uint_as_float(x.x); v[1] = __uint_as_float(x.z);
+            ok = x.y == tag && x.w == tag;
+        } else {
+            u4v x, y;
+            ld16x2_sc1(rec + 4 * lane, x, y);
+            v[0] = __uint_as_float(x.x); v[1] = __uint_as_float(x.z); v[2] = __uint_as_float(y.x); v[3] = __uint_as_float(y.z);
+            ok = x.y == tag && x.w == tag && y.y == tag && y.w == tag;
+        }
+        if (__all(ok)) return true;
+        if ((++spins & 255u) == 0u) {
+            if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+            if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
+        }
+    }
 }
 
 // ONE wave receives a whole 128-value vector: two adjacent granules per lane in one 16-byte L1-bypassing load (load and wait
 // are one asm statement: no register is ever in flight where the compiler can see it).  (Two polling waves see an arrival at
 // the later of two independent poll phases; one wave sees it at its own.)
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ bool wave_recv2(const u64* g2, unsigned tag, float& v0, float& v1, unsigned int* status,
                                            unsigned code, int lane, bool have_first, u4v first) {
     unsigned spins = 0;
@@ -570,10 +590,10 @@ __host__ __device__ constexpr size_t stage_lds_floats(int NK) { return (size_t)3
 // ... and h_l[step] the other way: a ring does not wait for such a layer's taps any more, so it may file h_l[t] before the tap workgroup has
 // read h_l[t-1]; h_l[t+1] -- the next writer of h_l[t-1]'s slot -- needs pre_l[t+1], which that workgroup makes only after it has.
 __device__ __forceinline__ size_t h_rec(const RingParams& p, int b, int l, int step) {
-    return (((size_t)b * p.L + l) * 2 + (size_t)(step & 1)) * (4 + RC);
+    return (((size_t)b * p.L + l) * 2 + (size_t)(step & 1)) * RC;                    // in granules
 }
 __device__ __forceinline__ size_t pre_rec(const RingParams& p, int b, int l, int step) {
-    return (((size_t)b * p.L + l) * 2 + (size_t)(step & 1)) * (4 + GC);
+    return (((size_t)b * p.L + l) * 2 + (size_t)(step & 1)) * GC;                    // in granules
 }
 
 // ---- tap workgroup (one per layer, shared by all rings) -----------------------------------------------------------------
@@ -609,7 +629,7 @@ __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
 #ifndef WNV_EXP_NOPRE
 #define WNV_EXP_NOPRE 0
 #endif
-__device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
+__device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int l, int part, float* smem) {
     if (WNV_EXP_NOPRE >= 2) return;
     const TapLds s = carve_tap(smem, p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -693,14 +713,13 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                     for (int e = lane; e < p.cin; e += 64) xu[hoff + e] = cb[e];
                 TAP_STAMP(1);
                 if (tf >= 0) {
-                    const float* rec = p.fmail + h_rec(p, b, l, tf);
-                    if (!bulk_wait(reinterpret_cast<const u64*>(rec), p.tag_base + (unsigned)tf + 1u, p.status, 0x600u + (unsigned)l, lane))
+                    float hv[2];                                                  // channels 2 lane, 2 lane + 1
+                    if (!rec_recv<1>(p.fmail + h_rec(p, b, l, tf), p.tag_base + (unsigned)tf + 1u, hv, p.status, 0x600u + (unsigned)l, lane))
                         s.flags[0] = 1;
-                    if (lane < RC / 4 && rows > 0) {
-                        const float4 v = bulk_load16(rec + 4 + 4 * lane);
+                    if (rows > 0) {
                         float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
-                        *reinterpret_cast<float4*>(hist + (size_t)(tf % rows) * RC + 4 * lane) = v;
-                        if (kfresh >= 0) *reinterpret_cast<float4*>(xu + kfresh * RC + 4 * lane) = v;
+                        *reinterpret_cast<float2*>(hist + (size_t)(tf % rows) * RC + 2 * lane) = make_float2(hv[0], hv[1]);
+                        if (kfresh >= 0) *reinterpret_cast<float2*>(xu + kfresh * RC + 2 * lane) = make_float2(hv[0], hv[1]);
                     }
                 }
             }
@@ -769,7 +788,7 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                     const int u = tid >> 6 >> 1, n4 = tid & 127;                // 128 threads x 4 outputs per utterance
                     const bool live = u0 + u < nb && n4 < GC / 4;
                     const int b = b0 + u0 + u;
-                    float* rec = p.pmail + pre_rec(p, b, l, tp);
+                    u64* rec = p.pmail + pre_rec(p, b, l, tp);
                     if (live) {
                         // the bias rows are the MODEL's gate rows (tanh rows [0, G/2), sigmoid rows [G/2, G)); this kernel's 256 outputs
                         // are tanh channels 0..127 then sigmoid channels 0..127, zero beyond G/2 (models narrower than 128 / 256 are padded)
@@ -784,19 +803,16 @@ __device__ void run_tap(const RingParams& p, int l, int part, float* smem) {
                             const float4 q = *reinterpret_cast<const float4*>(s.part + ((size_t)u * RW + w) * GC + 4 * n4);
                             v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
                         }
-                        if (n4 < GC / 4) bulk_store16(rec + 4 + 4 * n4, v);
+                        // pre_l[tp] of utterance b leaves as tagged granules (write-through: the stage may sit on any XCD): no drain
+                        const unsigned ptag = p.tag_base + (unsigned)tp + 1u;
+                        st_granule2(rec + 4 * n4, ptag, v.x, v.y, false);
+                        st_granule2(rec + 4 * n4 + 2, ptag, v.z, v.w, false);
                     }
                 }
                 __syncthreads();                                                 // s.part is free for the next four utterances
                 TAP_STAMP(min(3 + u0 / 4, 4));
             }
-            // every payload of the pass has been issued: ONE drain (the write-through stores' acknowledgements take ~1 us), then
-            // the tag granules of all utterances
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
             TAP_STAMP(5);
-            if (tid < nb)
-                st_granule(reinterpret_cast<u64*>(p.pmail + pre_rec(p, b0 + tid, l, tp)), p.tag_base + (unsigned)tp + 1u, 0.f, false);
 #undef TAP_STAMP
         }
     }
@@ -867,7 +883,7 @@ __device__ __forceinline__ void group_matvec8(const f2 (&w)[8][8], const float* 
 // (L0: the ring's head evaluates layer 0 -- run_head; ZMSG: this instantiation is stage 1 of such a ring.  Compile-time switches:
 //  the stage loop is codegen-sensitive, a run-time flag in it costs every stage 3 %.)
 template <int NK, bool L0, bool ZMSG>
-__device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
+__device__ __attribute__((always_inline)) void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
     constexpr int NLDS = lds_passes(NK);
     constexpr bool RP = NK <= 2;                // pipelined polls in the reserved registers (the K = 512 instantiation needs them itself)
     const StageLds s = carve_stage(smem);
@@ -945,9 +961,9 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
                 else return wave_recv2(g2, tag, v0, v1, p.status, code, lane, false, u4v{0, 0, 0, 0});
             };
             if (wave == 0) {
-                const float* rec = p.pmail + pre_rec(p, b, l, t);
-                if (!WNV_EXP_NOPRE && !bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
-                const float4 pv = bulk_load16(rec + 4 + 4 * lane);
+                float pvv[4] = {0.f, 0.f, 0.f, 0.f};                             // pre_l[t], outputs 4 lane .. 4 lane + 3
+                if (!WNV_EXP_NOPRE && !rec_recv<2>(p.pmail + pre_rec(p, b, l, t), tag, pvv, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                const float4 pv = make_float4(pvv[0], pvv[1], pvv[2], pvv[3]);
                 *reinterpret_cast<float4*>(s.pre + 4 * lane) = pv;
                 if constexpr (zmsg) {                                           // rows 4 lane .. 4 lane + 3 of N_1 h_0, plus pre_1: zin is complete;
                     if constexpr (RP) {                                         // the chain input u_0 comes with it
@@ -1105,15 +1121,11 @@ __device__ void run_stage(const RingParams& p, int ring, int sidx, float* smem) 
             __syncthreads();                        // fences the LDS vectors against the next step; makes flags[0] uniform
             if (s.flags[0]) return;                 // a bounded wait gave up somewhere: drain (status holds the code)
             if (wave == 0) {
-                // layer inputs to their tap workgroups (history ring, older taps of the next step): bulk records.  This stage knows
+                // layer inputs to their tap workgroups (history ring, older taps of the next step): records.  This stage knows
                 // h_{l-1}[t] (its N input); the last stage also forms h_l[t] of its own layer, which nobody else needs
                 auto file = [&](int layer, const float* vec) {
-                    float* rec = p.fmail + h_rec(p, b, layer, t);
-                    if (lane < RC / 4) {
-                        const float* src = vec + ES * (lane >> 2) + 4 * (lane & 3);  // channels 4 lane .. 4 lane + 3
-                        bulk_store16(rec + 4 + 4 * lane, *reinterpret_cast<const float4*>(src));
-                    }
-                    bulk_publish(reinterpret_cast<u64*>(rec), tag, lane);
+                    const float2 v = *reinterpret_cast<const float2*>(vec + eidx(2 * lane));     // channels 2 lane, 2 lane + 1
+                    st_granule2(p.fmail + h_rec(p, b, layer, t) + 2 * lane, tag, v.x, v.y, false);
                 };
                 if (!first_stage && !zmsg) file(l - 1, s.hb);                   // (zmsg: the head files h_0 itself)
                 if (last_stage) {
@@ -1193,7 +1205,7 @@ __device__ __forceinline__ bool rpoll_recv_zx(const u64* ga, const u64* gb, cons
 }
 
 template <bool ZMSG>
-__device__ void run_stage_split(const RingParams& p, int ring, int sidx, int half, float* smem) {
+__device__ __attribute__((always_inline)) void run_stage_split(const RingParams& p, int ring, int sidx, int half, float* smem) {
     const StageLds s = carve_stage(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = tid >> 8, gtid = tid & (GT - 1);
@@ -1253,9 +1265,9 @@ __device__ void run_stage_split(const RingParams& p, int ring, int sidx, int hal
                 return rpoll_recv2<false>(g2, tag, v0, v1, p.status, code, lane);
             };
             if (wave == 0) {
-                const float* rec = p.pmail + pre_rec(p, b, l, t);
-                if (!bulk_wait(reinterpret_cast<const u64*>(rec), tag, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
-                *reinterpret_cast<float4*>(s.pre + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
+                float pvv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (!rec_recv<2>(p.pmail + pre_rec(p, b, l, t), tag, pvv, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                *reinterpret_cast<float4*>(s.pre + 4 * lane) = make_float4(pvv[0], pvv[1], pvv[2], pvv[3]);
                 if constexpr (ZMSG) {                                           // lane L: rows 64 half + L (tanh) and 128 + 64 half + L (sigmoid)
                     float v[4] = {0.f, 0.f, 0.f, 0.f};
                     const u64* zt = p.zmail + (size_t)b * GC + 64 * half + lane;
@@ -1333,12 +1345,8 @@ __device__ void run_stage_split(const RingParams& p, int ring, int sidx, int hal
             if (s.flags[0]) return;
             if (wave == 0 && half == 0) {                                       // history of layer l - 1 (and of the last layer): half 0 files it
                 auto file = [&](int layer, const float* vec) {
-                    float* rec = p.fmail + h_rec(p, b, layer, t);
-                    if (lane < RC / 4) {
-                        const float* src = vec + ES * (lane >> 2) + 4 * (lane & 3);
-                        bulk_store16(rec + 4 + 4 * lane, *reinterpret_cast<const float4*>(src));
-                    }
-                    bulk_publish(reinterpret_cast<u64*>(rec), tag, lane);
+                    const float2 v = *reinterpret_cast<const float2*>(vec + eidx(2 * lane));     // channels 2 lane, 2 lane + 1
+                    st_granule2(p.fmail + h_rec(p, b, layer, t) + 2 * lane, tag, v.x, v.y, false);
                 };
                 if (!ZMSG) file(l - 1, s.hb);
                 if (last_stage) {
@@ -1480,7 +1488,7 @@ __device__ __forceinline__ void head_hidden(const HeadSlice<NK, NW2>& w, const f
 
 // head parts j > 0: hidden slice + partial outputs, sent to part 0
 template <int NK, int NW2>
-__device__ void run_head_part(const RingParams& p, int ring, int part, float* smem) {
+__device__ __attribute__((always_inline)) void run_head_part(const RingParams& p, int ring, int part, float* smem) {
     const HeadLds s = carve_head(smem, NK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int q = lane & 3, i = wave * 16 + (lane >> 2);
@@ -1546,7 +1554,7 @@ __device__ __forceinline__ bool head_collect(const RingParams& p, int b, unsigne
 }
 
 template <int NK, bool L0, bool SPLIT>
-__device__ void run_head(const RingParams& p, int ring, float* smem) {
+__device__ __attribute__((always_inline)) void run_head(const RingParams& p, int ring, float* smem) {
     WNV_TS_DECL;
     const HeadLds s = carve_head(smem, NK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1601,21 +1609,21 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
     // wave 2 fetches pre_0 of the step whose input is about to be made (tag tg) into LDS; a barrier follows at the call sites
     auto fetch_pre0 = [&](int b, unsigned tg) {
         if (l0 && wave == 2) {
-            const float* rec = p.pmail + pre_rec(p, b, 0, (int)(tg - p.tag_base - 1u));
-            if (!WNV_EXP_NOPRE && !bulk_wait(reinterpret_cast<const u64*>(rec), tg, p.status, 0x700u, lane)) s.flags[0] = 1;
-            *reinterpret_cast<float4*>(s.pre0 + 4 * lane) = bulk_load16(rec + 4 + 4 * lane);
+            float pvv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (!WNV_EXP_NOPRE && !rec_recv<2>(p.pmail + pre_rec(p, b, 0, (int)(tg - p.tag_base - 1u)), tg, pvv, p.status, 0x700u, lane)) s.flags[0] = 1;
+            *reinterpret_cast<float4*>(s.pre0 + 4 * lane) = make_float4(pvv[0], pvv[1], pvv[2], pvv[3]);
         }
     };
     // the input of step (tag tg, parity parn) from the sample xs (waves 0-1): u_0 first -- it is what the chain waits for
     // (pt, ps: c + pre_0 of the lane's two rows, read from LDS ahead of time; every address comes pinned in registers: between the
     //  sample and the sends there is no address arithmetic and no reload of a spilled kernel argument)
-    struct FeedAddr { u64 *x0, *x1, *z; float* f; u64 *q, *sk; };
+    struct FeedAddr { u64 *x0, *x1, *z, *f, *q, *sk; };
     auto feed_addr = [&](int b, int parn) {
         FeedAddr a;
         a.x0 = p.xmail + ((size_t)b * S1) * RC + tid;
         a.x1 = a.x0 + RC;
         a.z = p.zmail + (size_t)b * GC + tid;
-        a.f = p.fmail + h_rec(p, b, 0, parn) + 4 + tid;                 // (parn IS the parity of the step the input is made for)
+        a.f = p.fmail + h_rec(p, b, 0, parn) + tid;                     // (parn IS the parity of the step the input is made for)
         // (split rings: two partial vectors per slot; layer 0's terms are whole and go to half 0, half 1 of the residual slot gets zeros)
         a.q = p.hmail + ((((size_t)b * 2 + parn) * S1 + 1) * (SPLIT ? 2 : 1)) * RC + ch;
         a.sk = p.smail + (((size_t)b * S1 + 1) * (SPLIT ? 2 : 1)) * p.Kp + ch;
@@ -1637,7 +1645,7 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             WNV_TS(0);
             // h_0 for layer 0's tap workgroup (history, older taps of the next step): filed HERE, at the start of the step -- the
             // tap workgroups serve all rings in one pass, and the ring that runs ahead of the others waits for pre_0 first
-            if (l0) asm volatile("global_store_dword %0, %1, off sc1" :: "v"(ad.f), "v"(h0) : "memory");
+            if (l0) st_granule(ad.f, tg, h0, false);                            // (a tagged granule, written through: no drain, no flag)
         }
         if (l0) {                                                               // behind the sends: layer 0's residual and skip terms
             __syncthreads();
@@ -1652,9 +1660,6 @@ __device__ void run_head(const RingParams& p, int ring, float* smem) {
             const float m0 = dot16p(ws0[0], xu), m1 = dot16p(ws0[1], xu);
             const float m = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + bs0;
             if (writer) st_granule(ad.sk, tg, m, fast);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the h_0 payload of waves 0-1 has left the CU ...
-            __syncthreads();
-            if (tid == 0) st_granule(reinterpret_cast<u64*>(p.fmail + h_rec(p, b, 0, (int)(tg - p.tag_base - 1u))), tg, 0.f, false);   // ... publish the record
         }
     };
 
@@ -1781,7 +1786,7 @@ __device__ __forceinline__ CatLds carve_cat(float* smem, int NK) {
 __host__ __device__ constexpr size_t cat_lds_floats(int NK) { return (size_t)(4 * NK + 4) * QS + 3 * 256 + 4 * RC + 16 + (size_t)256 * RC; }
 
 template <int NK>
-__device__ void run_head_cat(const RingParams& p, int ring, float* smem) {
+__device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p, int ring, float* smem) {
     WNV_TS_DECL;
     const CatLds s = carve_cat(smem, NK);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1939,7 +1944,7 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
         }
     } else {
         if (pos == p.S) run_head<NK, L0, false>(p, ring, smem);
-        else run_head_part<NK, 1>(p, ring, pos - p.S, smem);
+        else if constexpr (NK > 1) run_head_part<NK, 1>(p, ring, pos - p.S, smem);     // (128 skip channels: the head is one workgroup)
     }
     }
 }
@@ -2438,14 +2443,14 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.zb_ld = (c.gate_channels + 3) & ~3; p.gh = c.gate_channels / 2;
     p.lay_dil = st->d_dil; p.lay_histoff = st->d_histoff;
     // state: [status 64 B][placement table 4 KiB][xmail B*(S+1)*128 u64][hmail B*2*(S+1)*128 u64][gmail, the same][smail B*(S+1)*Kp u64][omail B*NK*256 u64]
-    //        [hist B*hist_floats f32]
+    //        [zmail B*256 u64][fmail B*L*2*128 u64][pmail B*L*2*256 u64][hist B*hist_floats f32]
     const size_t head_bytes = 64 + 4096;                           // status word, placement table
     const size_t n_h = (size_t)B * (st->S + 1) * RC, n_s = (size_t)B * (st->S + 1) * st->Kp;
-    const size_t n_f = (size_t)B * st->L * 2 * (4 + RC), n_p = (size_t)B * st->L * 2 * (4 + GC);   // stage <-> tap-workgroup bulk records (floats)
+    const size_t n_f = (size_t)B * st->L * 2 * RC, n_p = (size_t)B * st->L * 2 * GC;   // stage <-> tap-workgroup records (granules), two slots by step parity
     const size_t n_o = (size_t)B * NK * p.Op;                      // partial head outputs of parts 1 .. NK-1
     const size_t n_z = (size_t)B * GC;                             // N_1 h_0 from the head (head_l0)
     const size_t qh = split ? 2 : 1;                               // split rings: two partial vectors per residual / skip slot
-    const size_t mail_bytes = (n_h + 2 * n_h * qh + 2 * n_h + n_s * qh + n_o + n_z) * sizeof(u64) + (n_f + n_p) * sizeof(float);
+    const size_t mail_bytes = (n_h + 2 * n_h * qh + 2 * n_h + n_s * qh + n_o + n_z + n_f + n_p) * sizeof(u64);
     const size_t hist_bytes = (size_t)B * st->hist_floats * sizeof(float);
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
@@ -2477,9 +2482,9 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.smail = p.gmail + 2 * n_h;
     p.omail = p.smail + n_s * qh;
     p.zmail = p.omail + n_o;
-    p.fmail = (float*)(p.zmail + n_z);
+    p.fmail = p.zmail + n_z;
     p.pmail = p.fmail + n_f;
-    p.hist = p.pmail + n_p;
+    p.hist = (float*)(p.pmail + n_p);
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.b0 = ga.b0; p.noise_B = ga.noise_B > 0 ? ga.noise_B : B;
     p.noise_ready = ga.noise_ready;
