@@ -117,8 +117,12 @@ __device__ __forceinline__ void st_granule(u64* p, unsigned tag, float v, bool f
 __device__ __forceinline__ void st_granule2(u64* p, unsigned tag, float v0, float v1, bool fast) {
     typedef unsigned u4s __attribute__((ext_vector_type(4)));
     const u4s x = {__float_as_uint(v0), tag, __float_as_uint(v1), tag};
-    if (fast) asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(p), "v"(x) : "memory");
-    else asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(x) : "memory");
+    // (s_nop 1: a VMEM store of more than 64 bits reads its data registers AFTER issue -- a VALU write to them needs wait states in
+    //  between, which the compiler's hazard recogniser inserts for stores it emits itself but cannot for one inside inline assembly.
+    //  Found in round 4: the tap workgroups' second record store had its address computed into the last two data registers of the
+    //  first -- lanes 12-15 of every 16 stored the POINTER where the tag belongs and the receiving stages waited for ever.)
+    if (fast) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(x) : "memory");
 }
 
 // RECORDS: the vectors nobody on the chain waits for -- stage -> tap workgroup h_l[t] (128 values), tap workgroup -> stage pre_l[t+1]
@@ -136,17 +140,31 @@ __device__ __forceinline__ u4v ld16_sc1(const u64* p) {
     asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(x) : "v"(p) : "memory");
     return x;
 }
-__device__ __forceinline__ void ld16x2_sc1(const u64* p, u4v& a, u4v& b) {                  // granules p[0..1] and p[2..3]: one round trip
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+__device__ __forceinline__ void ld16x2_sc1(const u64* p, const u64* q, u4v& a, u4v& b) {   // granules p[0..1] and q[0..1]: one round trip
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b) : "v"(p), "v"(q) : "memory");
 }
+// layout of a 256-value record (WNV_REC_SPLIT, default): lane L keeps values 4L, 4L + 1 in granules 2L, 2L + 1 and values 4L + 2, 4L + 3 in
+// granules 128 + 2L, 128 + 2L + 1 -- writer and reader both touch whole 128-byte lines per instruction
+#ifndef WNV_REC_SPLIT
+#define WNV_REC_SPLIT 1
+#endif
+__device__ __forceinline__ int rec4_a(int lane) { return WNV_REC_SPLIT ? 2 * lane : 4 * lane; }
+__device__ __forceinline__ int rec4_b(int lane) { return WNV_REC_SPLIT ? 128 + 2 * lane : 4 * lane + 2; }
 // one wave receives a record of 128 NG values: lane holds granules 2 NG lane .. 2 NG lane + 2 NG - 1; returns false on abort / timeout
+#ifdef WNV_DBG_MARK
+#define WNV_MARK(m, x) do { if ((m) && lane == 0) __hip_atomic_store((m), (unsigned)(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#else
+#define WNV_MARK(m, x) ((void)0)
+#endif
 template <int NG>
-__device__ __forceinline__ bool rec_recv(const u64* rec, unsigned tag, float (&v)[2 * NG], unsigned int* status, unsigned code, int lane) {
+__device__ __forceinline__ bool rec_recv(const u64* rec, unsigned tag, float (&v)[2 * NG], unsigned int* status, unsigned code, int lane, unsigned* mark = nullptr) {
     static_assert(NG == 1 || NG == 2, "");
     unsigned spins = 0;
+    WNV_MARK(mark, 0x10000u | (tag & 0xffffu));
     for (;;) {
         const u4v x = ld16_sc1(rec);                               // every lane the same 16 bytes: one request
+        if (mark) WNV_MARK(mark + 256, x.y);
         if (x.y == tag) break;
         if ((++spins & 63u) == 0u) {
             if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
@@ -155,6 +173,7 @@ __device__ __forceinline__ bool rec_recv(const u64* rec, unsigned tag, float (&v
         __builtin_amdgcn_s_sleep(8);
     }
     spins = 0;
+    WNV_MARK(mark, 0x20000u | (tag & 0xffffu));
     for (;;) {
         bool ok;
         if constexpr (NG == 1) {
@@ -163,11 +182,19 @@ __device__ __forceinline__ bool rec_recv(const u64* rec, unsigned tag, float (&v
             ok = x.y == tag && x.w == tag;
         } else {
             u4v x, y;
-            ld16x2_sc1(rec + 4 * lane, x, y);
+            ld16x2_sc1(rec + rec4_a(lane), rec + rec4_b(lane), x, y);
             v[0] = __uint_as_float(x.x); v[1] = __uint_as_float(x.z); v[2] = __uint_as_float(y.x); v[3] = __uint_as_float(y.z);
             ok = x.y == tag && x.w == tag && y.y == tag && y.w == tag;
+#ifdef WNV_DBG_MARK
+            if (mark && blockIdx.x == 16) {
+                __hip_atomic_store(mark - blockIdx.x + 512 + lane, (x.y & 0xffu) | ((x.w & 0xffu) << 8) | ((y.y & 0xffu) << 16) | ((y.w & 0xffu) << 24), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mark - blockIdx.x + 576 + lane, (unsigned)(size_t)(rec + rec4_a(lane)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mark - blockIdx.x + 640 + lane, x.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(mark - blockIdx.x + 576 + lane, x.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#endif
         }
-        if (__all(ok)) return true;
+        if (__all(ok)) { WNV_MARK(mark, 0x30000u | (tag & 0xffffu)); return true; }
         if ((++spins & 255u) == 0u) {
             if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
             if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(status, 0u, code); return false; }
@@ -805,8 +832,8 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
                         }
                         // pre_l[tp] of utterance b leaves as tagged granules (write-through: the stage may sit on any XCD): no drain
                         const unsigned ptag = p.tag_base + (unsigned)tp + 1u;
-                        st_granule2(rec + 4 * n4, ptag, v.x, v.y, false);
-                        st_granule2(rec + 4 * n4 + 2, ptag, v.z, v.w, false);
+                        st_granule2(rec + rec4_a(n4), ptag, v.x, v.y, false);
+                        st_granule2(rec + rec4_b(n4), ptag, v.z, v.w, false);
                     }
                 }
                 __syncthreads();                                                 // s.part is free for the next four utterances
@@ -962,7 +989,7 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
             };
             if (wave == 0) {
                 float pvv[4] = {0.f, 0.f, 0.f, 0.f};                             // pre_l[t], outputs 4 lane .. 4 lane + 3
-                if (!WNV_EXP_NOPRE && !rec_recv<2>(p.pmail + pre_rec(p, b, l, t), tag, pvv, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
+                if (!WNV_EXP_NOPRE && !rec_recv<2>(p.pmail + pre_rec(p, b, l, t), tag, pvv, p.status, 0x700u + (unsigned)sidx, lane, p.xcc + 256 + blockIdx.x)) s.flags[0] = 1;
                 const float4 pv = make_float4(pvv[0], pvv[1], pvv[2], pvv[3]);
                 *reinterpret_cast<float4*>(s.pre + 4 * lane) = pv;
                 if constexpr (zmsg) {                                           // rows 4 lane .. 4 lane + 3 of N_1 h_0, plus pre_1: zin is complete;
@@ -1610,7 +1637,7 @@ __device__ __attribute__((always_inline)) void run_head(const RingParams& p, int
     auto fetch_pre0 = [&](int b, unsigned tg) {
         if (l0 && wave == 2) {
             float pvv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (!WNV_EXP_NOPRE && !rec_recv<2>(p.pmail + pre_rec(p, b, 0, (int)(tg - p.tag_base - 1u)), tg, pvv, p.status, 0x700u, lane)) s.flags[0] = 1;
+            if (!WNV_EXP_NOPRE && !rec_recv<2>(p.pmail + pre_rec(p, b, 0, (int)(tg - p.tag_base - 1u)), tg, pvv, p.status, 0x700u, lane, p.xcc + 256 + blockIdx.x)) s.flags[0] = 1;
             *reinterpret_cast<float4*>(s.pre0 + 4 * lane) = make_float4(pvv[0], pvv[1], pvv[2], pvv[3]);
         }
     };
@@ -2596,6 +2623,33 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         }
     }
     if (status != 0) {
+        if (getenv("WNV_RING_DEBUG_DUMP")) {                        // (failure path only) where did the records of utterance 0 get to?
+            std::vector<u64> f(n_f / B), q(n_p / B);
+            (void)hipMemcpy(f.data(), p.fmail, f.size() * sizeof(u64), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(q.data(), p.pmail, q.size() * sizeof(u64), hipMemcpyDeviceToHost);
+#ifdef WNV_DBG_MARK
+            {
+                std::vector<unsigned> mk(1024);
+                (void)hipMemcpy(mk.data(), p.xcc, 4096, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[wnv dump] tag_base %u; pre-receive marks by block (phase << 16 | tag; last first-granule tag seen):", p.tag_base);
+                for (int k = 0; k < 256; ++k) if (mk[256 + k]) fprintf(stderr, " %d:%x/%x", k, mk[256 + k], mk[512 + k]);
+                fprintf(stderr, "\n[wnv dump] block 16, per lane: tags seen | addr a | addr b (pmail = %llx):", (unsigned long long)p.pmail);
+                for (int k = 0; k < 64; ++k) fprintf(stderr, " %d:%08x|%x|%x", k, mk[768 + k], mk[832 + k], mk[896 + k]);
+                fprintf(stderr, "\n");
+            }
+#endif
+            for (int l = 0; l < st->L; ++l)
+                for (int par = 0; par < 2; ++par) {
+                    fprintf(stderr, "[wnv dump] layer %2d slot %d  h tags (step + 1):", l, par);
+                    for (int k : {0, 1, 2, 63, 64, 127}) fprintf(stderr, " %lld", (long long)(f[((size_t)l * 2 + par) * RC + k] >> 32) - (long long)p.tag_base);
+                    fprintf(stderr, "   pre tags:");
+                    for (int k : {0, 1, 2, 3, 4, 127, 128, 254, 255}) fprintf(stderr, " %lld", (long long)(q[((size_t)l * 2 + par) * GC + k] >> 32) - (long long)p.tag_base);
+                    fprintf(stderr, "\n");
+                }
+            fprintf(stderr, "[wnv dump] layer 2 slot 0, pre granules 22..33 as raw u64:");
+            for (int k = 22; k < 34; ++k) fprintf(stderr, " %d:%016llx", k, q[((size_t)2 * 2 + 0) * GC + k]);
+            fprintf(stderr, "\n");
+        }
         char buf[128];
         snprintf(buf, sizeof buf, "ring kernel gave up waiting (code 0x%x: 0x1ss = activation into stage ss, 0x2ss = skip into stage ss, 0x300 = head)", status);
         err = buf;
