@@ -144,14 +144,9 @@ __device__ __forceinline__ void ld16x2_sc1(const u64* p, const u64* q, u4v& a, u
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b) : "v"(p), "v"(q) : "memory");
 }
-// layout of a 256-value record (WNV_REC_SPLIT, default): lane L keeps values 4L, 4L + 1 in granules 2L, 2L + 1 and values 4L + 2, 4L + 3 in
-// granules 128 + 2L, 128 + 2L + 1 -- writer and reader both touch whole 128-byte lines per instruction
-#ifndef WNV_REC_SPLIT
-#define WNV_REC_SPLIT 1
-#endif
-__device__ __forceinline__ int rec4_a(int lane) { return WNV_REC_SPLIT ? 2 * lane : 4 * lane; }
-__device__ __forceinline__ int rec4_b(int lane) { return WNV_REC_SPLIT ? 128 + 2 * lane : 4 * lane + 2; }
-// one wave receives a record of 128 NG values: lane holds granules 2 NG lane .. 2 NG lane + 2 NG - 1; returns false on abort / timeout
+// a 256-value record: granule n = value n; the receiving lane L takes granules 4L .. 4L + 3 in two 16-byte loads
+__device__ __forceinline__ int rec4_a(int lane) { return 4 * lane; }
+__device__ __forceinline__ int rec4_b(int lane) { return 4 * lane + 2; }
 #ifdef WNV_DBG_MARK
 #define WNV_MARK(m, x) do { if ((m) && lane == 0) __hip_atomic_store((m), (unsigned)(x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
@@ -496,6 +491,9 @@ template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 __device__ __forceinline__ float quad_allreduce(float v) { return dpp_add<0x4E>(dpp_add<0xB1>(v)); }   // [1,0,3,2] then [2,3,0,1]
+template <int CTRL> __device__ __forceinline__ float dpp_fold(float keep, float send) {
+    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, true));
+}
 
 // tanh(a) * sigmoid(g) with the hardware exp2 / rcp (absolute error ~1e-7; the generic kernel keeps libm's
 // tanhf/expf and is the cross-check):  tanh(a) = sign(a) (1 - e)/(1 + e), e = exp(-2|a|);  sigmoid(g) = 1/(1 + exp(-g))
@@ -633,21 +631,19 @@ constexpr int KR_MAX = 32;         // K rows per wave held in VGPRs (32 float4 =
 constexpr int KL_MAX = 16;         // further K rows per wave held in LDS
 constexpr int TB = 8;              // utterances per pass (one polling wave each; their latencies overlap)
 struct TapLds {
-    float* xin;      // [TB][8 * kper] mat-vec inputs: tap rows then conditioning row, zero padded
-    float* part;     // [4][8][256] per-wave partial sums of four utterances
+    float* xin;      // [2][TB][8 * kper] mat-vec inputs (two buffers: the next pass's gather lands in the other one): tap rows then conditioning row, zero padded
     int* flags;
     float4* wl;      // [8 waves][klds_rows][64 lanes] LDS-resident rows
 };
 __device__ __forceinline__ TapLds carve_tap(float* smem, const RingParams& p) {
     TapLds s;
     s.xin = smem;
-    s.part = smem + (size_t)TB * RW * p.kper;
-    s.flags = reinterpret_cast<int*>(s.part + (size_t)4 * RW * GC);
+    s.flags = reinterpret_cast<int*>(smem + (size_t)2 * TB * RW * p.kper);
     s.wl = reinterpret_cast<float4*>(s.flags + 16);
     return s;
 }
 __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
-    return (size_t)TB * RW * kper + (size_t)4 * RW * GC + 16 + (size_t)RW * klds_rows * 64 * 4;
+    return (size_t)2 * TB * RW * kper + 16 + (size_t)RW * klds_rows * 64 * 4;
 }
 
 // EXPERIMENT BUILDS ONLY (-DWNV_EXP_NOPRE=1|2; results are WRONG on purpose, timing only): 1 = stages and head do not wait for the tap
@@ -656,6 +652,9 @@ __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
 #ifndef WNV_EXP_NOPRE
 #define WNV_EXP_NOPRE 0
 #endif
+// (SPEC: the speculative look at the next pass's h record -- four registers live across the mat-vec, one more than the capped NK = 2
+//  instantiation has next to its 128 weight registers)
+template <bool SPEC>
 __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int l, int part, float* smem) {
     if (WNV_EXP_NOPRE >= 2) return;
     const TapLds s = carve_tap(smem, p);
@@ -664,184 +663,231 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
     const int rows = (p.kw - 1) * d;
     const int hoff = (p.kw - 1) * RC;
     const int kx = RW * p.kper;                                    // padded K
-    const int k0 = wave * p.kper;                                  // this wave's K rows: [k0, k0 + kper) of the padded matrix
+    // MAT-VEC MAPPING (round 4): the eight WAVES split the 256 outputs (wave w: outputs [32 w, 32 w + 32)), the eight lanes ks = lane & 7 of
+    // a lane group og = lane >> 3 split K (slice ks: rows [ks kper, ks kper + kper)) for the four outputs 32 w + 4 og .. + 3: the K slices meet
+    // in three DPP steps inside the wave and every lane publishes from its registers.  (Until round 4 the WAVES split K: partial sums of four
+    // utterances through 32 KB of LDS, a barrier, a reduce that waited for its bias loads, another barrier -- 3.1-3.8 us per round of four
+    // utterances for 1.1 us of FMAs, profiles/r04_tap_pass_timeline.txt; the passes of the tap workgroups are what bounds the throughput
+    // beyond 32 utterances per GPU.)
+    const int ks = lane & 7, og = lane >> 3;
+    const int ob = 32 * wave + 4 * og;                             // this lane's four outputs
+    const int k0 = ks * p.kper;                                    // this lane's K rows: [k0, k0 + kper) of the padded matrix
     const float* Wt = p.wpre + (size_t)l * p.kpre * GC;           // K-major [kpre][256]
-    // resident rows: lane owns outputs 4 lane .. 4 lane + 3 of every row
-    float4 wreg[KR_MAX];
+    // REDUCE-SCATTER WITHOUT SELECTS (as group_matvec8): after the FMAs a lane holds 16 partial sums -- 4 utterances x 4 outputs -- and
+    // lane ks is to end up with outputs ob + 2 (ks & 1), + 1 of utterance ks >> 1.  Which utterance an accumulator GROUP g means and which
+    // output pair comes first depend on the lane, so that every step adds the partner's "sent" registers to the own "kept" ones:
+    //   step 1, row_half_mirror (ks <-> 7 - ks; the partner has the other parity, so pairs cross): groups 2, 3 are sent, 0, 1 kept;  step 2, ks <-> ks ^ 2: group 1 sent, 0 kept;
+    //   step 3, ks <-> ks ^ 1: pair 1 sent, pair 0 kept.                                             14 DPP adds instead of 48.
+    // Group g of lane ks = utterance ug[g]:  ug[0] = ks >> 1, ug[1] = (ks >> 1) ^ 1, ug[2], ug[3] = what lane 7 - ks keeps in groups 0, 1;
+    // odd lanes hold their weights as (outputs 2, 3, 0, 1).
+    const bool odd = (ks & 1) != 0;
+    auto wload = [&](int k) {
+        if (k >= p.kpre) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 w = *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + ob);
+        return odd ? make_float4(w.z, w.w, w.x, w.y) : w;
+    };
+    float4 wreg[KR_MAX];                                            // resident rows (registers), then LDS rows, then whatever streams
 #pragma unroll
-    for (int r = 0; r < KR_MAX; ++r) {
-        const int k = k0 + r;
-        wreg[r] = (r < p.kreg_rows && k < p.kpre) ? *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + lane * 4)
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (int r = 0; r < p.klds_rows; ++r) {
-        const int k = k0 + p.kreg_rows + r;
-        s.wl[((size_t)wave * p.klds_rows + r) * 64 + lane] =
-            k < p.kpre ? *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + lane * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (int i = tid; i < TB * kx; i += RT) s.xin[i] = 0.f;
+    for (int r = 0; r < KR_MAX; ++r) wreg[r] = r < p.kreg_rows ? wload(k0 + r) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < p.klds_rows; ++r) s.wl[((size_t)wave * p.klds_rows + r) * 64 + lane] = wload(k0 + p.kreg_rows + r);
+    const int uq = ks >> 1, uqm = 3 - uq;                            // (7 - ks) >> 1 = 3 - (ks >> 1)
+    const int ug[4] = {uq, uq ^ 1, uqm, uqm ^ 1};
+    const int xo0 = ug[0] * kx + k0, xo1 = ug[1] * kx + k0, xo2 = ug[2] * kx + k0, xo3 = ug[3] * kx + k0;   // input of group g: xin[...][ug[g]][k0 ..]
+    // what a lane publishes: after the all-reduce over ks every lane of a group holds all 16 sums (4 utterances x 4 outputs); lane ks sends
+    // outputs ob + 2 (ks & 1), + 1 of utterance ks >> 1 of the round -- with their addends: c_l (a constant of the lane) and the effective
+    // conv bias (per utterance when the model has a speaker embedding).  The bias rows are the MODEL's gate rows (tanh rows [0, G/2),
+    // sigmoid rows [G/2, G)); this kernel's 256 outputs are tanh channels 0..127 then sigmoid channels 0..127, zero beyond G/2
+    const int pu = uq, po = ob + 2 * (ks & 1);                     // utterance of the round, first of the two outputs
+    const int zhalf = po >> 7, zch = po & 127;
+    const float2 cvl = *reinterpret_cast<const float2*>(p.cvec + (size_t)l * GC + po);
+    const float* zbase = p.zbias + (size_t)l * p.zb_ld + (size_t)zhalf * p.gh + zch;
+    const bool z0 = zch < p.gh, z1 = zch + 1 < p.gh;
+    for (int i = tid; i < 2 * TB * kx; i += RT) s.xin[i] = 0.f;
     if (tid == 0) s.flags[0] = 0;
     __syncthreads();
     const int kres = p.kreg_rows + p.klds_rows;                    // rows of this wave that never touch memory again
 
-    for (int t = -1; t + 1 < p.T; ++t) {                           // consumes h_l[t] (t >= 0), produces pre_l[t + 1]
+    // A layer with dilation >= 2 needs NOTHING of this step's h for pre[t + 1] (its taps are h[t+1-d], h[t+1-2d], ...): its pass does not
+    // wait for h[t] -- the row is waited for and filed by the NEXT pass of the utterance (tf = t - 1), a whole step later --, so the rings
+    // never wait for this layer's taps (pre_rec: why the records come in two slots).  With d = 2 the youngest tap of step t + 1 is h[t-1],
+    // the row that pass files: taken from the record, as a dilation-1 layer takes h[t].
+    const bool early = d >= 2 && rows > 0;
+    const int ntap4 = hoff / 4, ncin4 = (p.cin & 3) == 0 ? p.cin / 4 : 0;      // float4s of a mat-vec input: tap rows, conditioning row
+    constexpr int GQ = 2;                                          // ... per lane ((kw - 1) 128 + cin <= 512 floats: why_not)
+    const int pstride = p.tap_parts * p.tb;                        // this workgroup's passes of a step: utterances [b0, b0 + tb), b0 += pstride
+    const int bfirst = part * p.tb;
+    if (bfirst >= p.B) return;
+    auto fresh_tap = [&](int tf_) { return ((d == 1 || early) && d <= 2 && tf_ >= 0 && rows > 0) ? p.kw - 2 : -1; };   // the tap that is h[tf] itself
+
+    // ---- SOFTWARE PIPELINE (round 4).  A pass = [B] finish the inputs (wave w = utterance b0 + w: gathered rows -> LDS, h_l[tf] from its
+    //      record -> history ring and LDS), barrier, [C] ISSUE the next pass's gather, [D] mat-vec + reduce + publish.  The gather -- the
+    //      kw-1 older taps (one contiguous 512-byte history row each; zeros before t = 0: the rings start zeroed) and c[t + 1], 16-byte
+    //      loads, two per lane -- is ~1.5 us of global-load latency; issued at [C] it lands under the mat-vec of the pass before (until
+    //      round 4 it was paid in front of every pass: beyond 32 utterances per GPU the passes of the tap workgroups bound the
+    //      throughput, profiles/r04_tap_bound_experiment.txt).  The next pass's h record is looked at speculatively in the same
+    //      breath (two granules per lane): when the utterance's stage has filed it already -- the rule in that regime -- [B] takes it
+    //      without a poll round trip.  What the next pass gathers was filed by THIS wave at the latest in [B] of this pass (a
+    //      dilation-1 layer: h[t], one step back; in order in this CU's L1); the row the next pass files itself is never gathered.
+    // The gathered rows go global -> LDS by DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land at base + 16 lane; no staging
+    // registers -- next to 128 weight registers there are none to spare: the register-staged form spilled 27) into the OTHER input
+    // buffer; the issuing wave waits for its own DMAs (vmcnt) in [B] of the pass that uses them, in front of the barrier.
+    u64 hx0 = 0, hx1 = 0;
+    auto gather_issue = [&](int t_, int b, float* xu) {
+        const int tp_ = t_ + 1, tf_ = early ? t_ - 1 : t_, kf = fresh_tap(tf_);
+        const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
+        const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            const int i = 64 * q + lane;
+            const float* src = nullptr;
+            if (i < ntap4) {
+                const int k = i >> 5, r4 = i & 31;                   // RC / 4 = 32 float4s per row
+                if (k != kf) src = hb + (size_t)((tp_ + k * d) % rows) * RC + 4 * r4;
+            } else if (i < ntap4 + ncin4) {
+                src = cb + 4 * (i - ntap4);
+            }
+            const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)(xu + 256 * q));
+            if (src) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds) : "memory");
+        }
+        hx0 = hx1 = 0;
+        if (SPEC && tf_ >= 0) {                                     // speculative look at the record (L1-bypassing, not waited for here)
+            const u64* rec = p.fmail + h_rec(p, b, l, tf_) + 2 * lane;
+            hx0 = ld_granule(rec); hx1 = ld_granule(rec + 1);
+        }
+    };
+
+    int t = -1, b0 = bfirst, cur = 0;                              // pass (t, b0) consumes h_l[tf], produces pre_l[t + 1]; its inputs: buffer cur
+    if (wave < min(p.tb, p.B - b0)) gather_issue(t, b0 + wave, s.xin + (size_t)wave * kx);
+    for (;;) {
         const int tp = t + 1;
-        for (int b0 = part * p.tb; b0 < p.B; b0 += p.tap_parts * p.tb) {
-            const int nb = min(p.tb, p.B - b0);
+        const int nb = min(p.tb, p.B - b0);
+        const int tf = early ? t - 1 : t;                           // the step whose h this pass waits for and files
+        const int kfresh = fresh_tap(tf);
 #ifdef WNV_FINE_TRACE
-#define TAP_STAMP(k) do { if (p.trace_tap && l == 0 && part == 0 && b0 == 0 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
-                              p.trace_tap[(size_t)(t - p.trace_t0) * TRW + (k)] = wall_clock64(); } while (0)
+#define TAP_STAMP(k) do { const int pk_ = (b0 - bfirst) / pstride; \
+                          if (p.trace_tap && l == 6 && part == 0 && pk_ < 3 && (k) < 5 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
+                              p.trace_tap[(size_t)(t - p.trace_t0) * TRW + 5 * pk_ + (k)] = wall_clock64(); } while (0)
 #else
 #define TAP_STAMP(k) ((void)0)
 #endif
-            TAP_STAMP(0);
-            // A layer with dilation >= 2 needs NOTHING of this step's h for pre[t + 1] (its taps are h[t+1-d], h[t+1-2d], ...): its pass
-            // does not wait for h[t] -- the row is waited for and filed by the NEXT pass (tf = t - 1), a whole step later --, so the rings
-            // never wait for this layer's taps (pre_rec: why the records come in two slots).  With d = 2 the youngest tap of step t + 1 is
-            // h[t-1], the row this pass files: taken from the record, as a dilation-1 layer takes h[t].
-            const bool early = d >= 2 && rows > 0;
-            const int tf = early ? t - 1 : t;                                   // the step whose h this pass waits for and files
-            // ---- wave w takes utterance b0 + w.  FIRST the loads that do not depend on this step's h: the kw-1 older taps of step tp
-            //      (zeros before t = 0: the rings start zeroed) and c[tp] -- a tap is one contiguous 512-B history row, the conditioning
-            //      row 4 cin bytes: 16-byte loads, all of a lane's loads in flight together (two per lane for kw = 3, cin = 80).  THEN
-            //      h_l[t], forwarded by the utterance's stage (two granules per lane, one 16-B load), which is filed in the history
-            //      ring.  (Until the end of round 3 the gather came behind the filing and a barrier: its global-load latency, ~1.4 us of
-            //      an ~8-us pass, was paid after the wait for h instead of under it; the passes of the tap workgroups are what bounds
-            //      the throughput beyond 16 utterances.)  Only a layer with dilation 1 reads the row that is being filed -- tap kw-2 of
-            //      step t + 1 IS h[t] -- and takes it from the record instead. ------------------------------------------------------
-            if (wave < nb) {
-                const int b = b0 + wave;
-                const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
+        TAP_STAMP(0);
+        // ---- [B] wave w finishes the mat-vec input of utterance b0 + w ------------------------------------------------------------
+        if (wave < nb) {
+            const int b = b0 + wave;
+            float* xu = s.xin + ((size_t)cur * TB + wave) * kx;
+            if (ncin4 == 0) {                                        // cin not a multiple of 4: scalar conditioning row
                 const float* cb = p.c_up + ((size_t)b * p.T + tp) * p.cin;
-                float* xu = s.xin + (size_t)wave * kx;
-                const int ntap4 = hoff / 4, ncin4 = (p.cin & 3) == 0 ? p.cin / 4 : 0;
-                const int kfresh = ((d == 1 || (d == 2 && early)) && tf >= 0 && rows > 0) ? p.kw - 2 : -1;   // the tap that is h[tf] itself
-                constexpr int GQ = 2;                                            // float4s per lane in flight (kw = 3, cin = 80: 84 float4s per utterance)
-                for (int i0 = 0; i0 < ntap4 + ncin4; i0 += 64 * GQ) {
-                    float4 v[GQ];
-#pragma unroll
-                    for (int q = 0; q < GQ; ++q) {
-                        const int i = i0 + 64 * q + lane;
-                        v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-                        if (i < ntap4) {
-                            const int k = i >> 5, r4 = i & 31;                   // RC / 4 = 32 float4s per row
-                            if (k != kfresh) v[q] = *reinterpret_cast<const float4*>(hb + (size_t)((tp + k * d) % rows) * RC + 4 * r4);
-                        } else if (i < ntap4 + ncin4) {
-                            v[q] = *reinterpret_cast<const float4*>(cb + 4 * (i - ntap4));
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < GQ; ++q) {
-                        const int i = i0 + 64 * q + lane;
-                        if (i < ntap4 + ncin4 && (i >= ntap4 || (i >> 5) != kfresh)) *reinterpret_cast<float4*>(xu + 4 * i) = v[q];
-                    }
+                for (int e = lane; e < p.cin; e += 64) xu[hoff + e] = cb[e];
+            }
+            TAP_STAMP(1);
+            if (tf >= 0) {
+                const unsigned htag = p.tag_base + (unsigned)tf + 1u;
+                float hv[2] = {__uint_as_float((unsigned)hx0), __uint_as_float((unsigned)hx1)};         // channels 2 lane, 2 lane + 1
+                if (!__all((unsigned)(hx0 >> 32) == htag && (unsigned)(hx1 >> 32) == htag)) {
+                    if (!rec_recv<1>(p.fmail + h_rec(p, b, l, tf), htag, hv, p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
                 }
-                if (ncin4 == 0)                                                  // cin not a multiple of 4: scalar conditioning row
-                    for (int e = lane; e < p.cin; e += 64) xu[hoff + e] = cb[e];
-                TAP_STAMP(1);
-                if (tf >= 0) {
-                    float hv[2];                                                  // channels 2 lane, 2 lane + 1
-                    if (!rec_recv<1>(p.fmail + h_rec(p, b, l, tf), p.tag_base + (unsigned)tf + 1u, hv, p.status, 0x600u + (unsigned)l, lane))
-                        s.flags[0] = 1;
-                    if (rows > 0) {
-                        float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
-                        *reinterpret_cast<float2*>(hist + (size_t)(tf % rows) * RC + 2 * lane) = make_float2(hv[0], hv[1]);
-                        if (kfresh >= 0) *reinterpret_cast<float2*>(xu + kfresh * RC + 2 * lane) = make_float2(hv[0], hv[1]);
-                    }
+                if (rows > 0) {
+                    float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
+                    *reinterpret_cast<float2*>(hist + (size_t)(tf % rows) * RC + 2 * lane) = make_float2(hv[0], hv[1]);
+                    if (kfresh >= 0) *reinterpret_cast<float2*>(xu + kfresh * RC + 2 * lane) = make_float2(hv[0], hv[1]);
                 }
             }
-            __syncthreads();
-            if (s.flags[0]) return;
-            TAP_STAMP(2);
-            // ---- mat-vec for all utterances of the pass, four at a time (accumulators + weights must fit the register file):
-            //      VGPR rows, then LDS rows, then whatever streams -----------------------------------------------------------
-#pragma unroll 1
-            for (int u0 = 0; u0 < nb; u0 += 4) {
-                // packed FMAs (v_pk_fma_f32: two outputs per instruction, the input broadcast into both halves): this loop is what a
-                // pass costs -- 336 rows x 256 outputs x 8 utterances = 688 k MACs per workgroup -- and the pass time of the tap
-                // workgroups is what bounds the throughput mode (B >= 32: two passes per part and step)
-                f2 acc[4][2];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[u][0] = acc[u][1] = f2{0.f, 0.f};
-                const float* xb = s.xin + (size_t)u0 * kx + k0;
-#pragma unroll
-                for (int r4 = 0; r4 < KR_MAX / 4; ++r4) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)u * kx + 4 * r4);
-                        const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float4 w = wreg[4 * r4 + e];
-                            const f2 xx = f2{xs[e], xs[e]};
-                            acc[u][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[u][0]);
-                            acc[u][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[u][1]);
-                        }
-                    }
-                }
-                for (int r = 0; r < p.klds_rows; r += 4) {                     // klds_rows is a multiple of 4: one 16-byte x read per utterance
-                    float4 w[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = s.wl[((size_t)wave * p.klds_rows + r + e) * 64 + lane];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float4 x = *reinterpret_cast<const float4*>(xb + (size_t)u * kx + p.kreg_rows + r);
-                        const float xs[4] = {x.x, x.y, x.z, x.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const f2 xx = f2{xs[e], xs[e]};
-                            acc[u][0] = __builtin_elementwise_fma(f2{w[e].x, w[e].y}, xx, acc[u][0]);
-                            acc[u][1] = __builtin_elementwise_fma(f2{w[e].z, w[e].w}, xx, acc[u][1]);
-                        }
-                    }
-                }
-                for (int k = k0 + kres; k < k0 + p.kper && k < p.kpre; ++k) {
-                    const float4 w = *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + lane * 4);
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float xs = xb[(size_t)u * kx + k - k0];
-                        const f2 xx = f2{xs, xs};
-                        acc[u][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[u][0]);
-                        acc[u][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[u][1]);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    *reinterpret_cast<float4*>(s.part + ((size_t)u * RW + wave) * GC + lane * 4) = make_float4(acc[u][0].x, acc[u][0].y, acc[u][1].x, acc[u][1].y);
-                __syncthreads();
-                // reduce over the waves and hand pre_l[tp] to the stages: thread (u, n4) finishes four adjacent outputs of
-                // utterance u0 + u -- waves 0-1 serve u = 0, waves 2-3 u = 1, ... -- and the first wave of each pair publishes
-                {
-                    const int u = tid >> 6 >> 1, n4 = tid & 127;                // 128 threads x 4 outputs per utterance
-                    const bool live = u0 + u < nb && n4 < GC / 4;
-                    const int b = b0 + u0 + u;
-                    u64* rec = p.pmail + pre_rec(p, b, l, tp);
-                    if (live) {
-                        // the bias rows are the MODEL's gate rows (tanh rows [0, G/2), sigmoid rows [G/2, G)); this kernel's 256 outputs
-                        // are tanh channels 0..127 then sigmoid channels 0..127, zero beyond G/2 (models narrower than 128 / 256 are padded)
-                        const int zhalf = (4 * n4) >> 7, zch = (4 * n4) & 127;
-                        const float* zrow = p.zbias + (size_t)b * p.zbias_bstride + (size_t)l * p.zb_ld + (size_t)zhalf * p.gh + zch;
-                        const float4 zb = make_float4(zch < p.gh ? zrow[0] : 0.f, zch + 1 < p.gh ? zrow[1] : 0.f, zch + 2 < p.gh ? zrow[2] : 0.f,
-                                                      zch + 3 < p.gh ? zrow[3] : 0.f);
-                        const float4 cv = *reinterpret_cast<const float4*>(p.cvec + (size_t)l * GC + 4 * n4);
-                        float4 v = make_float4(zb.x + cv.x, zb.y + cv.y, zb.z + cv.z, zb.w + cv.w);
-#pragma unroll
-                        for (int w = 0; w < RW; ++w) {
-                            const float4 q = *reinterpret_cast<const float4*>(s.part + ((size_t)u * RW + w) * GC + 4 * n4);
-                            v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
-                        }
-                        // pre_l[tp] of utterance b leaves as tagged granules (write-through: the stage may sit on any XCD): no drain
-                        const unsigned ptag = p.tag_base + (unsigned)tp + 1u;
-                        st_granule2(rec + rec4_a(n4), ptag, v.x, v.y, false);
-                        st_granule2(rec + rec4_b(n4), ptag, v.z, v.w, false);
-                    }
-                }
-                __syncthreads();                                                 // s.part is free for the next four utterances
-                TAP_STAMP(min(3 + u0 / 4, 4));
-            }
-            TAP_STAMP(5);
-#undef TAP_STAMP
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs into buffer cur (issued a pass ago) have landed
         }
+        __syncthreads();
+        if (s.flags[0]) return;
+        TAP_STAMP(2);
+        // ---- [C] the next pass of this workgroup: its gather is issued now and lands under the mat-vec below -------------------------
+        int tn = t, bn = b0 + pstride;
+        if (bn >= p.B) { bn = bfirst; tn = t + 1; }
+        const bool more = tn + 1 < p.T;
+        if (more && wave < min(p.tb, p.B - bn)) gather_issue(tn, bn + wave, s.xin + ((size_t)(cur ^ 1) * TB + wave) * kx);
+        // ---- [D] mat-vec for all utterances of the pass, four at a time (accumulators + weights must fit the register file):
+        //      VGPR rows, then LDS rows, then whatever streams; no barrier inside (the inputs are read-only here, the next
+        //      pass's land in the other buffer, and its [B] barrier is behind every wave's last read of this one) -----------
+#pragma unroll 1
+        for (int u0 = 0; u0 < nb; u0 += 4) {
+            // packed FMAs (v_pk_fma_f32: two outputs per instruction, the input broadcast into both halves): this loop is what a
+            // pass costs -- 336 rows x 256 outputs x 8 utterances = 688 k MACs per workgroup
+            const bool pub = u0 + pu < nb;                                   // this lane has something to publish in this round
+            const int rb = b0 + u0 + pu;
+            float zb0 = 0.f, zb1 = 0.f;                                      // the utterance's effective conv bias: requested ahead of the FMAs
+            if (pub) {
+                const float* zrow = zbase + (size_t)rb * p.zbias_bstride;
+                if (z0) zb0 = zrow[0];
+                if (z1) zb1 = zrow[1];
+            }
+            f2 acc[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = f2{0.f, 0.f};
+            const float* xr = s.xin + ((size_t)cur * TB + u0) * kx;
+            const float* xg[4] = {xr + xo0, xr + xo1, xr + xo2, xr + xo3};
+            // (loop order: a row's weights against two utterances -- four INDEPENDENT accumulators in a row; with one utterance
+            //  innermost the compiler alternated two and every v_pk_fma_f32 waited for the one before the last: 6.8 clocks per
+            //  instruction instead of 4.7, profiles/r04_tap_pass_timeline.txt; all four at once need 16 input registers: spills)
+#pragma unroll
+            for (int r4 = 0; r4 < KR_MAX / 4; ++r4) {
+#pragma unroll
+                for (int gp = 0; gp < 4; gp += 2) {                      // two utterances at a time: four independent accumulators in a row
+                    const float4 xa = *reinterpret_cast<const float4*>(xg[gp] + 4 * r4), xc = *reinterpret_cast<const float4*>(xg[gp + 1] + 4 * r4);
+                    const float xs[2][4] = {{xa.x, xa.y, xa.z, xa.w}, {xc.x, xc.y, xc.z, xc.w}};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 w = wreg[4 * r4 + e];
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const f2 xx = f2{xs[g][e], xs[g][e]};
+                            acc[gp + g][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[gp + g][0]);
+                            acc[gp + g][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[gp + g][1]);
+                        }
+                    }
+                }
+            }
+            for (int r = 0; r < p.klds_rows; r += 4) {                     // klds_rows is a multiple of 4: one 16-byte x read per utterance
+                float4 w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = s.wl[((size_t)wave * p.klds_rows + r + e) * 64 + lane];
+#pragma unroll
+                for (int gp = 0; gp < 4; gp += 2) {
+                    const float4 xa = *reinterpret_cast<const float4*>(xg[gp] + p.kreg_rows + r), xc = *reinterpret_cast<const float4*>(xg[gp + 1] + p.kreg_rows + r);
+                    const float xs[2][4] = {{xa.x, xa.y, xa.z, xa.w}, {xc.x, xc.y, xc.z, xc.w}};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const f2 xx = f2{xs[g][e], xs[g][e]};
+                            acc[gp + g][0] = __builtin_elementwise_fma(f2{w[e].x, w[e].y}, xx, acc[gp + g][0]);
+                            acc[gp + g][1] = __builtin_elementwise_fma(f2{w[e].z, w[e].w}, xx, acc[gp + g][1]);
+                        }
+                }
+            }
+            for (int k = k0 + kres; k < k0 + p.kper && k < p.kpre; ++k) {
+                const float4 w = wload(k);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float xs = xg[g][k - k0];
+                    const f2 xx = f2{xs, xs};
+                    acc[g][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[g][0]);
+                    acc[g][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[g][1]);
+                }
+            }
+            // the K slices meet (see REDUCE-SCATTER above)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[g][h] = f2{dpp_fold<0x141>(acc[g][h].x, acc[g + 2][1 - h].x), dpp_fold<0x141>(acc[g][h].y, acc[g + 2][1 - h].y)};   // (the mirror partner has the other parity: its OTHER pair holds these outputs)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[0][h] = f2{dpp_fold<0x4E>(acc[0][h].x, acc[1][h].x), dpp_fold<0x4E>(acc[0][h].y, acc[1][h].y)};
+            const float v0 = dpp_fold<0xB1>(acc[0][0].x, acc[0][1].x) + (zb0 + cvl.x);
+            const float v1 = dpp_fold<0xB1>(acc[0][0].y, acc[0][1].y) + (zb1 + cvl.y);
+            // pre_l[tp] of utterance rb leaves as tagged granules (write-through: the stage may sit on any XCD): no drain
+            if (pub) st_granule2(p.pmail + pre_rec(p, rb, l, tp) + po, p.tag_base + (unsigned)tp + 1u, v0, v1, false);
+            TAP_STAMP(min(3 + u0 / 4, 4));
+        }
+#undef TAP_STAMP
+        if (!more) break;
+        t = tn; b0 = bn; cur ^= 1;
     }
 }
 
@@ -864,9 +910,6 @@ __device__ __forceinline__ void load_image8g(const float* img, int gtid, f2 (&w)
         const float4 v = src[(size_t)c * GT + gtid];
         w[2 * c] = f2{v.x, v.y}; w[2 * c + 1] = f2{v.z, v.w};
     }
-}
-template <int CTRL> __device__ __forceinline__ float dpp_fold(float keep, float send) {
-    return keep + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), CTRL, 0xF, 0xF, true));
 }
 // (za, zb: two addends read from LDS ahead of the x slice -- their latency hides under the FMAs -- and added to a and g)
 __device__ __forceinline__ void group_matvec8(const f2 (&w)[8][8], const float* xslice, const float* za, const float* zb, float& a, float& g) {
@@ -1926,7 +1969,7 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
         // split rings (see run_stage_split): block b on XCD b % 8, slot b / 8; ring r = XCDs 2r (head, stages 1 .. sA) and 2r + 1
         if ((int)blockIdx.x >= p.ring_blocks) {
             const int k = (int)blockIdx.x - p.ring_blocks;
-            if (k < p.tap_parts * p.L) run_tap(p, k % p.L, k / p.L, smem);
+            if (k < p.tap_parts * p.L) run_tap<true>(p, k % p.L, k / p.L, smem);
             return;
         }
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, ring = xcd >> 1;
@@ -1951,14 +1994,14 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
     const int free_slots = (p.rstride - p.n_rings) * P;
     if ((int)blockIdx.x >= p.ring_blocks) {
         const int k = free_slots + (int)blockIdx.x - p.ring_blocks;
-        run_tap(p, k % p.L, k / p.L, smem);
+        run_tap<NK != 2>(p, k % p.L, k / p.L, smem);
         return;
     }
     const int ring = blockIdx.x % p.rstride;
     const int pos = blockIdx.x / p.rstride;
     if (ring >= p.n_rings) {
         const int k = pos * (p.rstride - p.n_rings) + (ring - p.n_rings);
-        if (k < p.tap_parts * p.L) run_tap(p, k % p.L, k / p.L, smem);
+        if (k < p.tap_parts * p.L) run_tap<NK != 2>(p, k % p.L, k / p.L, smem);
         return;
     }
     if (L0 && pos == 0) return;                   // layer 0 is evaluated by the head (run_head)
@@ -2521,7 +2564,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.kper = (((st->kpre + RW - 1) / RW) + 3) & ~3;
     p.kreg_rows = std::min(p.kper, KR_MAX);
     p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);                      // multiples of 4 (kper is one)
-    while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 150 * 1024) p.klds_rows -= 4;
+    while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 158 * 1024) p.klds_rows -= 4;
     p.ring_blocks = split ? 8 * max_slots : rstride * P;
     const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
                                 st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
