@@ -46,31 +46,33 @@ def test_lpt_and_packing():
 
 
 def test_group_size_from_the_measured_curve():
-    """No group size given: everything in one launch up to the throughput plateau (32 utterances per GPU, the reference recipe's
-    own inference batch, egs/mol/run.sh:31), groups of 32 beyond it -- 40 pending utterances run as 32 + 8; a number wins."""
-    assert THROUGHPUT_GROUP == 32
-    assert [auto_group_size(n) for n in (0, 1, 5, 8, 9, 31, 32, 33, 40, 1000)] == [1, 1, 5, 8, 9, 31, 32, 32, 32, 32]
-    lengths = [1000 + 37 * ((7 * i) % 40) for i in range(40)]
-    groups = pack_groups(range(40), lengths)
-    assert [len(g) for g in groups] == [32, 8]
-    assert sorted(sum(groups, [])) == list(range(40))
+    """No group size given: everything in one launch up to the throughput plateau (48 utterances per GPU since round 4; the reference
+    recipe's own inference batch is 32, egs/mol/run.sh:31), groups of 48 beyond it -- 40 pending utterances run as one launch, 56 as
+    48 + 8; a number wins."""
+    assert THROUGHPUT_GROUP == 48
+    assert [auto_group_size(n) for n in (0, 1, 5, 8, 9, 32, 40, 48, 49, 1000)] == [1, 1, 5, 8, 9, 32, 40, 48, 48, 48]
+    lengths = [1000 + 37 * ((7 * i) % 40) for i in range(56)]
+    assert [len(g) for g in pack_groups(range(40), lengths)] == [40]
+    groups = pack_groups(range(56), lengths)
+    assert [len(g) for g in groups] == [48, 8]
+    assert sorted(sum(groups, [])) == list(range(56))
     assert min(lengths[i] for i in groups[0]) >= max(lengths[i] for i in groups[1])       # neighbouring lengths, descending
     assert [len(g) for g in pack_groups(range(40), lengths, 8)] == [8] * 5                  # hparams.batch_size wins
     assert [len(g) for g in pack_groups(range(6), lengths)] == [6]
-    assert [len(g) for g in pack_groups(range(70), lengths * 2)] == [32, 32, 6]
+    assert [len(g) for g in pack_groups(range(100), lengths * 2)] == [48, 48, 4]
     with pytest.raises(ValueError):
         pack_groups(range(4), lengths, 0)
     # padding loss: a group runs to its longest member
     assert padding_loss([[0, 1]], [100, 50]) == pytest.approx(0.25)
     assert padding_loss([[0], [1]], [100, 50]) == 0.0
-    assert padding_loss(groups, lengths) < padding_loss([list(range(40))], lengths)         # two sorted groups pad less than one
+    assert padding_loss(groups, lengths) < padding_loss([list(range(56))], lengths)         # two sorted groups pad less than one
     # the stats the job mode of bench.py reports
     st = {}
-    mels = make_mels(40, seed=3)
+    mels = make_mels(56, seed=3)
     got = synthesize_sharded(mels, fake_synth, hop_size=HOP, cin_pad=PAD, stats=st)
     for a, b in zip(got, expected(mels)):
         assert torch.allclose(a, b, atol=1e-6)
-    assert [len(g) for g in st["groups"]] == [32, 8]
+    assert [len(g) for g in st["groups"]] == [48, 8]
     assert st["true_samples"] == sum(m.shape[-1] * HOP for m in mels) and st["padded_samples"] >= st["true_samples"]
     assert st["padding_loss"] == pytest.approx(1 - st["true_samples"] / st["padded_samples"])
 

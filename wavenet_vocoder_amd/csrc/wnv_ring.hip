@@ -144,6 +144,11 @@ __device__ __forceinline__ void ld16x2_sc1(const u64* p, const u64* q, u4v& a, u
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a), "=&v"(b) : "v"(p), "v"(q) : "memory");
 }
+__device__ __forceinline__ void ld16x4_sc1(const u64* p0, const u64* p1, const u64* p2, const u64* p3, u4v& a, u4v& b, u4v& c, u4v& d) {   // ... and four
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                 "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(p0), "v"(p1), "v"(p2), "v"(p3) : "memory");
+}
 // a 256-value record: granule n = value n; the receiving lane L takes granules 4L .. 4L + 3 in two 16-byte loads
 __device__ __forceinline__ int rec4_a(int lane) { return 4 * lane; }
 __device__ __forceinline__ int rec4_b(int lane) { return 4 * lane + 2; }
@@ -952,7 +957,11 @@ __device__ __forceinline__ void group_matvec8(const f2 (&w)[8][8], const float* 
 // lane j <-> 7 - j, hands lanes 0-3 the sums of channel 2og and lanes 4-7 those of 2og + 1; two quad_perm steps finish).
 // (L0: the ring's head evaluates layer 0 -- run_head; ZMSG: this instantiation is stage 1 of such a ring.  Compile-time switches:
 //  the stage loop is codegen-sensitive, a run-time flag in it costs every stage 3 %.)
-template <int NK, bool L0, bool ZMSG>
+// (MULTI: the instantiation for rings that carry several utterances -- more than 8 per GPU --, where the stage's OCCUPANCY per utterance
+//  bounds the throughput: everything ahead of the chain input is asked for in one round trip.  A compile-time switch: the same
+//  prologue in the single-utterance instantiation costs the headline 1.3 % through the register allocation of the stage loop
+//  (same box: 504.8 / 503.4 against 497.7 / 497.2 kSamples/s), while 48 utterances gain 3.5 %.)
+template <int NK, bool L0, bool ZMSG, bool MULTI>
 __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
     constexpr int NLDS = lds_passes(NK);
     constexpr bool RP = NK <= 2;                // pipelined polls in the reserved registers (the K = 512 instantiation needs them itself)
@@ -1031,8 +1040,29 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
                 else return wave_recv2(g2, tag, v0, v1, p.status, code, lane, false, u4v{0, 0, 0, 0});
             };
             if (wave == 0) {
+                // MULTI (several utterances per ring): everything this stage needs ahead of the chain input -- pre_l[t] (256 values, from the
+                // tap workgroup), the layer input h_{l-2} handed on by stage l - 1 and the residual increment q of stage l - 2 (128 values
+                // each) -- is asked for in ONE round trip; what has not arrived is then waited for on its own.  (Otherwise: pre poll, pre
+                // payload, h, q, one round trip after the other -- off the chain while a ring carries one utterance, but part of the
+                // stage's OCCUPANCY per utterance once it carries several, which is what bounds 48+ utterances per GPU.)
                 float pvv[4] = {0.f, 0.f, 0.f, 0.f};                             // pre_l[t], outputs 4 lane .. 4 lane + 3
-                if (!WNV_EXP_NOPRE && !rec_recv<2>(p.pmail + pre_rec(p, b, l, t), tag, pvv, p.status, 0x700u + (unsigned)sidx, lane, p.xcc + 256 + blockIdx.x)) s.flags[0] = 1;
+                const u64* prec = p.pmail + pre_rec(p, b, l, t);
+                bool pre_ok = WNV_EXP_NOPRE != 0, g_ok = false, q_ok = false;
+                float g0 = 0.f, g1 = 0.f, q0 = 0.f, q1 = 0.f;
+                const size_t slot = (((size_t)b * 2 + par) * S1 + sidx - 1) * RC + 2 * lane;
+                // h_{l-2}: there long before q (stage 2 of a ring whose head evaluates layer 0 takes h_0 from the head itself; stage 1: h_0)
+                const u64* gsrc = (L0 && sidx == 2) || sidx == 1 ? p.xmail + ((size_t)b * S1) * RC + 2 * lane : p.gmail + slot;
+                const u64* qsrc = p.hmail + slot;
+                if (MULTI && !zmsg && !first_stage && !WNV_EXP_NOPRE) {
+                    u4v ra, rb2, rc, rd;
+                    ld16x4_sc1(prec + rec4_a(lane), prec + rec4_b(lane), gsrc, sidx == 1 ? gsrc : qsrc, ra, rb2, rc, rd);
+                    pre_ok = __all(ra.y == tag && ra.w == tag && rb2.y == tag && rb2.w == tag);
+                    g_ok = __all(rc.y == tag && rc.w == tag);
+                    q_ok = sidx != 1 && __all(rd.y == tag && rd.w == tag);
+                    pvv[0] = __uint_as_float(ra.x); pvv[1] = __uint_as_float(ra.z); pvv[2] = __uint_as_float(rb2.x); pvv[3] = __uint_as_float(rb2.z);
+                    g0 = __uint_as_float(rc.x); g1 = __uint_as_float(rc.z); q0 = __uint_as_float(rd.x); q1 = __uint_as_float(rd.z);
+                }
+                if (!pre_ok && !rec_recv<2>(prec, tag, pvv, p.status, 0x700u + (unsigned)sidx, lane, p.xcc + 256 + blockIdx.x)) s.flags[0] = 1;
                 const float4 pv = make_float4(pvv[0], pvv[1], pvv[2], pvv[3]);
                 *reinterpret_cast<float4*>(s.pre + 4 * lane) = pv;
                 if constexpr (zmsg) {                                           // rows 4 lane .. 4 lane + 3 of N_1 h_0, plus pre_1: zin is complete;
@@ -1049,14 +1079,11 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
                 } else if (!first_stage) {
                     bool ok;
                     if (sidx == 1) {                                            // h_0 is the chain input of stage 0 (from the head)
-                        ok = recv128(p.xmail + ((size_t)b * S1) * RC + 2 * lane, 0x400u + (unsigned)sidx, hv0, hv1);
+                        ok = g_ok || recv128(gsrc, 0x400u + (unsigned)sidx, g0, g1);
+                        hv0 = g0; hv1 = g1;
                     } else {
-                        const size_t slot = (((size_t)b * 2 + par) * S1 + sidx - 1) * RC + 2 * lane;
-                        float g0 = 0.f, g1 = 0.f, q0 = 0.f, q1 = 0.f;
-                        // h_{l-2}: there long before q (stage 2 of a ring whose head evaluates layer 0 takes h_0 from the head itself)
-                        const u64* gsrc = L0 && sidx == 2 ? p.xmail + ((size_t)b * S1) * RC + 2 * lane : p.gmail + slot;
-                        ok = recv128(gsrc, 0x480u + (unsigned)sidx, g0, g1) &&
-                             recv128(p.hmail + slot, 0x400u + (unsigned)sidx, q0, q1);
+                        ok = (g_ok || recv128(gsrc, 0x480u + (unsigned)sidx, g0, g1)) &&
+                             (q_ok || recv128(qsrc, 0x400u + (unsigned)sidx, q0, q1));
                         hv0 = (q0 + g0) * 0.70710678118654752440f;
                         hv1 = (q1 + g1) * 0.70710678118654752440f;
                     }
@@ -1962,7 +1989,7 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
     }
 }
 
-template <int NK, bool L0, bool SPLIT>
+template <int NK, bool L0, bool SPLIT, bool MULTI>
 __device__ __forceinline__ void ring_body(const RingParams& p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (SPLIT) {
@@ -2005,8 +2032,8 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
         return;
     }
     if (L0 && pos == 0) return;                   // layer 0 is evaluated by the head (run_head)
-    if (L0 && pos == 1) run_stage<NK, L0, L0>(p, ring, pos, smem);
-    else if (pos < p.S) run_stage<NK, L0, false>(p, ring, pos, smem);
+    if (L0 && pos == 1) run_stage<NK, L0, L0, MULTI>(p, ring, pos, smem);
+    else if (pos < p.S) run_stage<NK, L0, false, MULTI>(p, ring, pos, smem);
     else if (p.cin1 > 1) {
         if constexpr (NK <= 2) {                // one-hot models with 512 skip channels stay on the generic kernel (why_not)
             if (pos == p.S) run_head_cat<NK>(p, ring, smem);
@@ -2020,12 +2047,13 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
 }
 
 // NK <= 2: capped at 244 VGPRs -- v244 .. v255 are the poll slots (see "POLLS IN RESERVED REGISTERS")
-template <int NK, bool L0>
-__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK, L0, false>(p); }
+template <int NK, bool L0, bool MULTI>
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK, L0, false, MULTI>(p); }
 // split rings: two CUs per layer (scalar-input models with 128 skip channels, up to 8 utterances)
-__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel_split(const RingParams p) { ring_body<1, true, true>(p); }
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel_split(const RingParams p) { ring_body<1, true, true, false>(p); }
 // K = 512: needs the whole register file; polls one load at a time in compiler-allocated registers
-__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4, false, false>(p); }
+template <bool MULTI>
+__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4, false, false, MULTI>(p); }
 
 // Placement census (once per handle): every workgroup of a one-block-per-CU grid reports the XCC it runs on.  The host derives
 // the number of XCDs and checks the block -> XCD mapping the ring layout relies on (block b on XCD b % n_xcd, observed; HIP
@@ -2086,13 +2114,52 @@ bool wnv_ring_default() {
 }
 const char* wnv_ring_why_not(const wnv_config& c, int B) { const char* w = why_not(c, B); return w ? w : "supported"; }
 
+// -DWNV_GUARD: every device buffer the sample-loop kernel writes (the state block: status, placement table, mailboxes, records,
+// history; the timeline buffer of trace builds) sits between two red zones of a fixed byte pattern that the host checks after the
+// launch -- a write past either end is reported instead of landing in a neighbour's memory.
+#ifdef WNV_GUARD
+constexpr size_t GUARD_BYTES = 1 << 20;
+constexpr int GUARD_BYTE = 0xC3;
+static hipError_t guard_alloc(void** user, size_t bytes) {
+    char* raw = nullptr;
+    hipError_t e = hipMalloc((void**)&raw, bytes + 2 * GUARD_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipMemset(raw, GUARD_BYTE, GUARD_BYTES);
+    if (e == hipSuccess) e = hipMemset(raw + GUARD_BYTES + bytes, GUARD_BYTE, GUARD_BYTES);
+    *user = raw + GUARD_BYTES;
+    return e;
+}
+static hipError_t guard_free(void* user) { return user ? hipFree((char*)user - GUARD_BYTES) : hipSuccess; }
+// true when both red zones are intact; otherwise says where the first foreign byte sits
+static bool guard_check(const void* user, size_t bytes, const char* what) {
+    std::vector<unsigned char> z(GUARD_BYTES);
+    bool ok = true;
+    for (int side = 0; side < 2; ++side) {
+        const char* zone = side ? (const char*)user + bytes : (const char*)user - GUARD_BYTES;
+        if (hipMemcpy(z.data(), zone, GUARD_BYTES, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "[wnv guard] %s: cannot read the red zone\n", what); return false; }
+        for (size_t i = 0; i < GUARD_BYTES; ++i)
+            if (z[i] != GUARD_BYTE) {
+                const long long off = side ? (long long)i : (long long)i - (long long)GUARD_BYTES;
+                fprintf(stderr, "[wnv guard] %s (%zu bytes): red zone %s it is overwritten, first at %s%lld bytes (value 0x%02x)\n", what, bytes,
+                        side ? "behind" : "in front of", side ? "end + " : "start ", off, z[i]);
+                ok = false;
+                break;
+            }
+    }
+    return ok;
+}
+#else
+static hipError_t guard_alloc(void** user, size_t bytes) { return hipMalloc(user, bytes); }
+static hipError_t guard_free(void* user) { return user ? hipFree(user) : hipSuccess; }
+#endif
+
 void wnv_ring_destroy(WnvRingState* st) {
     if (!st) return;
     if (st->pending) (void)hipStreamSynchronize(st->pending_stream);   // an asynchronous launch still reads all of the below
     if (st->d_w) (void)hipFree(st->d_w);
     if (st->d_dil) (void)hipFree(st->d_dil);
     if (st->d_histoff) (void)hipFree(st->d_histoff);
-    if (st->d_state) (void)hipFree(st->d_state);
+    if (st->d_state) (void)guard_free(st->d_state);
     if (st->h_status) (void)hipHostFree(st->h_status);
     delete st;
 }
@@ -2525,8 +2592,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
     if (bytes > st->state_cap) {
-        if (st->d_state) { RING_HIP(hipFree(st->d_state)); st->d_state = nullptr; st->state_cap = 0; }
-        RING_HIP(hipMalloc(&st->d_state, bytes));
+        if (st->d_state) { RING_HIP(guard_free(st->d_state)); st->d_state = nullptr; st->state_cap = 0; }
+        RING_HIP(guard_alloc(&st->d_state, bytes));
         st->state_cap = bytes;
         fresh = true;
     }
@@ -2569,9 +2636,12 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
                                 st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
+    const bool multi = upr > 1;                                    // several utterances per ring: the throughput instantiation of the stages
     const void* kfn = split ? (const void*)wnv_ring_kernel_split
-                    : NK == 1 ? (head_l0 ? (const void*)wnv_ring_kernel<1, true> : (const void*)wnv_ring_kernel<1, false>)
-                              : NK == 2 ? (const void*)wnv_ring_kernel<2, false> : (const void*)wnv_ring_kernel_k512;
+                    : NK == 1 ? (head_l0 ? (multi ? (const void*)wnv_ring_kernel<1, true, true> : (const void*)wnv_ring_kernel<1, true, false>)
+                                         : (multi ? (const void*)wnv_ring_kernel<1, false, true> : (const void*)wnv_ring_kernel<1, false, false>))
+                    : NK == 2 ? (multi ? (const void*)wnv_ring_kernel<2, false, true> : (const void*)wnv_ring_kernel<2, false, false>)
+                              : (multi ? (const void*)wnv_ring_kernel_k512<true> : (const void*)wnv_ring_kernel_k512<false>);
     RING_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.tap_parts = tap_parts; p.tb = tb;
     const int grid = split ? p.ring_blocks + tap_parts * st->L : p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);
@@ -2606,16 +2676,15 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
 #endif
     if (trace_path && *trace_path && p.T > 64) {
         trace_words = (size_t)trace_n * upr * (st->S + 1) * TRW + (size_t)trace_n * TRW;
-        RING_HIP(hipMalloc((void**)&d_trace, trace_words * sizeof(unsigned long long)));
+        RING_HIP(guard_alloc((void**)&d_trace, trace_words * sizeof(unsigned long long)));
         RING_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
         p.trace_tap = d_trace + (size_t)trace_n * upr * (st->S + 1) * TRW;
     }
-    if (split) hipLaunchKernelGGL(wnv_ring_kernel_split, dim3(grid), dim3(RT), lds, stream, p);
-    else if (NK == 1 && head_l0) hipLaunchKernelGGL((wnv_ring_kernel<1, true>), dim3(grid), dim3(RT), lds, stream, p);
-    else if (NK == 1) hipLaunchKernelGGL((wnv_ring_kernel<1, false>), dim3(grid), dim3(RT), lds, stream, p);
-    else if (NK == 2) hipLaunchKernelGGL((wnv_ring_kernel<2, false>), dim3(grid), dim3(RT), lds, stream, p);
-    else hipLaunchKernelGGL(wnv_ring_kernel_k512, dim3(grid), dim3(RT), lds, stream, p);
+    {
+        void* kargs[] = {(void*)&p};
+        RING_HIP(hipLaunchKernel(kfn, dim3(grid), dim3(RT), kargs, lds, stream));
+    }
     RING_HIP(hipGetLastError());
     // a bounded spin that gave up must reach the caller: the status word follows the kernel into pinned host memory; the call
     // waits for it here unless the caller asked for an asynchronous launch (then wnv_ring_wait reports it)
@@ -2626,11 +2695,18 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         return WNV_OK;
     }
     RING_HIP(hipStreamSynchronize(stream));
+#ifdef WNV_GUARD
+    if (!guard_check(st->d_state, st->state_cap, "ring state block")) { err = "WNV_GUARD: the ring state block's red zone is overwritten"; return WNV_ERR_HIP; }
+    { static int told = 0; if (!told++) fprintf(stderr, "[wnv guard] red zones of %zu bytes around the ring state block (%zu bytes) checked after every launch\n", GUARD_BYTES, st->state_cap); }
+#endif
     const unsigned int status = *st->h_status;
     if (d_trace) {
         std::vector<unsigned long long> tr(trace_words);
         RING_HIP(hipMemcpy(tr.data(), d_trace, trace_words * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        (void)hipFree(d_trace);
+#ifdef WNV_GUARD
+        if (!guard_check(d_trace, trace_words * sizeof(unsigned long long), "timeline buffer")) { (void)guard_free(d_trace); err = "WNV_GUARD: the timeline buffer's red zone is overwritten"; return WNV_ERR_HIP; }
+#endif
+        (void)guard_free(d_trace);
         if (FILE* f = fopen(trace_path, "w")) {
             fprintf(f, "# step pos(S=head) stamps in ns relative to the head's send of the first traced step (100 MHz wall clock); utterance 0 of ring 0\n");
             const unsigned long long t00 = tr[(((size_t)0 * upr + 0) * (st->S + 1) + st->S) * TRW + 0];

@@ -21,17 +21,18 @@ import torch
 __all__ = ["lpt_assign", "pack_groups", "pad_group", "broadcast_weights", "synthesize_sharded", "auto_group_size",
            "padding_loss", "THROUGHPUT_GROUP"]
 
-# Utterances per launch at which the ring kernel's aggregate rate stops growing (profiles/r03_ring_v14_batches_and_configs.txt and the
-# round-4 rows of profiles/README.md: kSamples/s per GPU 496 / 954 / 1903 / 1984 / 1980 at B = 8 / 16 / 32 / 48 / 64).  Up to here every
-# utterance of a group advances at the chain latency (~2.5x real time at 24 kHz), so a larger group costs no more wall time than a
-# smaller one; beyond it the per-utterance rate drops and nothing is gained.
-THROUGHPUT_GROUP = 32
+# Utterances per launch at which the ring kernel's aggregate rate stops growing.  Round 4 (profiles/r04_final_numbers.txt; kSamples/s
+# per GPU at B = 8 / 16 / 32 / 40 / 48 / 56 / 64): 504 / 1000 / 2014 / 2257 / 2712 / 2388 / 2703 -- up to 32 utterances every utterance advances at
+# the chain latency (~2.6x real time at 24 kHz), 48 still gain a third in aggregate at 2.35x real time each, beyond that nothing is
+# gained (a ring carries whole utterances: 56 = seven per ring run slower than 48 = six).  (Round 3: the plateau began at 32 -- 1.98
+# MSamples/s -- because the tap workgroups' passes bound the step there.)
+THROUGHPUT_GROUP = 48
 
 
 def auto_group_size(n_pending: int) -> int:
     """Group size for ``n_pending`` utterances waiting on ONE GPU when the caller did not fix one: everything in one launch while it
     fits the plateau (few utterances: a group of <= 8 is one utterance per ring, the lowest latency), groups of ``THROUGHPUT_GROUP``
-    otherwise -- 40 pending utterances run as 32 + 8."""
+    otherwise -- 40 pending utterances run as ONE launch (17.7 us per step against 2 x 16.1 for 32 + 8), 100 as 48 + 48 + 4."""
     return max(1, min(int(n_pending), THROUGHPUT_GROUP))
 
 
@@ -106,7 +107,7 @@ def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torc
     indices, and returns the waveforms (B, T) -- on the GPU box that is
     ``model.incremental_forward(c=c.cuda(), T=frames*hop)[:, 0]``.  Returns the list of trimmed waveforms in the
     original order on rank ``gather_to`` (on every rank if ``gather_to`` is None), None elsewhere.
-    ``group_size=None`` (default): from the measured throughput curve, ``auto_group_size`` -- up to 32 utterances per launch; a
+    ``group_size=None`` (default): from the measured throughput curve, ``auto_group_size`` -- up to 48 utterances per launch; a
     number (``hparams.batch_size`` of the caller) wins.  ``stats``: filled with this rank's groups, true / padded samples."""
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
