@@ -284,11 +284,33 @@ def job_mode(args, model, kw, dev, dist, world, rank):
 
     group = args.job_group if args.job_group > 0 else None
 
-    def run():
+    def run_padded():
         st = {}
         launches.clear()
         wavs = sharding.synthesize_sharded(mels, synth, hop_size=hop, cin_pad=pad, group_size=group, stats=st, gather_to=0)
         return wavs, st
+
+    def run_packed():
+        """Every rank packs its share of the job (longest-first over the ranks) into slots of one launch."""
+        st = {}
+        launches.clear()
+        mine = sharding.lpt_assign(lengths, world)[rank]
+        outs = sharding.synthesize_packed(model, mels, hop_size=hop, cin_pad=pad, slots=group, indices=mine, stats=st, seed=4321)
+        launches.append((st.get("slots", 0), st.get("slot_steps", 0)))
+        st["groups"] = [mine]
+        local = {i: o[0].detach().to("cpu") for i, o in zip(mine, outs)}
+        if dist is None:
+            return [local[i] for i in range(len(mels))], st
+        parts = [None] * world if rank == 0 else None
+        dist.gather_object(local, parts, dst=0)
+        if rank != 0:
+            return None, st
+        merged = {}
+        for part in parts:
+            merged.update(part)
+        return [merged[i] for i in range(len(mels))], st
+
+    run = run_packed if args.packed else run_padded
 
     for _ in range(max(args.warmup, 1)):                                                     # engine, scratch, mailboxes exist
         run()
@@ -322,8 +344,9 @@ def job_mode(args, model, kw, dev, dist, world, rank):
                 "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic (seeded N(0,1) mels of seeded lengths 1-8 s, random-init weights, in-kernel Philox noise)",
                 "config": {"workload": f"{args.workload}: {describe(kw)}; JOB of {args.job} utterances, {min(frames)}-{max(frames)} frames "
-                                       f"({true_total / 24000.0:.1f} s of audio), scheduler = lpt_assign + pack_groups("
-                                       f"{'auto' if group is None else group})",
+                                       f"({true_total / 24000.0:.1f} s of audio), scheduler = "
+                                       + (f"lpt_assign + PACKED SLOTS (continuous batching, {'48' if group is None else group} slots per GPU)" if args.packed
+                                          else f"lpt_assign + pack_groups({'auto' if group is None else group})"),
                            "parallelism": f"utterance-sharded x{world}"},
                 "job": {"utterances": args.job, "true_samples": true_total, "padded_samples": padded_total,
                         "padding_loss": round(1.0 - true_total / padded_total, 4),
@@ -351,6 +374,8 @@ def main():
                     help="JOB MODE: synthesise N utterances of seeded lengths 1-8 s through the scheduler (sharding.lpt_assign + "
                          "pack_groups) instead of one fixed batch; reports true kSamples/s and the padding loss")
     ap.add_argument("--job-group", type=int, default=0, help="job mode: utterances per launch (0 = sharding.auto_group_size)")
+    ap.add_argument("--packed", action="store_true",
+                    help="job mode: PACKED SLOTS (continuous batching, sharding.synthesize_packed) instead of padded groups")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (no throughput_mode, no cpu_baseline): what the rocprofv3 summaries are taken with")
     args = ap.parse_args()

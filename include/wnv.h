@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WNV_ABI_VERSION 3
+#define WNV_ABI_VERSION 4
 #define WNV_MAX_UPSAMPLE_STAGES 8
 
 typedef enum wnv_status {
@@ -169,6 +169,15 @@ typedef struct wnv_generate_args {
                                /* filling the tape and advancing the counter while the kernel runs; the kernel waits (bounded) */
                                /* for every step it is about to read.  Needs kernel == 2 and WNV_GEN_ASYNC.  NULL: the whole   */
                                /* tape is valid at the call.                                                                   */
+    const int32_t* seg_start;  /* ABI 4, optional: PACKED SLOTS (continuous batching).  The B rows of this call are not utterances    */
+    const int32_t* seg_uid;    /* but SLOTS that run several utterances back to back: device (B, T) each; seg_start[b][t] = the step  */
+                               /* at which the utterance occupying slot b at step t began, seg_uid[b][t] = its id in the job.  At a   */
+                               /* boundary (seg_start[b][t] == t) the utterance starts as incremental_forward starts one: history     */
+                               /* before its first step reads as zeros (conv.py:34-36), the first input is zeros / one-hot 127          */
+                               /* (wavenet.py:281-289); the in-kernel noise stream is addressed with (seg_uid, t - seg_start), so a   */
+                               /* waveform does not depend on how the job was packed.  c_up is the slots' concatenated conditioning.  */
+                               /* Ring kernel only, models without global conditioning, in-kernel noise (noise, teacher, initial,      */
+                               /* g, g_ids NULL); otherwise WNV_ERR_UNSUPPORTED / WNV_ERR_INVALID_ARG.  NULL: one utterance per row.  */
 } wnv_generate_args;
 
 /* The pipelined ring kernel is a persistent launch whose workgroups wait for each other; every wait is bounded and a

@@ -30,6 +30,8 @@ prev_send = base
 for pos in list(range(S)) + [S]:
     r = [x for x in rows if int(x[0]) == t and int(x[1]) == pos][0]
     v = [int(x) - base if int(x) >= 0 else None for x in r[2:]]
+    if pos < S and v[0] is None:                     # (position 0 of a ring whose head evaluates layer 0 is empty)
+        continue
     if pos < S:
         print(f" stage {pos:2d}: recv {v[0]:6d} (hop {v[0]-prev_send:5d})  gate/send-u +{v[1]-v[0]:5d}  h-sent +{v[2]-v[1]:5d}  skip-sent +{v[3]-v[2]:5d}  deferred-done +{v[4]-v[3]:5d}")
         prev_send = v[1]

@@ -188,8 +188,8 @@ def test_ring_kernel_keeps_its_poll_registers_out_of_the_compilers_hands(tmp_pat
     branch = re.compile(r"^\s*(s_branch|s_cbranch_\w+)\s+(\.LBB\w+)")
     REACH = 150
     checked = 0
-    # <NK, head evaluates layer 0, several utterances per ring>, and the split-ring kernel
-    for nk, l0 in ((1, "0ELb0"), (1, "1ELb0"), (2, "0ELb0"), (1, "0ELb1"), (1, "1ELb1"), (2, "0ELb1"), (1, "split")):
+    # <NK, head evaluates layer 0, MODE: 0 = up to four utterances per ring, 1 = more, 2 = packed slots>, and the split-ring kernel
+    for nk, l0 in [(nk, f"{l0}ELi{mode}") for mode in (0, 1, 2) for nk, l0 in ((1, 0), (1, 1), (2, 0))] + [(1, "split")]:
         kname = "wnv_ring_kernel_splitE" if l0 == "split" else f"wnv_ring_kernelILi{nk}ELb{l0}E"
         m = re.search(rf"^_ZN\S*{kname}\S*:[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M)
         assert m, f"kernel <{nk}, {l0}> not found"
@@ -233,7 +233,7 @@ def test_ring_kernel_keeps_its_poll_registers_out_of_the_compilers_hands(tmp_pat
         checked += 1
         meta = re.search(rf"\.name:\s+_ZN\S*{kname}\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
         assert meta and int(meta.group(1)) == 0, "the capped kernel spills"
-    assert checked == 7
+    assert checked == 10
 
 
 # ---- host-only handles (wnv_create with device = -1): the native checkpoint path without a GPU ------------------------------

@@ -13,7 +13,7 @@ from typing import Optional
 __all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "ForwardArgs", "MelConfig", "LogmelArgs", "LIB_PATH",
            "WNV_ABI_VERSION", "DIST", "UPSAMPLE"]
 
-WNV_ABI_VERSION = 3
+WNV_ABI_VERSION = 4
 WNV_MAX_UPSAMPLE_STAGES = 8
 WNV_GEN_ASYNC = 1
 # WNV_LIB selects another build of the same sources (debug/trace builds: python -m wavenet_vocoder_amd.build --out ... --flags ...)
@@ -68,7 +68,7 @@ class GenerateArgs(C.Structure):
         ("initial", C.c_void_p), ("teacher", C.c_void_p), ("Tt", C.c_int64), ("noise", C.c_void_p),
         ("seed", C.c_uint64), ("softmax", C.c_int32), ("quantize", C.c_int32), ("out", C.c_void_p),
         ("params_out", C.c_void_p), ("index_out", C.c_void_p), ("kernel", C.c_int32), ("flags", C.c_int32),
-        ("stream", C.c_void_p), ("noise_ready", C.c_void_p),
+        ("stream", C.c_void_p), ("noise_ready", C.c_void_p), ("seg_start", C.c_void_p), ("seg_uid", C.c_void_p),
     ]
 
 

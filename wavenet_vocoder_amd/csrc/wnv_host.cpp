@@ -609,6 +609,13 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     if ((a->flags & WNV_GEN_ASYNC) && a->kernel != 2) return fail(WNV_ERR_INVALID_ARG, "WNV_GEN_ASYNC needs kernel = 2 (the ring kernel chosen explicitly: auto mode must see the launch's status to fall back)");
     if (a->noise_ready && !(a->noise && a->kernel == 2 && (a->flags & WNV_GEN_ASYNC)))
         return fail(WNV_ERR_INVALID_ARG, "a streamed noise tape (noise_ready) needs noise, kernel = 2 and WNV_GEN_ASYNC: the caller fills the tape while the kernel runs");
+    if ((a->seg_start == nullptr) != (a->seg_uid == nullptr)) return fail(WNV_ERR_INVALID_ARG, "seg_start and seg_uid come together (packed slots)");
+    if (a->seg_start) {
+        if (a->noise || a->teacher || a->initial || a->g || a->g_ids)
+            return fail(WNV_ERR_INVALID_ARG, "packed slots take in-kernel noise and no teacher / initial input / global conditioning (one bias table per slot)");
+        if (a->kernel != 0 && a->kernel != 2) return fail(WNV_ERR_UNSUPPORTED, "packed slots run on the pipelined ring kernel only");
+        if (!(wnv_ring_supported(c, a->B) && wnv_ring_default())) return fail(WNV_ERR_UNSUPPORTED, "packed slots need the pipelined ring kernel: %s", wnv_ring_why_not(c, a->B));
+    }
     if ((a->flags & WNV_GEN_ASYNC) && a->B > 64) return fail(WNV_ERR_INVALID_ARG, "WNV_GEN_ASYNC takes at most 64 utterances per call (larger batches run as several launches)");
     DeviceGuard g(h->device);
     hipStream_t s = (hipStream_t)a->stream;
@@ -635,6 +642,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     ga.seed = a->seed; ga.softmax = a->softmax; ga.quantize = c.scalar_input ? 1 : a->quantize;
     ga.nz = wnv_noise_width(&c);
     ga.noise_ready = a->noise_ready;
+    ga.seg_start = a->seg_start; ga.seg_uid = a->seg_uid;
     ga.out = a->out; ga.params_out = a->params_out; ga.index_out = a->index_out;
     // asynchronous ring launches only when the caller chose the ring explicitly: auto mode must see the status to fall back
     ga.async = (a->flags & WNV_GEN_ASYNC) && a->kernel == 2;
@@ -647,6 +655,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         else if (!h->wide_disabled && !wnv_ring_supported(c, a->B) && wnv_wide_supported(c, a->B) && wnv_ring_default()) kernel = 3;
         else kernel = 1;
         if (kernel != 1 && h->persist_cooldown > 0) { --h->persist_cooldown; kernel = 1; }     // pausing after a time-out (see wnv_engine)
+        if (a->seg_start && kernel != 2) return fail(WNV_ERR_UNSUPPORTED, "packed slots need the pipelined ring kernel, which this handle is not using right now");
     }
     if (kernel == 3) {                     // wide models: one GROUP of 8 workgroups per layer (wnv_wide.hip); same fallback rules as the ring
         if (!wnv_wide_supported(c, a->B)) return fail(WNV_ERR_UNSUPPORTED, "the group-ring kernel does not cover this configuration: %s", wnv_wide_why_not(c, a->B));
@@ -689,7 +698,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         // or busy with another process: WNV_ERR_TIMEOUT after the bounded spins) is served by the generic kernel.  UNSUPPORTED is
         // permanent for the handle; after a TIMEOUT the persistent kernel is tried again after a pause that doubles with every
         // consecutive time-out (persist_cooldown).  An explicit kernel = 2 reports the reason instead.
-        const bool recoverable = st == WNV_ERR_UNSUPPORTED || st == WNV_ERR_TIMEOUT;
+        const bool recoverable = (st == WNV_ERR_UNSUPPORTED || st == WNV_ERR_TIMEOUT) && !a->seg_start;   // (packed slots: the caller re-plans)
         if (!(a->kernel == 0 && recoverable)) return fail(st, "%s", err.c_str());
         if (st == WNV_ERR_TIMEOUT) {
             h->persist_backoff = h->persist_backoff ? std::min(2 * h->persist_backoff, 32) : 2;

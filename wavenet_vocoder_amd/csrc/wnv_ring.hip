@@ -37,6 +37,7 @@
 #endif
 
 #include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cmath>
@@ -88,10 +89,14 @@ struct RingParams {
     int kper, kreg_rows, klds_rows;              // tap workgroup: K rows per wave; of those resident in VGPRs / in LDS (the rest streams)
     unsigned int* xcc;                 // [grid] XCC id + 1 of every workgroup (placement handshake)
     float* hist;
+    const float* zero_row;             // 128 zeros behind the history rings (packed slots: what lies before an utterance's first step)
     const float *c_up, *initial, *teacher, *noise;
     unsigned long long seed;
     int b0, noise_B;                   // this launch is utterances [b0, b0 + B) of a call of noise_B (noise tape / Philox stream addressing)
     const unsigned* noise_ready;       // streamed tape (coherent host memory): steps [0, *noise_ready) of `noise` are valid; null: all of it
+    const int *seg_start, *seg_uid;    // PACKED SLOTS (wnv_generate_args, ABI 4): [B][T] each -- the step at which the utterance occupying slot b at step t
+                                       // began, and its id in the job; null: one utterance per row.  An utterance's history before its first step reads as
+                                       // zeros (tap workgroups), its first input is zeros / one-hot 127 and its noise stream is (uid, t - start) (heads)
     float *out, *params_out;
     unsigned int* status;
     unsigned long long* trace;         // optional [T_trace][upr][S+1][16] wall-clock stamps of ring 0's utterances (debug)
@@ -632,7 +637,7 @@ __device__ __forceinline__ size_t pre_rec(const RingParams& p, int b, int l, int
 // -- is computed here for EVERY utterance, with the [kw-1 taps + cin][256] matrix resident on this CU (VGPRs first, then
 // LDS; only what fits neither streams from L2).  The stages forward h_l[t] (one write-through granule per value) and get
 // pre_l[t+1] back the same way; both trips have a whole step of slack.  The workgroup also owns the history rings.
-constexpr int KR_MAX = 32;         // K rows per wave held in VGPRs (32 float4 = 128 registers)
+constexpr int KR_MAX = 32;         // K rows per lane slice held in VGPRs (32 float4 = 128 registers)
 constexpr int KL_MAX = 16;         // further K rows per wave held in LDS
 constexpr int TB = 8;              // utterances per pass (one polling wave each; their latencies overlap)
 struct TapLds {
@@ -657,9 +662,11 @@ __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
 #ifndef WNV_EXP_NOPRE
 #define WNV_EXP_NOPRE 0
 #endif
-// (SPEC: the speculative look at the next pass's h record -- four registers live across the mat-vec, one more than the capped NK = 2
-//  instantiation has next to its 128 weight registers)
-template <bool SPEC>
+// (SPEC: a speculative look at the next pass's h record, issued with the gather -- four registers live across the mat-vec.  Instantiated
+//  with SPEC = false since the packed-slot masks took the last registers of the capped kernels: it saved one poll round trip per pass
+//  while the tap passes bound the step; now the stages' occupancy does.)
+// (PACKED: the launch runs packed slots -- RingParams::seg_start; a compile-time switch like SPEC: together they spill)
+template <bool SPEC, bool PACKED>
 __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int l, int part, float* smem) {
     if (WNV_EXP_NOPRE >= 2) return;
     const TapLds s = carve_tap(smem, p);
@@ -741,13 +748,17 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         const int tp_ = t_ + 1, tf_ = early ? t_ - 1 : t_, kf = fresh_tap(tf_);
         const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
         const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
+        // packed slots: the utterance that occupies the slot at step tp_ began at step st_; what lies before reads as zeros (conv.py:34-36)
+        const int st_ = PACKED ? p.seg_start[(size_t)b * p.T + tp_] : INT_MIN;
 #pragma unroll
         for (int q = 0; q < GQ; ++q) {
             const int i = 64 * q + lane;
             const float* src = nullptr;
             if (i < ntap4) {
                 const int k = i >> 5, r4 = i & 31;                   // RC / 4 = 32 float4s per row
-                if (k != kf) src = hb + (size_t)((tp_ + k * d) % rows) * RC + 4 * r4;
+                // (a row from before the utterance's start comes from a row of zeros: a select on the address, no branch -- the tap role has
+                //  no register to spare)
+                if (k != kf) src = tp_ - (p.kw - 1 - k) * d >= st_ ? hb + (size_t)((tp_ + k * d) % rows) * RC + 4 * r4 : p.zero_row + 4 * r4;
             } else if (i < ntap4 + ncin4) {
                 src = cb + 4 * (i - ntap4);
             }
@@ -794,7 +805,11 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
                 if (rows > 0) {
                     float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
                     *reinterpret_cast<float2*>(hist + (size_t)(tf % rows) * RC + 2 * lane) = make_float2(hv[0], hv[1]);
-                    if (kfresh >= 0) *reinterpret_cast<float2*>(xu + kfresh * RC + 2 * lane) = make_float2(hv[0], hv[1]);
+                    if (kfresh >= 0) {
+                        // (packed slots: the row is the previous utterance's when the one at step tp began later than tf)
+                        const bool mine = !PACKED || tf >= p.seg_start[(size_t)b * p.T + tp];
+                        *reinterpret_cast<float2*>(xu + kfresh * RC + 2 * lane) = mine ? make_float2(hv[0], hv[1]) : make_float2(0.f, 0.f);
+                    }
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs into buffer cur (issued a pass ago) have landed
@@ -1497,8 +1512,10 @@ __host__ __device__ constexpr size_t head_lds_floats(int NK) { return (size_t)GC
 // (a STREAMED tape is host memory the CPU is still writing: its values are read with system-scope loads that bypass the vector L1 and
 //  the L2 -- a line fetched for the last published step also holds the start of the next, unpublished one -- behind wait_noise's
 //  acquire; a tape in device memory is complete before the launch and is read with plain loads)
-__device__ __forceinline__ float head_noise(const RingParams& p, int t, int b, int idx, int kind) {
-    if (!p.noise) return wnv_noise_gen(p.seed, t, p.b0 + b, idx, kind);
+// (tl, ub: the coordinates of the in-kernel stream -- step and utterance index of the call, or, with packed slots, the step within the
+//  utterance and its id in the job)
+__device__ __forceinline__ float head_noise(const RingParams& p, int t, int b, int idx, int kind, int tl, int ub) {
+    if (!p.noise) return wnv_noise_gen(p.seed, tl, ub, idx, kind);
     const float* src = p.noise + ((size_t)t * p.noise_B + p.b0 + b) * p.nz + idx;
     if (p.noise_ready) return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     return *src;
@@ -1650,7 +1667,7 @@ __device__ __forceinline__ bool head_collect(const RingParams& p, int b, unsigne
     return true;
 }
 
-template <int NK, bool L0, bool SPLIT>
+template <int NK, bool L0, bool SPLIT, bool PACKED>
 __device__ __attribute__((always_inline)) void run_head(const RingParams& p, int ring, float* smem) {
     WNV_TS_DECL;
     const HeadLds s = carve_head(smem, NK);
@@ -1779,10 +1796,17 @@ __device__ __attribute__((always_inline)) void run_head(const RingParams& p, int
             // ---- everything that does not depend on the network, while the ring works ---------------------------
             const bool nz_ok = wait_noise(p, t, noise_seen);                        // (false: draining -- the step's noise is not read)
             if (!nz_ok) s.flags[0] = 1;
+            int tl = t, ub = p.b0 + b;                                              // coordinates of the noise stream
+            bool next_starts = false;                                               // packed slots: step t + 1 is the first of another utterance
+            if constexpr (PACKED) {
+                const size_t so = (size_t)b * p.T + t;
+                tl = t - p.seg_start[so]; ub = p.seg_uid[so];
+                next_starts = t + 1 < p.T && p.seg_start[so + 1] == t + 1;
+            }
             float gum = 0.f, lr = 0.f, forced = 0.f;
-            if (i < nmix && nz_ok) gum = -logf(-logf(head_noise(p, t, b, i, 0)));   // Gumbel noise (mixture.py:138-140)
+            if (i < nmix && nz_ok) gum = -logf(-logf(head_noise(p, t, b, i, 0, tl, ub)));   // Gumbel noise (mixture.py:138-140)
             if (wave < 2) {
-                const float r = nz_ok ? head_noise(p, t, b, nmix, p.dist == 2 ? 1 : 0) : 0.5f;
+                const float r = nz_ok ? head_noise(p, t, b, nmix, p.dist == 2 ? 1 : 0, tl, ub) : 0.5f;
                 lr = p.dist == 1 ? logf(r) - logf(1.0f - r) : r;                     // mixture.py:151-152 / :265-267
                 if (t + 1 < p.Tt) forced = p.teacher[(size_t)b * p.Tt + t + 1];
             }
@@ -1855,6 +1879,7 @@ __device__ __attribute__((always_inline)) void run_head(const RingParams& p, int
                     xo = fminf(fmaxf(xo, -1.0f), 1.0f);
                 }
                 xs = t + 1 < p.Tt ? forced : xo;                                    // wavenet.py:297-305
+                if (next_starts) xs = 0.f;                                          // (a new utterance begins: wavenet.py:281-283)
                 xout = xo;
             }
             if (t + 1 < p.T) feed(b, tag + 1u, ad, xs, pt, ps);
@@ -1882,7 +1907,7 @@ __device__ __forceinline__ CatLds carve_cat(float* smem, int NK) {
 }
 __host__ __device__ constexpr size_t cat_lds_floats(int NK) { return (size_t)(4 * NK + 4) * QS + 3 * 256 + 4 * RC + 16 + (size_t)256 * RC; }
 
-template <int NK>
+template <int NK, bool PACKED>
 __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p, int ring, float* smem) {
     WNV_TS_DECL;
     const CatLds s = carve_cat(smem, NK);
@@ -1936,7 +1961,14 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
             // noise of this step, while the ring works: e ~ Exp(1) per class
             const bool nz_ok = wait_noise(p, t, noise_seen);                        // (false: draining -- the step's noise is not read)
             if (!nz_ok) s.ints[0] = 1;
-            if (tid < O) s.nzb[tid] = nz_ok ? head_noise(p, t, b, tid, 2) : 1.0f;
+            int tl = t, ub = p.b0 + b;
+            bool next_starts = false;                                               // packed slots: step t + 1 is the first of another utterance
+            if constexpr (PACKED) {
+                const size_t so = (size_t)b * p.T + t;
+                tl = t - p.seg_start[so]; ub = p.seg_uid[so];
+                next_starts = t + 1 < p.T && p.seg_start[so + 1] == t + 1;
+            }
+            if (tid < O) s.nzb[tid] = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
             if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.ints[0] = 1;
             __syncthreads();
             WNV_TS(1);
@@ -1965,7 +1997,8 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
                 const int idx = sample_categorical(O, s.obuf, s.nzb, p.softmax, p.quantize, lane);
                 if (p.quantize) {
                     if (t + 1 < p.T && !dense_next) {
-                        st_granule(p.xmail + ((size_t)b * S1) * RC + tid, tag + 1u, s.wfl[(size_t)idx * RC + tid] + bf, fast);
+                        // (a new utterance begins with the one-hot vector of class 127: wavenet.py:284-289)
+                        st_granule(p.xmail + ((size_t)b * S1) * RC + tid, tag + 1u, s.wfl[(size_t)(next_starts ? 127 : idx) * RC + tid] + bf, fast);
                         WNV_TS(0);
                     }
                     if (tid == 0) {
@@ -1989,20 +2022,22 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
     }
 }
 
-template <int NK, bool L0, bool SPLIT, bool MULTI>
+// MODE: 0 = one to four utterances per ring, 1 = more (the stages' throughput prologue), 2 = packed slots (seg_start; any number)
+template <int NK, bool L0, bool SPLIT, int MODE>
 __device__ __forceinline__ void ring_body(const RingParams& p) {
+    constexpr bool MULTI = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     if constexpr (SPLIT) {
         // split rings (see run_stage_split): block b on XCD b % 8, slot b / 8; ring r = XCDs 2r (head, stages 1 .. sA) and 2r + 1
         if ((int)blockIdx.x >= p.ring_blocks) {
             const int k = (int)blockIdx.x - p.ring_blocks;
-            if (k < p.tap_parts * p.L) run_tap<true>(p, k % p.L, k / p.L, smem);
+            if (k < p.tap_parts * p.L) run_tap<true, false>(p, k % p.L, k / p.L, smem);
             return;
         }
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, ring = xcd >> 1;
         if (ring >= p.n_rings) return;
         if ((xcd & 1) == 0) {
-            if (slot == 0) { run_head<NK, true, true>(p, ring, smem); return; }
+            if (slot == 0) { run_head<NK, true, true, false>(p, ring, smem); return; }
             const int stage = 1 + ((slot - 1) >> 1), half = (slot - 1) & 1;
             if (stage > p.sA) return;
             if (stage == 1) run_stage_split<true>(p, ring, stage, half, smem);
@@ -2021,14 +2056,14 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
     const int free_slots = (p.rstride - p.n_rings) * P;
     if ((int)blockIdx.x >= p.ring_blocks) {
         const int k = free_slots + (int)blockIdx.x - p.ring_blocks;
-        run_tap<NK != 2>(p, k % p.L, k / p.L, smem);
+        run_tap<MODE != 2 && NK != 2, MODE == 2>(p, k % p.L, k / p.L, smem);
         return;
     }
     const int ring = blockIdx.x % p.rstride;
     const int pos = blockIdx.x / p.rstride;
     if (ring >= p.n_rings) {
         const int k = pos * (p.rstride - p.n_rings) + (ring - p.n_rings);
-        if (k < p.tap_parts * p.L) run_tap<NK != 2>(p, k % p.L, k / p.L, smem);
+        if (k < p.tap_parts * p.L) run_tap<MODE != 2 && NK != 2, MODE == 2>(p, k % p.L, k / p.L, smem);
         return;
     }
     if (L0 && pos == 0) return;                   // layer 0 is evaluated by the head (run_head)
@@ -2036,24 +2071,24 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
     else if (pos < p.S) run_stage<NK, L0, false, MULTI>(p, ring, pos, smem);
     else if (p.cin1 > 1) {
         if constexpr (NK <= 2) {                // one-hot models with 512 skip channels stay on the generic kernel (why_not)
-            if (pos == p.S) run_head_cat<NK>(p, ring, smem);
+            if (pos == p.S) run_head_cat<NK, MODE == 2>(p, ring, smem);
             else run_head_part<NK, 2>(p, ring, pos - p.S, smem);
         }
     } else {
-        if (pos == p.S) run_head<NK, L0, false>(p, ring, smem);
+        if (pos == p.S) run_head<NK, L0, false, MODE == 2>(p, ring, smem);
         else if constexpr (NK > 1) run_head_part<NK, 1>(p, ring, pos - p.S, smem);     // (128 skip channels: the head is one workgroup)
     }
     }
 }
 
 // NK <= 2: capped at 244 VGPRs -- v244 .. v255 are the poll slots (see "POLLS IN RESERVED REGISTERS")
-template <int NK, bool L0, bool MULTI>
-__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK, L0, false, MULTI>(p); }
+template <int NK, bool L0, int MODE>
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK, L0, false, MODE>(p); }
 // split rings: two CUs per layer (scalar-input models with 128 skip channels, up to 8 utterances)
-__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel_split(const RingParams p) { ring_body<1, true, true, false>(p); }
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel_split(const RingParams p) { ring_body<1, true, true, 0>(p); }
 // K = 512: needs the whole register file; polls one load at a time in compiler-allocated registers
-template <bool MULTI>
-__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4, false, false, MULTI>(p); }
+template <int MODE>
+__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4, false, false, MODE>(p); }
 
 // Placement census (once per handle): every workgroup of a one-block-per-CU grid reports the XCC it runs on.  The host derives
 // the number of XCDs and checks the block -> XCD mapping the ring layout relies on (block b on XCD b % n_xcd, observed; HIP
@@ -2487,6 +2522,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
             g.out = ga.out + (size_t)b0 * cin1 * ga.T;
             if (ga.params_out) g.params_out = ga.params_out + (size_t)b0 * O * ga.T;
             if (ga.index_out) g.index_out = ga.index_out + (size_t)b0 * ga.T;
+            if (ga.seg_start) { g.seg_start = ga.seg_start + (size_t)b0 * ga.T; g.seg_uid = ga.seg_uid + (size_t)b0 * ga.T; }
             const wnv_status s0 = wnv_ring_generate(pst, device, c, store, g, stream, err);
             if (s0 != WNV_OK) return s0;
         }
@@ -2588,7 +2624,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t n_z = (size_t)B * GC;                             // N_1 h_0 from the head (head_l0)
     const size_t qh = split ? 2 : 1;                               // split rings: two partial vectors per residual / skip slot
     const size_t mail_bytes = (n_h + 2 * n_h * qh + 2 * n_h + n_s * qh + n_o + n_z + n_f + n_p) * sizeof(u64);
-    const size_t hist_bytes = (size_t)B * st->hist_floats * sizeof(float);
+    const size_t hist_bytes = ((size_t)B * st->hist_floats + RC) * sizeof(float);    // (+ one row of zeros: RingParams::zero_row)
     const size_t bytes = head_bytes + mail_bytes + hist_bytes;
     bool fresh = false;
     if (bytes > st->state_cap) {
@@ -2622,9 +2658,11 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.fmail = p.zmail + n_z;
     p.pmail = p.fmail + n_f;
     p.hist = (float*)(p.pmail + n_p);
+    p.zero_row = p.hist + (size_t)B * st->hist_floats;
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.b0 = ga.b0; p.noise_B = ga.noise_B > 0 ? ga.noise_B : B;
     p.noise_ready = ga.noise_ready;
+    p.seg_start = ga.seg_start; p.seg_uid = ga.seg_uid;
     p.out = ga.out; p.params_out = ga.params_out;
     // LDS: the stage carve is the larger one
     // tap workgroups: K rows per wave (a multiple of 4), first in VGPRs, then in LDS, the remainder streams from L2
@@ -2636,12 +2674,17 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
                                 st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
-    const bool multi = upr > 1;                                    // several utterances per ring: the throughput instantiation of the stages
+    // more than four utterances per ring (40+ per GPU): the stages' occupancy per utterance bounds the step -> their throughput
+    // instantiation.  Up to four a ring is still bound by the chain's latency and the plain prologue is faster (same box, B = 16 / 32:
+    // 1002 / 2014 against 970 / 1918 kSamples/s; B = 48: 2616 against 2742)
+    const int mode = ga.seg_start ? 2 : upr > 4 ? 1 : 0;
+    if (split && mode == 2) { err = "ring kernel: packed slots and split rings do not combine"; return WNV_ERR_UNSUPPORTED; }
+#define WNV_PICK(NKV, L0V) (mode == 2 ? (const void*)wnv_ring_kernel<NKV, L0V, 2> : mode == 1 ? (const void*)wnv_ring_kernel<NKV, L0V, 1> : (const void*)wnv_ring_kernel<NKV, L0V, 0>)
     const void* kfn = split ? (const void*)wnv_ring_kernel_split
-                    : NK == 1 ? (head_l0 ? (multi ? (const void*)wnv_ring_kernel<1, true, true> : (const void*)wnv_ring_kernel<1, true, false>)
-                                         : (multi ? (const void*)wnv_ring_kernel<1, false, true> : (const void*)wnv_ring_kernel<1, false, false>))
-                    : NK == 2 ? (multi ? (const void*)wnv_ring_kernel<2, false, true> : (const void*)wnv_ring_kernel<2, false, false>)
-                              : (multi ? (const void*)wnv_ring_kernel_k512<true> : (const void*)wnv_ring_kernel_k512<false>);
+                    : NK == 1 ? (head_l0 ? WNV_PICK(1, true) : WNV_PICK(1, false))
+                    : NK == 2 ? WNV_PICK(2, false)
+                              : (mode == 2 ? (const void*)wnv_ring_kernel_k512<2> : mode == 1 ? (const void*)wnv_ring_kernel_k512<1> : (const void*)wnv_ring_kernel_k512<0>);
+#undef WNV_PICK
     RING_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.tap_parts = tap_parts; p.tb = tb;
     const int grid = split ? p.ring_blocks + tap_parts * st->L : p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);

@@ -253,7 +253,7 @@ class Engine:
     def generate(self, *, B: int, T: int, c_up=None, g=None, g_ids=None, initial=None, teacher=None,
                  noise=None, seed: int = 0, softmax: bool = True, quantize: bool = True,
                  want_params: bool = False, want_index: bool = False, kernel: int = 0, asynchronous: bool = False,
-                 noise_ready=None):
+                 noise_ready=None, seg_start=None, seg_uid=None):
         """Runs the whole autoregressive loop.  Returns (out (B,C,T), params (B,O,T)|None, index (B,T)|None).
         ``asynchronous`` (ring kernel chosen explicitly, kernel=2): return right after the launch; ``wait()`` or the next
         call reports a bounded-spin timeout (WNV_GEN_ASYNC in include/wnv.h).  ``noise`` / ``noise_ready`` may be device
@@ -277,6 +277,14 @@ class Engine:
         a.flags = _lib.WNV_GEN_ASYNC if asynchronous else 0
         a.stream = _stream(dev)
         a.noise_ready = _ptr(noise_ready)
+        if (seg_start is None) != (seg_uid is None):
+            raise ValueError("seg_start and seg_uid come together (packed slots, include/wnv.h)")
+        if seg_start is not None:       # packed slots: (B, T) int32 each; raw pointers cross the boundary, so shape / dtype / device are checked here
+            for name, tns in (("seg_start", seg_start), ("seg_uid", seg_uid)):
+                require_gpu_tensor(tns, name)
+                if tns.dtype != torch.int32 or not tns.is_contiguous() or tuple(tns.shape) != (B, T):
+                    raise ValueError(f"{name} must be a contiguous int32 (B, T) = {(B, T)} tensor, got {tns.dtype} {tuple(tns.shape)}")
+            a.seg_start, a.seg_uid = _ptr(seg_start), _ptr(seg_uid)
         check(_lib.lib().wnv_generate(self._h, C.byref(a)))
         return out, params, index
 

@@ -19,7 +19,7 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 __all__ = ["lpt_assign", "pack_groups", "pad_group", "broadcast_weights", "synthesize_sharded", "auto_group_size",
-           "padding_loss", "THROUGHPUT_GROUP"]
+           "padding_loss", "THROUGHPUT_GROUP", "plan_slots", "synthesize_packed"]
 
 # Utterances per launch at which the ring kernel's aggregate rate stops growing.  Round 4 (profiles/r04_final_numbers.txt; kSamples/s
 # per GPU at B = 8 / 16 / 32 / 40 / 48 / 56 / 64): 504 / 1000 / 2014 / 2257 / 2712 / 2388 / 2703 -- up to 32 utterances every utterance advances at
@@ -140,3 +140,69 @@ def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torc
     for part in parts:
         merged.update(part)
     return [merged[i] for i in range(len(mels))]
+
+
+# ---- packed slots: continuous batching ---------------------------------------------------------------------------------------------
+# A padded batch runs to its longest member (evaluate.py:55-57,215): with utterances of 1-8 s a quarter to a third of the samples a GPU
+# makes is padding, whatever the grouping.  The ring kernel does not need that: a ROW of a launch can be a SLOT that runs several
+# utterances back to back (wnv_generate_args.seg_start / seg_uid, ABI 4) -- at a boundary the next utterance starts exactly as
+# incremental_forward starts one (zero history, zero / index-127 first input) and draws its noise from its own stream, so every
+# waveform is what the utterance gives on its own.  The planner below fills THROUGHPUT_GROUP slots longest-first.
+
+def plan_slots(lengths: Sequence[int], n_slots: int) -> List[List[int]]:
+    """Utterance indices per slot, in running order: longest-processing-time-first over ``n_slots`` bins (a slot's cost is the SUM of
+    its utterances' lengths); no more slots than utterances."""
+    n_slots = max(1, min(int(n_slots), len(lengths)))
+    return [b for b in lpt_assign(lengths, n_slots) if b]
+
+
+def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin_pad: int, slots: Optional[int] = None,
+                      seed: Optional[int] = None, indices: Optional[Sequence[int]] = None, stats: Optional[dict] = None,
+                      upsample_batch: int = 32) -> List[torch.Tensor]:
+    """The waveforms (network outputs ``(C, T_i)`` on the model's device, one per mel of ``mels[i] for i in indices``) of a job run as
+    PACKED SLOTS on this process's GPU.  ``model``: an ``EngineHost`` WaveNet on the device, without global conditioning, that the ring
+    kernel covers (otherwise NotImplementedError: the caller falls back to padded groups).  ``slots``: rows of the launch (default
+    THROUGHPUT_GROUP); ``seed``: of the in-kernel noise streams (default: drawn from torch's generator, as ``rng = "philox"`` does)."""
+    if getattr(model, "embed_speakers", None) is not None or int(getattr(model, "gin_channels", -1) or -1) > 0:
+        raise NotImplementedError("packed slots: models with global conditioning keep one bias table per row")
+    idx = list(range(len(mels))) if indices is None else list(indices)
+    if not idx:
+        return []
+    eng = model._get_engine()
+    dev = eng.device
+    cin = int(mels[idx[0]].shape[0])
+    frames = [int(mels[i].shape[-1]) for i in idx]
+    lengths = [f * hop_size for f in frames]
+    bins = plan_slots(lengths, THROUGHPUT_GROUP if slots is None else slots)          # positions into idx
+    n, T = len(bins), max(sum(lengths[k] for k in b) for b in bins)
+    c_slot = torch.zeros(n, T, cin, device=dev, dtype=torch.float32)
+    seg_start = torch.zeros(n, T, dtype=torch.int32)
+    seg_uid = torch.zeros(n, T, dtype=torch.int32)
+    where = {}
+    for s, b in enumerate(bins):
+        off = 0
+        for k in b:
+            where[k] = (s, off)
+            seg_start[s, off:] = off            # (the tail of a slot that ends early keeps its last utterance running: ignored)
+            seg_uid[s, off:] = idx[k]
+            off += lengths[k]
+    # the conditioning of every utterance, upsampled in padded groups of neighbouring length, copied to its place in its slot
+    order = sorted(range(len(idx)), key=lambda k: -frames[k])
+    for a in range(0, len(order), upsample_batch):
+        grp = order[a:a + upsample_batch]
+        c = pad_group([mels[idx[k]] for k in grp], cin_pad).to(dev)
+        cu = eng.upsample(c, T_expected=max(lengths[k] for k in grp))               # (B, T_max, cin) time-major
+        for row, k in enumerate(grp):
+            s, off = where[k]
+            c_slot[s, off:off + lengths[k]] = cu[row, :lengths[k]]
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    out, _, _ = eng.generate(B=n, T=T, c_up=c_slot, seed=seed, seg_start=seg_start.to(dev), seg_uid=seg_uid.to(dev), kernel=0)
+    if stats is not None:
+        stats.update(slots=n, slot_steps=T, true_samples=sum(lengths), padded_samples=n * T,
+                     padding_loss=1.0 - sum(lengths) / float(n * T), utterances_per_slot=[len(b) for b in bins])
+    res = []
+    for k in range(len(idx)):
+        s, off = where[k]
+        res.append(out[s, :, off:off + lengths[k]])
+    return res
