@@ -508,10 +508,10 @@ def main():
             "ranks": ranks,
         }
         if world == 1 and args.batch == B_PER_GPU and args.workload == WORKLOAD and not args.no_extras:
-            # informative only (not `value`): the same kernel with 32 utterances per GPU -- the rings pipeline four
+            # informative only (not `value`): the same kernel with 48 utterances per GPU -- the rings pipeline six
             # utterances each like a systolic array (DESIGN.md 5.2 "Throughput vs. batch")
             try:
-                B2, T2 = 32, 8192
+                B2, T2 = 48, 8192                      # (round 4: the plateau moved from 32 to 48 utterances per GPU)
                 c2, g2 = inputs(name, B2, T2, seed=7)
                 c2 = c2.to(dev)
                 eng.generate(B=B2, T=T2, c_up=eng.upsample(c2, T_expected=T2), seed=1, kernel=args.kernel)

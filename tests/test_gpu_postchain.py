@@ -119,3 +119,36 @@ def test_evaluate_directory_loop_end_to_end(tmp_path):
         assert rate == 24000 and w.dtype == np.int16 and len(w) == (frames[i] + 4) * 256
         assert np.abs(w.astype(np.int32)).max() <= 32767 and w.std() > 0
         assert np.array_equal(w, outs[1][i][1]), "same seed, same files"
+
+
+def test_evaluate_directory_loop_packed_slots(tmp_path, capsys):
+    """The same loop with nothing fixing the grouping: the job runs as PACKED SLOTS (continuous batching) -- right lengths, clipped
+    int16, deterministic under a fixed torch seed, the post-chain applied per utterance (an utterance's file does not depend on what
+    shared its slot: the job of five and the job of its first three -- same longest member, so the same zero-padded conditioning
+    batch, evaluate.py:55-57 -- give the same first three files)."""
+    from scipy.io import wavfile
+    from tests._configs import build
+    from wavenet_vocoder_amd import evaluate as E
+    rng = np.random.default_rng(1)
+    frames = [9, 5, 12, 7, 5]
+    for i, f in enumerate(frames):
+        np.save(tmp_path / f"utt{i:02d}-feats.npy", rng.standard_normal((f + 4, 80)).astype(np.float32))
+    m = build("cfg2_mol").to("cuda")
+    h = hp(cin_channels=80, cin_pad=2, hop_size=256, batch_size=None, sample_rate=24000)
+    outs = []
+    for run in range(2):
+        torch.manual_seed(321)
+        paths = E.synthesize_dir(m, str(tmp_path), str(tmp_path / f"out{run}"), h)
+        outs.append([wavfile.read(p)[1] for p in paths])
+    assert "falling back" not in capsys.readouterr().out
+    for i, w in enumerate(outs[0]):
+        assert w.dtype == np.int16 and len(w) == (frames[i] + 4) * 256 and w.std() > 0
+        assert np.array_equal(w, outs[1][i])
+    torch.manual_seed(321)
+    part = [wavfile.read(p)[1] for p in E.synthesize_dir(m, str(tmp_path), str(tmp_path / "out_part"), h, num_utterances=3)]
+    for i in range(3):
+        assert np.array_equal(part[i], outs[0][i]), "an utterance's waveform depends on its own conditioning, id and the seed only"
+    # a speaker-embedding model is not packed: padded groups, silently
+    m4 = build("cfg4_mol_multispeaker").to("cuda")
+    paths = E.synthesize_dir(m4, str(tmp_path), str(tmp_path / "out4"), h, speaker_id=2, num_utterances=2)
+    assert len(paths) == 2

@@ -92,14 +92,57 @@ def write_wav(path: str, sample_rate: int, pcm: np.ndarray) -> None:
         f.write(data)
 
 
+def _synthesize_packed(model, mels, hparams, group):
+    """The job as packed slots: every rank packs its share (longest-first over the ranks), the post-chain of synthesis.py:66-84 runs
+    per UTTERANCE (the inverse pre-emphasis is an IIR: its state must not leak across a slot's boundaries) on padded batches of the
+    finished waveforms, rank 0 gathers.  Returns the list of clipped float waveforms on rank 0, None elsewhere."""
+    import torch.distributed as dist
+    from . import synthesis
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
+    model.eval()
+    lengths = [int(m.shape[-1]) * hparams.hop_size for m in mels]
+    mine = sharding.lpt_assign(lengths, world)[rank]
+    with torch.no_grad():
+        outs = sharding.synthesize_packed(model, mels, hop_size=hparams.hop_size, cin_pad=hparams.cin_pad, indices=mine)
+    local = {}
+    order = sorted(range(len(mine)), key=lambda k: -lengths[mine[k]])
+    for a in range(0, len(order), 32):                              # post-chain on padded batches of neighbouring length
+        grp = order[a:a + 32]
+        Tm = max(lengths[mine[k]] for k in grp)
+        y = torch.zeros(len(grp), outs[grp[0]].shape[0], Tm, device=outs[grp[0]].device)
+        for row, k in enumerate(grp):
+            y[row, :, :lengths[mine[k]]] = outs[k]
+        wav = synthesis.postprocess(y, hparams).clamp_(-1.0, 1.0)
+        for row, k in enumerate(grp):
+            local[mine[k]] = wav[row, :lengths[mine[k]]].detach().to("cpu")
+    if not distributed:
+        return [local[i] for i in range(len(mels))]
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(local, parts, dst=0, group=group)
+    if rank != 0:
+        return None
+    merged = {}
+    for part in parts:
+        merged.update(part)
+    return [merged[i] for i in range(len(mels))]
+
+
 def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterances: int = -1,
                    speaker_id: Optional[int] = None, group=None,
-                   synth_group: Optional[Callable[[torch.Tensor, List[int]], torch.Tensor]] = None) -> List[str]:
+                   synth_group: Optional[Callable[[torch.Tensor, List[int]], torch.Tensor]] = None,
+                   packed: Optional[bool] = None) -> List[str]:
     """The main loop of evaluate.py (:155-251) without reference wavs: every ``*-feats.npy`` under ``data_dir`` becomes
     ``dst_dir/{name}_gen.wav``.  Utterances are sharded over the ranks of ``group`` (one process per GPU); rank 0
     writes the files and returns their paths (other ranks return []).  Utterances per launch: ``hparams.batch_size`` when it is
     set (the reference's recipes pass 32, egs/mol/run.sh:31), otherwise from the measured throughput curve
-    (``sharding.auto_group_size``: up to 32 per GPU)."""
+    (``sharding.auto_group_size``: up to 48 per GPU).
+
+    ``packed`` (round 4): run the job as PACKED SLOTS -- continuous batching, ``sharding.synthesize_packed``: no padding to a group's
+    longest member, every waveform is what the utterance gives on its own -- instead of padded groups.  None (default): when nothing
+    fixes the grouping (no ``synth_group``, no ``hparams.batch_size``), the model has no speaker embedding and the ring kernel takes
+    it; a model or device the packed path does not cover falls back to padded groups."""
     from . import synthesis
     utts = collect_features(data_dir, speaker_id=speaker_id, num_utterances=num_utterances)
     assert len(utts) > 0, f"no *-feats.npy under {data_dir}"
@@ -112,8 +155,20 @@ def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterance
         wav = synthesis.batch_wavegen(model, c=c, g=g, hparams=hparams)          # (B, T) float32, post-chain applied
         return torch.from_numpy(np.clip(wav, -1.0, 1.0))                         # evaluate.py:238
 
-    wavs = sharding.synthesize_sharded(mels, synth_group or default_group, hop_size=hparams.hop_size,
-                                       cin_pad=hparams.cin_pad, group_size=getattr(hparams, "batch_size", None), group=group)
+    wavs = None
+    if packed is None:
+        packed = synth_group is None and getattr(hparams, "batch_size", None) is None and not model.has_speaker_embedding() \
+            and next(model.parameters()).is_cuda
+    if packed:
+        try:
+            wavs = _synthesize_packed(model, mels, hparams, group)
+        except (NotImplementedError, TimeoutError) as e:          # not a ring configuration / the ring does not fit: padded groups
+            print(f"[wnv] packed slots not used ({str(e)[:120]}); falling back to padded groups", flush=True)
+            wavs = None
+            packed = False
+    if not packed:
+        wavs = sharding.synthesize_sharded(mels, synth_group or default_group, hop_size=hparams.hop_size,
+                                           cin_pad=hparams.cin_pad, group_size=getattr(hparams, "batch_size", None), group=group)
     if wavs is None:
         return []
     os.makedirs(dst_dir, exist_ok=True)
