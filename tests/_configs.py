@@ -24,6 +24,10 @@ CONFIGS = {
     "cfg3_gaussian": dict(out_channels=2, layers=24, stacks=4, residual_channels=128, gate_channels=256,
                           skip_out_channels=128, kernel_size=3, dropout=0.0, scalar_input=True,
                           output_distribution="Normal", **MEL),
+    # cfg3b: egs/gaussian as BASELINE.json words it: 30 layers / 3 stacks (dilation up to 512)
+    "cfg3b_gaussian30": dict(out_channels=2, layers=30, stacks=3, residual_channels=128, gate_channels=256,
+                             skip_out_channels=128, kernel_size=3, dropout=0.0, scalar_input=True,
+                             output_distribution="Normal", **MEL),
     # cfg4: MoL + global speaker embedding, 512 skip channels
     "cfg4_mol_multispeaker": dict(out_channels=30, layers=24, stacks=4, residual_channels=128, gate_channels=256,
                                   skip_out_channels=512, kernel_size=3, dropout=0.0, scalar_input=True,

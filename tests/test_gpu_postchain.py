@@ -148,7 +148,3 @@ def test_evaluate_directory_loop_packed_slots(tmp_path, capsys):
     part = [wavfile.read(p)[1] for p in E.synthesize_dir(m, str(tmp_path), str(tmp_path / "out_part"), h, num_utterances=3)]
     for i in range(3):
         assert np.array_equal(part[i], outs[0][i]), "an utterance's waveform depends on its own conditioning, id and the seed only"
-    # a speaker-embedding model is not packed: padded groups, silently
-    m4 = build("cfg4_mol_multispeaker").to("cuda")
-    paths = E.synthesize_dir(m4, str(tmp_path), str(tmp_path / "out4"), h, speaker_id=2, num_utterances=2)
-    assert len(paths) == 2
