@@ -42,6 +42,23 @@ def test_packed_slots_reproduce_the_padded_batch(name, slots):
     m.to("cpu")
 
 
+def test_a_long_job_runs_as_several_launches_with_the_same_waveforms():
+    """``max_slot_steps`` bounds a launch (the slots' conditioning is resident): the split changes nothing an utterance can see."""
+    m = build("cfg2_mol").to("cuda")
+    mels = job(14, 80, 3, lo=6, hi=12)
+    one = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=5)
+    st = {}
+    many = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=5, max_slot_steps=6000, stats=st)
+    assert len(st["launches"]) >= 3
+    # (the conditioning is upsampled in padded groups of neighbours, as the reference's padded batches are: an utterance that is not the
+    #  longest of its group sees zeros behind its last frame instead of its replicated edge -- the last cin_pad frames and the FIR
+    #  half-widths of its conditioning depend on its neighbours; everything before that is equal, sample for sample)
+    for a, b in zip(one, many):
+        n = a.shape[-1] - 4 * HOP
+        assert n > 0 and torch.equal(a[..., :n], b[..., :n])
+    m.to("cpu")
+
+
 def test_packed_slots_refuse_what_they_do_not_cover():
     m = build("cfg4_mol_multispeaker").to("cuda")                # a speaker embedding: one bias table per row
     with pytest.raises(NotImplementedError):

@@ -138,13 +138,13 @@ def test_evaluate_directory_loop_packed_slots(tmp_path, capsys):
     outs = []
     for run in range(2):
         torch.manual_seed(321)
-        paths = E.synthesize_dir(m, str(tmp_path), str(tmp_path / f"out{run}"), h)
+        paths = E.synthesize_dir(m, str(tmp_path), str(tmp_path / f"out{run}"), h, packed=True)
         outs.append([wavfile.read(p)[1] for p in paths])
     assert "falling back" not in capsys.readouterr().out
     for i, w in enumerate(outs[0]):
         assert w.dtype == np.int16 and len(w) == (frames[i] + 4) * 256 and w.std() > 0
         assert np.array_equal(w, outs[1][i])
     torch.manual_seed(321)
-    part = [wavfile.read(p)[1] for p in E.synthesize_dir(m, str(tmp_path), str(tmp_path / "out_part"), h, num_utterances=3)]
+    part = [wavfile.read(p)[1] for p in E.synthesize_dir(m, str(tmp_path), str(tmp_path / "out_part"), h, num_utterances=3, packed=True)]
     for i in range(3):
         assert np.array_equal(part[i], outs[0][i]), "an utterance's waveform depends on its own conditioning, id and the seed only"

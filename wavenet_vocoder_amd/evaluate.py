@@ -156,9 +156,11 @@ def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterance
         return torch.from_numpy(np.clip(wav, -1.0, 1.0))                         # evaluate.py:238
 
     wavs = None
-    if packed is None:
+    if packed is None:                                    # (nothing to pack while every utterance can have a row of its own)
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         packed = synth_group is None and getattr(hparams, "batch_size", None) is None and not model.has_speaker_embedding() \
-            and next(model.parameters()).is_cuda
+            and next(model.parameters()).is_cuda and len(mels) > sharding.THROUGHPUT_GROUP * world
     if packed:
         try:
             wavs = _synthesize_packed(model, mels, hparams, group)

@@ -158,22 +158,58 @@ def plan_slots(lengths: Sequence[int], n_slots: int) -> List[List[int]]:
 
 def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin_pad: int, slots: Optional[int] = None,
                       seed: Optional[int] = None, indices: Optional[Sequence[int]] = None, stats: Optional[dict] = None,
-                      upsample_batch: int = 32) -> List[torch.Tensor]:
+                      upsample_batch: int = 32, max_slot_steps: int = 1 << 20) -> List[torch.Tensor]:
     """The waveforms (network outputs ``(C, T_i)`` on the model's device, one per mel of ``mels[i] for i in indices``) of a job run as
     PACKED SLOTS on this process's GPU.  ``model``: an ``EngineHost`` WaveNet on the device, without global conditioning, that the ring
-    kernel covers (otherwise NotImplementedError: the caller falls back to padded groups).  ``slots``: rows of the launch (default
-    THROUGHPUT_GROUP); ``seed``: of the in-kernel noise streams (default: drawn from torch's generator, as ``rng = "philox"`` does)."""
+    kernel covers (otherwise NotImplementedError: the caller falls back to padded groups).  ``slots``: rows of a launch (default
+    THROUGHPUT_GROUP); ``seed``: of the in-kernel noise streams (default: drawn from torch's generator, as ``rng = "philox"`` does).
+    A job longer than ``slots x max_slot_steps`` samples runs as several launches (the slots' conditioning is resident for a launch:
+    320 bytes per sample -- 16 GB at the default bound of 2**20 steps x 48 slots); an utterance's noise stream does not depend on that."""
     if getattr(model, "embed_speakers", None) is not None or int(getattr(model, "gin_channels", -1) or -1) > 0:
         raise NotImplementedError("packed slots: models with global conditioning keep one bias table per row")
     idx = list(range(len(mels))) if indices is None else list(indices)
     if not idx:
         return []
+    n_slots = THROUGHPUT_GROUP if slots is None else int(slots)
+    if seed is None:
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    lengths_all = [int(mels[i].shape[-1]) * hop_size for i in idx]
+    # launches: longest first, a launch closes when its slots would have to run more than max_slot_steps steps on average
+    order = sorted(range(len(idx)), key=lambda k: (-lengths_all[k], k))
+    launches, cur, tot = [], [], 0
+    for k in order:
+        if cur and (tot + lengths_all[k]) > n_slots * max_slot_steps:
+            launches.append(cur)
+            cur, tot = [], 0
+        cur.append(k)
+        tot += lengths_all[k]
+    launches.append(cur)
+    res: List[Optional[torch.Tensor]] = [None] * len(idx)
+    agg = dict(slots=0, slot_steps=0, true_samples=0, padded_samples=0, utterances_per_slot=[], launches=[])
+    for members in launches:
+        out_m, st_m = _packed_launch(model, mels, [idx[k] for k in members], hop_size, cin_pad, n_slots, seed, upsample_batch)
+        for k, y in zip(members, out_m):
+            res[k] = y
+        agg["slots"] = max(agg["slots"], st_m["slots"])
+        agg["slot_steps"] += st_m["slot_steps"]
+        agg["true_samples"] += st_m["true_samples"]
+        agg["padded_samples"] += st_m["padded_samples"]
+        agg["utterances_per_slot"] += st_m["utterances_per_slot"]
+        agg["launches"].append((st_m["slots"], st_m["slot_steps"]))
+    if stats is not None:
+        agg["padding_loss"] = 1.0 - agg["true_samples"] / float(max(agg["padded_samples"], 1))
+        stats.update(agg)
+    return res
+
+
+def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, upsample_batch):
+    """One launch of packed slots over the utterances ``ids`` (indices into ``mels``, which are also their ids in the job)."""
     eng = model._get_engine()
     dev = eng.device
-    cin = int(mels[idx[0]].shape[0])
-    frames = [int(mels[i].shape[-1]) for i in idx]
+    cin = int(mels[ids[0]].shape[0])
+    frames = [int(mels[i].shape[-1]) for i in ids]
     lengths = [f * hop_size for f in frames]
-    bins = plan_slots(lengths, THROUGHPUT_GROUP if slots is None else slots)          # positions into idx
+    bins = plan_slots(lengths, n_slots)                                               # positions into ids
     n, T = len(bins), max(sum(lengths[k] for k in b) for b in bins)
     c_slot = torch.zeros(n, T, cin, device=dev, dtype=torch.float32)
     seg_start = torch.zeros(n, T, dtype=torch.int32)
@@ -184,25 +220,22 @@ def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin
         for k in b:
             where[k] = (s, off)
             seg_start[s, off:] = off            # (the tail of a slot that ends early keeps its last utterance running: ignored)
-            seg_uid[s, off:] = idx[k]
+            seg_uid[s, off:] = ids[k]
             off += lengths[k]
-    # the conditioning of every utterance, upsampled in padded groups of neighbouring length, copied to its place in its slot
-    order = sorted(range(len(idx)), key=lambda k: -frames[k])
+    # the conditioning of every utterance, upsampled in padded groups of neighbouring length (as the reference's padded batches,
+    # evaluate.py:55-57,163-164), copied to its place in its slot
+    order = sorted(range(len(ids)), key=lambda k: -frames[k])
     for a in range(0, len(order), upsample_batch):
         grp = order[a:a + upsample_batch]
-        c = pad_group([mels[idx[k]] for k in grp], cin_pad).to(dev)
+        c = pad_group([mels[ids[k]] for k in grp], cin_pad).to(dev)
         cu = eng.upsample(c, T_expected=max(lengths[k] for k in grp))               # (B, T_max, cin) time-major
         for row, k in enumerate(grp):
             s, off = where[k]
             c_slot[s, off:off + lengths[k]] = cu[row, :lengths[k]]
-    if seed is None:
-        seed = int(torch.empty((), dtype=torch.int64).random_().item())
     out, _, _ = eng.generate(B=n, T=T, c_up=c_slot, seed=seed, seg_start=seg_start.to(dev), seg_uid=seg_uid.to(dev), kernel=0)
-    if stats is not None:
-        stats.update(slots=n, slot_steps=T, true_samples=sum(lengths), padded_samples=n * T,
-                     padding_loss=1.0 - sum(lengths) / float(n * T), utterances_per_slot=[len(b) for b in bins])
+    st = dict(slots=n, slot_steps=T, true_samples=sum(lengths), padded_samples=n * T, utterances_per_slot=[len(b) for b in bins])
     res = []
-    for k in range(len(idx)):
+    for k in range(len(ids)):
         s, off = where[k]
-        res.append(out[s, :, off:off + lengths[k]])
-    return res
+        res.append(out[s, :, off:off + lengths[k]].clone())                          # (a copy: the launch's output buffer goes away)
+    return res, st
