@@ -49,7 +49,7 @@ def test_a_long_job_runs_as_several_launches_with_the_same_waveforms():
     one = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=5)
     st = {}
     many = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=5, max_slot_steps=6000, stats=st)
-    assert len(st["launches"]) >= 3
+    assert len(st["launches"]) >= 2
     # (the conditioning is upsampled in padded groups of neighbours, as the reference's padded batches are: an utterance that is not the
     #  longest of its group sees zeros behind its last frame instead of its replicated edge -- the last cin_pad frames and the FIR
     #  half-widths of its conditioning depend on its neighbours; everything before that is equal, sample for sample)
