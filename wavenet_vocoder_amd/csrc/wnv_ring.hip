@@ -480,6 +480,9 @@ __device__ __forceinline__ void ts_flush(const RingParams& p, int b, int t, int 
         if ((mask >> k) & 1u) row[k + shift] = tsv[k];
 }
 #define WNV_TS_DECL unsigned long long tsv[TRW] = {0}
+#ifndef WNV_TRACE_TAP_LAYER
+#define WNV_TRACE_TAP_LAYER 6           // the tap workgroup whose passes are stamped (6: dilation 1 in the 24-layer models)
+#endif
 #define WNV_TS(k) (tsv[k] = __builtin_amdgcn_s_memrealtime())
 // the less important stamps: every live stamp is an SGPR pair in a kernel that has none to spare (with all of them the trace build
 // spills vector registers in its hot loops and runs 25 % slower than the product): -DWNV_FINE_TRACE=2 turns them on
@@ -781,7 +784,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         const int kfresh = fresh_tap(tf);
 #ifdef WNV_FINE_TRACE
 #define TAP_STAMP(k) do { const int pk_ = (b0 - bfirst) / pstride; \
-                          if (p.trace_tap && l == 6 && part == 0 && pk_ < 3 && (k) < 5 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
+                          if (p.trace_tap && l == WNV_TRACE_TAP_LAYER && part == 0 && pk_ < 3 && (k) < 5 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
                               p.trace_tap[(size_t)(t - p.trace_t0) * TRW + 5 * pk_ + (k)] = wall_clock64(); } while (0)
 #else
 #define TAP_STAMP(k) ((void)0)
