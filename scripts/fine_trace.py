@@ -55,7 +55,10 @@ for t in steps[1:-1]:
     nxt = get(t + 1, S) if t + 1 in steps else None
     last = st[S - 1]
     if nxt and hd[3] >= 0 and hd[4] >= 0:
-        for k, x in dict(head_hidden=hd[3] - hd[1], head_out=hd[4] - hd[3], head_sample_send=nxt[0] - hd[4]).items():
+        d = dict(head_hidden=hd[3] - hd[1], head_out=hd[4] - hd[3], head_sample_send=nxt[0] - hd[4])
+        if hd[5] >= 0 and hd[6] >= 0 and hd[7] >= 0:      # the categorical head: partial outputs collected | logits in LDS | class sampled
+            d.update(head_collect=hd[5] - hd[4], head_logits_barrier=hd[6] - hd[5], head_sample=hd[7] - hd[6], head_send=nxt[0] - hd[7])
+        for k, x in d.items():
             acc.setdefault(k, []).append(x)
     first = st[min(st)]
     e = dict(head_skip_hop=sub(hd[1] - base, last["v"][3]), head_mlp_sample=(nxt[0] - hd[1]) if nxt else None, first_hop=first["v"][8], step=(nxt[0] - hd[0]) if nxt else None)

@@ -1977,16 +1977,19 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
             WNV_TS(1);
             head_hidden<NK, 2>(w, s.vs, s.hid, q, i);
             __syncthreads();
+            WNV_TSX(3);
             float x[32];
             lds_read32(s.hid + QS * q, x);
             float oa = quad_allreduce(dot32p(w.wh2[0], x));                       // wavenet.py:319, rows i and 128 + i
             float ob = quad_allreduce(dot32p(w.wh2[1], x));
+            WNV_TSX(4);
             if (NK > 1) {
                 const bool act[2] = {q == 0 && i < O, q == 0 && RC + i < O};
                 float ov[2] = {oa, ob};
                 if (!head_collect<2>(p, b, tag, i, act, ov, lane)) s.ints[0] = 1;
                 oa = ov[0]; ob = ov[1];
             }
+            WNV_TSX(5);
             oa += bh2a; ob += bh2b;
             if (q == 0) {
                 if (i < O) { s.obuf[i] = oa; if (p.params_out) p.params_out[((size_t)b * O + i) * p.T + t] = oa; }
@@ -1996,8 +1999,10 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
             // wavenet.py:332-335, then :297-308 for step t + 1.  Waves 0 and 1 each sample on their own (same inputs, same class) and send
             // their 64 channels of first_conv's row at once: no barrier and no LDS round trip between the argmax and the chain store
             const bool dense_next = t + 1 < p.Tt || !p.quantize;
+            WNV_TSX(6);
             if (wave < (p.quantize ? 2 : 1)) {              // (quantize = False: the probabilities go back into obuf -- one wave)
                 const int idx = sample_categorical(O, s.obuf, s.nzb, p.softmax, p.quantize, lane);
+                WNV_TSX(7);
                 if (p.quantize) {
                     if (t + 1 < p.T && !dense_next) {
                         // (a new utterance begins with the one-hot vector of class 127: wavenet.py:284-289)
@@ -2019,7 +2024,9 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
                 WNV_TS(0);
             }
             WNV_TS(2);
-            if (wave == 0) { WNV_TS_FLUSH(b, t, p.S, 0x6u, 0); WNV_TS_FLUSH(b, t + 1, p.S, 0x1u, 0); }   // 0 input of step t+1 sent | 1 skip sum in LDS | 2 step done
+            // 0 input of step t+1 sent | 1 skip sum in LDS | 2 step done | 3 hidden half in LDS | 4 own partial outputs | 5 the other parts' collected |
+            // 6 logits in LDS | 7 class sampled
+            if (wave == 0) { WNV_TS_FLUSH(b, t, p.S, 0xFEu, 0); WNV_TS_FLUSH(b, t + 1, p.S, 0x1u, 0); }
             if (s.ints[0]) return;
         }
     }
