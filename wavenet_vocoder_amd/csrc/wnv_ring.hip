@@ -1983,25 +1983,62 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
             float oa = quad_allreduce(dot32p(w.wh2[0], x));                       // wavenet.py:319, rows i and 128 + i
             float ob = quad_allreduce(dot32p(w.wh2[1], x));
             WNV_TSX(4);
+            // (fastcat, below: lane q = 0 of a quad finishes class i, lane q = 1 class 128 + i -- each collects only its own row)
+            const bool fastcat = p.quantize && p.softmax && O <= 256;
+            const int q2 = fastcat ? 1 : 0;                                          // the lane of the quad that owns row 128 + i
             if (NK > 1) {
-                const bool act[2] = {q == 0 && i < O, q == 0 && RC + i < O};
+                const bool act[2] = {q == 0 && i < O, q == q2 && RC + i < O};
                 float ov[2] = {oa, ob};
                 if (!head_collect<2>(p, b, tag, i, act, ov, lane)) s.ints[0] = 1;
                 oa = ov[0]; ob = ov[1];
             }
             WNV_TSX(5);
             oa += bh2a; ob += bh2b;
-            if (q == 0) {
-                if (i < O) { s.obuf[i] = oa; if (p.params_out) p.params_out[((size_t)b * O + i) * p.T + t] = oa; }
-                if (RC + i < O) { s.obuf[RC + i] = ob; if (p.params_out) p.params_out[((size_t)b * O + RC + i) * p.T + t] = ob; }
+            if (p.params_out) {
+                if (q == 0 && i < O) p.params_out[((size_t)b * O + i) * p.T + t] = oa;
+                if (q == q2 && RC + i < O) p.params_out[((size_t)b * O + RC + i) * p.T + t] = ob;
+            }
+            // wavenet.py:332-335, then :297-308 for step t + 1.
+            // SOFTMAX + MULTINOMIAL SPREAD OVER THE WORKGROUP (round 4).  After the quad reduce every lane of a quad holds the logits of
+            // classes i and 128 + i: lane q = 0 takes the first, q = 1 the second -- one class per lane, 32 per wave.  Wave maxima meet in LDS
+            // (maxima commute: the same maximum as one wave finds), every lane forms ITS exponential, the exponentials go to LDS and waves
+            // 0 / 1 finish with categorical_tail() -- the arithmetic of sample_categorical() on the same values in the same order.  (Until
+            // round 4 one wave did all of it, four classes per lane: 1.35 us of a 19.9 us step sat in that wave's ~340 dependent VALU
+            // instructions, profiles/r04_onehot_head_timeline.txt.)
+            if (fastcat) {
+                const int cls = q == 0 ? i : RC + i;
+                const bool mine = q < 2 && cls < O;
+                const float lg = mine ? (q == 0 ? oa : ob) : -INFINITY;
+                const float mw = wave_max(lg);
+                if (lane == 0) s.part[wave] = mw;
+                __syncthreads();
+                const float4 ma = *reinterpret_cast<const float4*>(s.part), mb = *reinterpret_cast<const float4*>(s.part + 4);
+                const float mx = fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w)));
+                if (mine) s.obuf[cls] = expf(lg - mx);
+            } else if (q == 0) {
+                if (i < O) s.obuf[i] = oa;
+                if (RC + i < O) s.obuf[RC + i] = ob;
             }
             __syncthreads();
-            // wavenet.py:332-335, then :297-308 for step t + 1.  Waves 0 and 1 each sample on their own (same inputs, same class) and send
-            // their 64 channels of first_conv's row at once: no barrier and no LDS round trip between the argmax and the chain store
+            // Waves 0 and 1 each sample on their own (same inputs, same class) and send their 64 channels of first_conv's row at once:
+            // no barrier and no LDS round trip between the argmax and the chain store
             const bool dense_next = t + 1 < p.Tt || !p.quantize;
             WNV_TSX(6);
             if (wave < (p.quantize ? 2 : 1)) {              // (quantize = False: the probabilities go back into obuf -- one wave)
-                const int idx = sample_categorical(O, s.obuf, s.nzb, p.softmax, p.quantize, lane);
+                int idx;
+                if (fastcat) {
+                    float x[4], e[4];
+                    bool on[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        on[k] = lane + 64 * k < O;
+                        x[k] = on[k] ? s.obuf[lane + 64 * k] : 0.f;
+                        e[k] = on[k] ? s.nzb[lane + 64 * k] : 1.f;
+                    }
+                    idx = categorical_tail(x, e, on, lane);
+                } else {
+                    idx = sample_categorical(O, s.obuf, s.nzb, p.softmax, p.quantize, lane);
+                }
                 WNV_TSX(7);
                 if (p.quantize) {
                     if (t + 1 < p.T && !dense_next) {

@@ -68,6 +68,33 @@ __device__ __forceinline__ float sample_scalar(int dist, int O, const float* obu
     return fminf(fmaxf(x, -1.0f), 1.0f);                                        // mixture.py:154 / :269
 }
 
+// The part of sample_categorical (O <= 256, softmax and quantize) behind the exponentials: a lane holds x[k] = exp(logit - max) and the
+// noise e[k] of its classes lane + 64 k.  Softmax normalisation (wavenet.py:332), Categorical's renormalisation, multinomial's
+// argmax(p_hat / e).  Shared with the ring's categorical head, which computes the exponentials with all its waves (one class per lane)
+// and hands them over through LDS: the same operations on the same values in the same order.
+__device__ __forceinline__ int categorical_tail(float (&x)[4], const float (&e)[4], const bool (&on)[4], int lane) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (on[k]) s += x[k];
+    s = wave_sum(s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (on[k]) x[k] = x[k] / s;
+    float s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (on[k]) s2 += x[k];
+    s2 = wave_sum(s2);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (!on[k]) continue;
+        const float q = (x[k] / s2) / e[k];
+        if (q > best) { best = q; bi = lane + 64 * k; }
+    }
+    wave_argmax(best, bi);
+    return bi;
+}
+
 // categorical outputs.  Turns obuf into probabilities in place (when softmax) and returns the sampled
 // class (when quantize), else -1.
 __device__ __forceinline__ int sample_categorical(int O, float* obuf, const float* nzv,
@@ -91,7 +118,10 @@ __device__ __forceinline__ int sample_categorical(int O, float* obuf, const floa
             mx = wave_max(mx);
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (on[k]) { x[k] = expf(x[k] - mx); s += x[k]; }
+            for (int k = 0; k < 4; ++k) if (on[k]) x[k] = expf(x[k] - mx);
+            if (quantize) return categorical_tail(x, e, on, lane);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (on[k]) s += x[k];
             s = wave_sum(s);
 #pragma unroll
             for (int k = 0; k < 4; ++k) if (on[k]) { x[k] = x[k] / s; if (!quantize) obuf[lane + 64 * k] = x[k]; }   // (quantize: nobody reads them,
