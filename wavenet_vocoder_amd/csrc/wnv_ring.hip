@@ -2000,42 +2000,45 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
             }
             // wavenet.py:332-335, then :297-308 for step t + 1.
             // SOFTMAX + MULTINOMIAL SPREAD OVER THE WORKGROUP (round 4).  After the quad reduce every lane of a quad holds the logits of
-            // classes i and 128 + i: lane q = 0 takes the first, q = 1 the second -- one class per lane, 32 per wave.  Wave maxima meet in LDS
-            // (maxima commute: the same maximum as one wave finds), every lane forms ITS exponential, the exponentials go to LDS and waves
-            // 0 / 1 finish with categorical_tail() -- the arithmetic of sample_categorical() on the same values in the same order.  (Until
-            // round 4 one wave did all of it, four classes per lane: 1.35 us of a 19.9 us step sat in that wave's ~340 dependent VALU
-            // instructions, profiles/r04_onehot_head_timeline.txt.)
+            // classes i and 128 + i: lane q = 0 takes the first, q = 1 the second -- one class per lane, 32 per wave.  The wave maxima meet
+            // in LDS, every lane forms exp(logit - max) / e of ITS class (sample_categorical's arithmetic, wnv_sample.h: the normalising sums
+            // are common factors the argmax does not see), the waves' best (value, class) pairs meet in LDS and every sending wave picks the
+            // winner -- smallest class among equals.  (Until round 4 one wave did all of it, four classes per lane, with both
+            // normalisations: 1.35 us of a 19.9 us step, profiles/r04_onehot_head_timeline.txt.)
             if (fastcat) {
                 const int cls = q == 0 ? i : RC + i;
                 const bool mine = q < 2 && cls < O;
                 const float lg = mine ? (q == 0 ? oa : ob) : -INFINITY;
+                const float ek = mine ? s.nzb[cls] : 1.f;
                 const float mw = wave_max(lg);
                 if (lane == 0) s.part[wave] = mw;
                 __syncthreads();
                 const float4 ma = *reinterpret_cast<const float4*>(s.part), mb = *reinterpret_cast<const float4*>(s.part + 4);
                 const float mx = fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w)));
-                if (mine) s.obuf[cls] = expf(lg - mx);
+                float best = mine ? expf(lg - mx) / ek : -INFINITY;
+                int bi = mine ? cls : 0x7fffffff;
+                wave_argmax(best, bi);
+                if (lane == 0) { s.part[8 + wave] = best; s.part[16 + wave] = __int_as_float(bi); }
             } else if (q == 0) {
                 if (i < O) s.obuf[i] = oa;
                 if (RC + i < O) s.obuf[RC + i] = ob;
             }
             __syncthreads();
-            // Waves 0 and 1 each sample on their own (same inputs, same class) and send their 64 channels of first_conv's row at once:
-            // no barrier and no LDS round trip between the argmax and the chain store
+            // Waves 0 and 1 each pick / sample on their own (same inputs, same class) and send their 64 channels of first_conv's row at
+            // once: no barrier and no LDS round trip between the argmax and the chain store
             const bool dense_next = t + 1 < p.Tt || !p.quantize;
             WNV_TSX(6);
             if (wave < (p.quantize ? 2 : 1)) {              // (quantize = False: the probabilities go back into obuf -- one wave)
                 int idx;
                 if (fastcat) {
-                    float x[4], e[4];
-                    bool on[4];
+                    float bv = s.part[8];
+                    idx = __float_as_int(s.part[16]);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        on[k] = lane + 64 * k < O;
-                        x[k] = on[k] ? s.obuf[lane + 64 * k] : 0.f;
-                        e[k] = on[k] ? s.nzb[lane + 64 * k] : 1.f;
+                    for (int k = 1; k < RW; ++k) {
+                        const float v = s.part[8 + k];
+                        const int c = __float_as_int(s.part[16 + k]);
+                        if (v > bv || (v == bv && c < idx)) { bv = v; idx = c; }
                     }
-                    idx = categorical_tail(x, e, on, lane);
                 } else {
                     idx = sample_categorical(O, s.obuf, s.nzb, p.softmax, p.quantize, lane);
                 }

@@ -68,78 +68,49 @@ __device__ __forceinline__ float sample_scalar(int dist, int O, const float* obu
     return fminf(fmaxf(x, -1.0f), 1.0f);                                        // mixture.py:154 / :269
 }
 
-// The part of sample_categorical (O <= 256, softmax and quantize) behind the exponentials: a lane holds x[k] = exp(logit - max) and the
-// noise e[k] of its classes lane + 64 k.  Softmax normalisation (wavenet.py:332), Categorical's renormalisation, multinomial's
-// argmax(p_hat / e).  Shared with the ring's categorical head, which computes the exponentials with all its waves (one class per lane)
-// and hands them over through LDS: the same operations on the same values in the same order.
-__device__ __forceinline__ int categorical_tail(float (&x)[4], const float (&e)[4], const bool (&on)[4], int lane) {
-    float s = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (on[k]) s += x[k];
-    s = wave_sum(s);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (on[k]) x[k] = x[k] / s;
-    float s2 = 0.f;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) if (on[k]) s2 += x[k];
-    s2 = wave_sum(s2);
-    float best = -INFINITY;
-    int bi = 0x7fffffff;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        if (!on[k]) continue;
-        const float q = (x[k] / s2) / e[k];
-        if (q > best) { best = q; bi = lane + 64 * k; }
-    }
-    wave_argmax(best, bi);
-    return bi;
-}
-
-// categorical outputs.  Turns obuf into probabilities in place (when softmax) and returns the sampled
-// class (when quantize), else -1.
+// categorical outputs.  Turns obuf into probabilities in place (when softmax and not quantize) and returns the sampled class (when
+// quantize), else -1.
+// THE CHOICE (wavenet.py:332-335): F.softmax, then OneHotCategorical(probs).sample() -- Categorical renormalises, torch.multinomial takes
+// argmax(p_hat / e), e ~ Exp(1).  With x_k = exp(logit_k - max) that is argmax_k (x_k / s / s2) / e_k, where s and s2 are the
+// two normalising sums: the SAME positive factors for every class, which an argmax does not see.  The kernels therefore take
+// argmax_k x_k / e_k (round 4; until then they carried out both normalisations: two wave-wide sums and eight more divisions per lane, 1.35 us
+// of a mu-law step in one wave).  Dropping the common factors moves the pick only where the top-2 margin is below the rounding of the
+// quotients (~2e-7 in the log domain; tests/_margins.py admits a flip below 1e-6 + twice the head-output difference).  Every kernel
+// (generic, ring, wide) uses this arithmetic -- the ring's categorical head with one class per lane --, so they agree on a class
+// whenever they agree on the logits.  Ties: the smallest index (torch.argmax on CPU).
 __device__ __forceinline__ int sample_categorical(int O, float* obuf, const float* nzv,
                                                   int softmax, int quantize, int lane) {
-    // up to 256 classes: a lane keeps its (at most four) classes n = lane + 64 k in registers through all stages -- one LDS read of the
-    // logits and the noise, one write of the probabilities (round 2 went through LDS between the stages: five round trips);
-    // the per-lane partial sums run over k in the order the strided loops did
+    // up to 256 classes: a lane keeps its (at most four) classes n = lane + 64 k in registers -- one LDS read of the logits and the noise
     if (O <= 256) {
         float x[4], e[4];
         bool on[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             on[k] = lane + 64 * k < O;
-            x[k] = on[k] ? obuf[lane + 64 * k] : 0.f;
+            x[k] = on[k] ? obuf[lane + 64 * k] : -INFINITY;
             e[k] = (on[k] && quantize) ? nzv[lane + 64 * k] : 1.f;
         }
         if (softmax) {                                                          // wavenet.py:332
-            float mx = -INFINITY;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (on[k]) mx = fmaxf(mx, x[k]);
+            float mx = fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3]));
             mx = wave_max(mx);
-            float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (on[k]) x[k] = expf(x[k] - mx);
-            if (quantize) return categorical_tail(x, e, on, lane);
+            for (int k = 0; k < 4; ++k) x[k] = on[k] ? expf(x[k] - mx) : 0.f;
+            if (!quantize) {                                                    // (tests only: the probabilities themselves are the output)
+                float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (on[k]) s += x[k];
-            s = wave_sum(s);
+                for (int k = 0; k < 4; ++k) s += x[k];
+                s = wave_sum(s);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) if (on[k]) { x[k] = x[k] / s; if (!quantize) obuf[lane + 64 * k] = x[k]; }   // (quantize: nobody reads them,
-            // and a second wave sampling the same step may still be reading the logits)
+                for (int k = 0; k < 4; ++k) if (on[k]) obuf[lane + 64 * k] = x[k] / s;
+            }
         }
         if (!quantize) return -1;
-        // OneHotCategorical(p).sample(): Categorical renormalises, multinomial takes argmax(p_hat / e)
-        float s2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) if (on[k]) s2 += x[k];
-        s2 = wave_sum(s2);
         float best = -INFINITY;
         int bi = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if (!on[k]) continue;
-            const float q = (x[k] / s2) / e[k];
-            if (q > best) { best = q; bi = lane + 64 * k; }
+            const float q = x[k] / e[k];
+            if (on[k] && q > best) { best = q; bi = lane + 64 * k; }
         }
         wave_argmax(best, bi);
         return bi;
@@ -150,18 +121,16 @@ __device__ __forceinline__ int sample_categorical(int O, float* obuf, const floa
         mx = wave_max(mx);
         float s = 0.f;
         for (int n = lane; n < O; n += 64) { const float e = expf(obuf[n] - mx); obuf[n] = e; s += e; }
-        s = wave_sum(s);
-        for (int n = lane; n < O; n += 64) obuf[n] = obuf[n] / s;
+        if (!quantize) {
+            s = wave_sum(s);
+            for (int n = lane; n < O; n += 64) obuf[n] = obuf[n] / s;
+        }
     }
     if (!quantize) return -1;
-    // OneHotCategorical(p).sample(): Categorical renormalises, multinomial takes argmax(p_hat / e)
-    float s2 = 0.f;
-    for (int n = lane; n < O; n += 64) s2 += obuf[n];
-    s2 = wave_sum(s2);
     float best = -INFINITY;
     int bi = 0x7fffffff;
     for (int n = lane; n < O; n += 64) {
-        const float q = (obuf[n] / s2) / nzv[n];
+        const float q = obuf[n] / nzv[n];
         if (q > best) { best = q; bi = n; }
     }
     wave_argmax(best, bi);
