@@ -2,7 +2,7 @@
 # item 5: categorical head with the softmax spread over the workgroup -- parity, rates, timeline
 set -u
 OUT=gpurun_out/${1:-r04v}; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_golden.py tests/test_gpu_ring.py tests/test_gpu_stress.py tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -8 | tee $OUT/pytest.txt
+timeout 900 python -m pytest tests/test_gpu_golden.py tests/test_gpu_ring.py tests/test_gpu_stress.py tests/test_gpu_fuzz.py tests/test_gpu_configs.py tests/test_gpu_wide.py tests/test_gpu_parity_depth.py -m gpu -x -q 2>&1 | grep -v amdgpu.ids | tail -8 | tee $OUT/pytest.txt
 {
 timeout 300 python scripts/exp_rate.py cfg1_mulaw256 8192 1,8,16,32 fastcat
 timeout 300 python scripts/exp_rate.py cfg1b_mulaw256_intree 8192 1,8 fastcat

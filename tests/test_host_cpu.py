@@ -189,8 +189,11 @@ def test_ring_kernel_keeps_its_poll_registers_out_of_the_compilers_hands(tmp_pat
     REACH = 150
     checked = 0
     # <NK, head evaluates layer 0, MODE: 0 = up to four utterances per ring, 1 = more, 2 = packed slots>, and the split-ring kernel
-    for nk, l0 in [(nk, f"{l0}ELi{mode}") for mode in (0, 1, 2) for nk, l0 in ((1, 0), (1, 1), (2, 0))] + [(1, "split")]:
-        kname = "wnv_ring_kernel_splitE" if l0 == "split" else f"wnv_ring_kernelILi{nk}ELb{l0}E"
+    # (round 4: the K = 512 kernel is capped too and polls the same way; its MODE 0 instantiation may spill two registers)
+    cases = [(nk, f"{l0}ELi{mode}") for mode in (0, 1, 2) for nk, l0 in ((1, 0), (1, 1), (2, 0))] + [(1, "split")] + [(4, f"k512_{mode}") for mode in (0, 1, 2)]
+    for nk, l0 in cases:
+        kname = ("wnv_ring_kernel_splitE" if l0 == "split" else f"wnv_ring_kernel_k512ILi{l0[-1]}E" if str(l0).startswith("k512")
+                 else f"wnv_ring_kernelILi{nk}ELb{l0}E")
         m = re.search(rf"^_ZN\S*{kname}\S*:[^\n]*\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M)
         assert m, f"kernel <{nk}, {l0}> not found"
         lines = [ln.split(";")[0].rstrip() for ln in m.group(1).splitlines()]
@@ -232,8 +235,8 @@ def test_ring_kernel_keeps_its_poll_registers_out_of_the_compilers_hands(tmp_pat
             assert taken, f"wnv_ring_kernel<{nk}, {l0}>: the poll issued at line {i0} is not taken within {REACH} instructions on any path"
         checked += 1
         meta = re.search(rf"\.name:\s+_ZN\S*{kname}\S*\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text)
-        assert meta and int(meta.group(1)) == 0, "the capped kernel spills"
-    assert checked == 10
+        assert meta and int(meta.group(1)) <= (2 if nk == 4 else 0), "the capped kernel spills"
+    assert checked == 13
 
 
 # ---- host-only handles (wnv_create with device = -1): the native checkpoint path without a GPU ------------------------------

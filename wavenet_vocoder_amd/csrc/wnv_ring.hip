@@ -982,7 +982,7 @@ __device__ __forceinline__ void group_matvec8(const f2 (&w)[8][8], const float* 
 template <int NK, bool L0, bool ZMSG, bool MULTI>
 __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, int ring, int sidx, float* smem) {
     constexpr int NLDS = lds_passes(NK);
-    constexpr bool RP = NK <= 2;                // pipelined polls in the reserved registers (the K = 512 instantiation needs them itself)
+    constexpr bool RP = true;                   // pipelined polls in the reserved registers (until round 4 the K = 512 instantiation needed them itself)
     const StageLds s = carve_stage(smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ks = tid & 7, og = tid >> 3;                      // K-slice; lane group = channels 2og, 2og + 1
@@ -1565,7 +1565,7 @@ __device__ __forceinline__ bool head_recv_skip(const RingParams& p, int b, unsig
     if (wave < 2 * NK) {
         const u64* own = p.smail + ((size_t)b * (p.S + 1) + p.S) * p.Kp + tid;
         float acc = 0.f, v = 0.f;
-        if constexpr (NK <= 2) {
+        if constexpr (NK <= 4) {
             if (p.S > 1) ok = rpoll_recv<0>(own - p.Kp, true, tag, acc, p.status, 0x300u, lane);
             ok = ok && rpoll_recv<0>(own, true, tag, v, p.status, 0x300u, lane);
         } else {
@@ -2136,9 +2136,10 @@ template <int NK, bool L0, int MODE>
 __global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK, L0, false, MODE>(p); }
 // split rings: two CUs per layer (scalar-input models with 128 skip channels, up to 8 utterances)
 __global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel_split(const RingParams p) { ring_body<1, true, true, 0>(p); }
-// K = 512: needs the whole register file; polls one load at a time in compiler-allocated registers
+// K = 512: capped like the others since round 4 (two spilled registers in the MODE 0 instantiation, none in the others): its polls used to
+// go one load at a time through compiler-allocated registers -- ~75 ns more per hop than the pipelined ones
 template <int MODE>
-__global__ void __launch_bounds__(RT) wnv_ring_kernel_k512(const RingParams p) { ring_body<4, false, false, MODE>(p); }
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel_k512(const RingParams p) { ring_body<4, false, false, MODE>(p); }
 
 // Placement census (once per handle): every workgroup of a one-block-per-CU grid reports the XCC it runs on.  The host derives
 // the number of XCDs and checks the block -> XCD mapping the ring layout relies on (block b on XCD b % n_xcd, observed; HIP
