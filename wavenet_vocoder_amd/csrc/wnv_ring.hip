@@ -2119,8 +2119,10 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
     if (L0 && pos == 0) return;                   // layer 0 is evaluated by the head (run_head)
     if (L0 && pos == 1) run_stage<NK, L0, L0, MULTI>(p, ring, pos, smem);
     else if (pos < p.S) run_stage<NK, L0, false, MULTI>(p, ring, pos, smem);
-    else if (p.cin1 > 1) {
-        if constexpr (NK <= 2) {                // one-hot models with 512 skip channels stay on the generic kernel (why_not)
+    else if (!L0 && p.cin1 > 1) {
+        // (L0 instantiations serve scalar-input models only -- the categorical head is not compiled into them: every role of a kernel is
+        //  inlined into ONE function, and a change in that head moved the register allocation of the stage loop -- 2 % of the headline)
+        if constexpr (NK <= 2 && !L0) {         // one-hot models with 512 skip channels stay on the generic kernel (why_not)
             if (pos == p.S) run_head_cat<NK, MODE == 2>(p, ring, smem);
             else run_head_part<NK, 2>(p, ring, pos - p.S, smem);
         }
