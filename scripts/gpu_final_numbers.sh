@@ -24,6 +24,13 @@ d = json.loads(sys.stdin.readline())
 print("%-26s B = %d  kernel %7.1f  (%.2f x real time at 24 kHz per utterance)" % (sys.argv[1], d["config"]["batch_per_gpu"], d["value"], d["value"] / d["config"]["batch_per_gpu"] / 24.0))' $w
 done
 done
+# K = 512 at two / four utterances per ring: the plain stage prologue (WNV_RING_MODE=0) against the throughput one the host now picks
+for B in 16 32; do
+  WNV_RING_MODE=0 python bench.py --workload cfg4_mol_multispeaker --steps 2 --T 8192 --batch $B --cpu-steps 0 --no-extras 2>/dev/null | tail -1 | python -c '
+import sys, json
+d = json.loads(sys.stdin.readline())
+print("%-26s B = %d  kernel %7.1f  (WNV_RING_MODE=0: the plain prologue)" % (sys.argv[1], d["config"]["batch_per_gpu"], d["value"]))' cfg4_mol_multispeaker
+done
 for J in 40 100 200; do
   for M in "" "--packed"; do
   python bench.py --job $J --steps 1 --warmup 1 $M 2>/dev/null | tail -1 | python -c '

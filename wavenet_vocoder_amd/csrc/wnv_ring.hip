@@ -2730,7 +2730,9 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     // more than four utterances per ring (40+ per GPU): the stages' occupancy per utterance bounds the step -> their throughput
     // instantiation.  Up to four a ring is still bound by the chain's latency and the plain prologue is faster (same box, B = 16 / 32:
     // 1002 / 2014 against 970 / 1918 kSamples/s; B = 48: 2616 against 2742)
-    int mode = ga.seg_start ? 2 : upr > 4 ? 1 : 0;
+    // (K = 512: a stage is busy ~3.8 us per utterance -- four skip passes, two of them streamed --, so its occupancy counts from two utterances per
+    //  ring on: the throughput instantiation measured +1-2 % at B = 16 / 32 (WNV_RING_MODE knob; both settings in profiles/r04_final_numbers.txt))
+    int mode = ga.seg_start ? 2 : (upr > 4 || (NK == 4 && upr >= 2)) ? 1 : 0;
     if (const char* e = getenv("WNV_RING_MODE")) { if (mode != 2 && (e[0] == '0' || e[0] == '1')) mode = e[0] - '0'; }   // measurement knob
     if (split && mode == 2) { err = "ring kernel: packed slots and split rings do not combine"; return WNV_ERR_UNSUPPORTED; }
 #define WNV_PICK(NKV, L0V) (mode == 2 ? (const void*)wnv_ring_kernel<NKV, L0V, 2> : mode == 1 ? (const void*)wnv_ring_kernel<NKV, L0V, 1> : (const void*)wnv_ring_kernel<NKV, L0V, 0>)
