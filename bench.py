@@ -71,7 +71,7 @@ def numa_local_cpus(want):
     return None
 
 
-def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0):
+def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0, B=None):
     """Time the oracle on the host (checker used as the measured CPU path -- the one place that is allowed).
     Bounded: each thread setting gets at most `budget_s` seconds of wall time (the per-step cost is constant
     once the history buffers exist, so a truncated run measures the same rate)."""
@@ -79,15 +79,15 @@ def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0):
     from tests._golden import oracle_config
     from wavenet_vocoder_amd.noise import make_noise_tape
     o = Oracle(oracle_config(kw), model_cpu.state_dict())
-    B = c.shape[0]
+    B = c.shape[0] if c is not None else 1                # (BASELINE configs[0] has no conditioning: the oracle then runs one utterance)
     frames = T_cpu // 256
-    c_cpu = c[:, :, : frames + 2 * kw["cin_pad"]].contiguous()
+    c_cpu = None if c is None else c[:, :, : frames + 2 * kw["cin_pad"]].contiguous()
     tape = make_noise_tape(T_cpu, B, scalar_input=kw.get("scalar_input", False),
                            output_distribution=kw.get("output_distribution", "Logistic"), out_channels=kw["out_channels"],
                            generator=torch.Generator().manual_seed(2))
     results, steps = {}, {}
     ncores = os.cpu_count() or 1
-    c_up = o.upsample(c_cpu).contiguous()                 # upsampled once; the timed loop is the sample loop
+    c_up = None if c_cpu is None else o.upsample(c_cpu).contiguous()   # upsampled once; the timed loop is the sample loop
     saved = o.cfg.upsample_conditional_features
     o.cfg.upsample_conditional_features = False
     # Every thread setting runs on CPUs of ONE NUMA node, nearest first (round 3 measured 4 threads SLOWER than 1 on the GPU box's
@@ -108,7 +108,7 @@ def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0):
                 pass
         torch.set_num_threads(threads)
         with torch.no_grad():
-            o.incremental_forward(c=c_up[:, :, :32], T=32, noise=tape)                     # warm-up
+            o.incremental_forward(c=None if c_up is None else c_up[:, :, :32], T=32, noise=tape)     # warm-up
             o.incremental_forward(c=c_up, T=T_cpu, noise=tape, max_seconds=budget_s)
         results[threads] = B * o.last_steps / o.last_seconds / 1e3
         steps[threads] = o.last_steps
@@ -405,7 +405,7 @@ def main():
     import copy
     model = copy.deepcopy(model_cpu).to(dev)
     eng = model._get_engine()
-    c_dev = c.to(dev)
+    c_dev = None if c is None else c.to(dev)             # (BASELINE configs[0] has no conditioning)
     g_dev = None if gids is None else gids[:, 0].to(dev)
 
     if args.job > 0:
@@ -418,7 +418,7 @@ def main():
     kern_ms = []
 
     def one_step(i):
-        c_up = eng.upsample(c_dev, T_expected=T)
+        c_up = None if c_dev is None else eng.upsample(c_dev, T_expected=T)
         ev[2 * i].record()
         out, _, _ = eng.generate(B=B, T=T, c_up=c_up, g_ids=g_dev, seed=1000 + i, kernel=args.kernel)
         ev[2 * i + 1].record()
@@ -550,7 +550,7 @@ def main():
                 else:
                     xi = torch.randint(0, kw["out_channels"], (B, T), generator=gx)
                     xt = torch.zeros(B, kw["out_channels"], T).scatter_(1, xi.unsqueeze(1), 1.0).to(dev)
-                c_up_f = eng.upsample(c_dev, T_expected=T)
+                c_up_f = None if c_dev is None else eng.upsample(c_dev, T_expected=T)
                 gi = None if gids is None else gids[:, 0].to(dev)
                 for _ in range(2):
                     eng.forward(xt, c_up=c_up_f, g_ids=gi)
