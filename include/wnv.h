@@ -328,6 +328,14 @@ wnv_status wnv_pinned_free(void* host_ptr);
  * With u = torch.empty(n, dtype=float64).uniform_(0, 1) this reproduces torch.empty(n).exponential_(1) bit for bit and leaves the
  * generator in the same state (tests/test_host_cpu.py).  Pure host code. */
 wnv_status wnv_exponential_from_uniform(const double* u, float* out, int64_t n, int32_t threads);
+/* n draws of torch's CPU generator as `torch.empty(n, dtype=float64).uniform_(0, 1, generator=g)` makes them, natively: `state` is the
+ * blob g.get_state() returns (CPUGeneratorImpl's legacy layout: seed u64 @0, left i32 @8, seeded i32 @12, next u64 @16, the 624 words of
+ * at::mt19937 as u64 @24) and is ADVANCED in place -- g.set_state(state) afterwards leaves g where the torch call would have.  Two
+ * consecutive 32-bit outputs make one draw, the first one high: (x & (2^53 - 1)) * 2^-53 (ATen/core/DistributionsHelper.h).  With
+ * wnv_exponential_from_uniform this is the reference's exponential race (wavenet.py:334-335) at ~1.5 ns per value instead of the 5-10 ns
+ * torch's element-by-element walk costs inside a busy process; the Python host checks it against torch once per process and falls back
+ * to uniform_ when the numbers or the state differ (added within ABI 4, round 4; pure host code). */
+wnv_status wnv_mt19937_uniform53(void* state, int64_t state_bytes, double* out, int64_t n);
 
 /* ---- misc --------------------------------------------------------------------------------------- */
 const char* wnv_last_error(void);

@@ -406,6 +406,44 @@ def test_fast_exponential_draws_are_torchs_own():
     assert _lib.lib().wnv_exponential_from_uniform(None, None, 0, 4) == 0
 
 
+def test_native_mersenne_twister_is_torchs_own():
+    """wnv_mt19937_uniform53 (round 4) must BE ``torch.empty(n, dtype=float64).uniform_(0, 1, generator=g)``: the same draws from the state
+    blob g.get_state() returns, the blob advanced exactly as torch advances the generator -- any n, any position inside a block of 624
+    words, odd word alignment across block boundaries, the default generator, and whatever is drawn afterwards."""
+    from wavenet_vocoder_amd import _lib, noise
+    lib = _lib.lib()
+
+    def native(g, n):
+        st = g.get_state()
+        out = torch.empty(n, dtype=torch.float64)
+        assert lib.wnv_mt19937_uniform53(st.data_ptr(), st.numel(), out.data_ptr(), n) == 0
+        g.set_state(st)
+        return out
+
+    for seed in (1, 1234, 2 ** 40 + 7):
+        for sizes in ((1, 2, 3, 311, 312, 313, 5000, 7, 0, 9), (624, 1, 623, 100_000, 65_536, 65_537, 131_073), (2, 2, 2)):
+            g1, g2 = torch.Generator().manual_seed(seed), torch.Generator().manual_seed(seed)
+            for n in sizes:
+                a = torch.empty(n, dtype=torch.float64).uniform_(0.0, 1.0, generator=g1)
+                assert torch.equal(a, native(g2, n)), (seed, n)
+                assert torch.equal(g1.get_state(), g2.get_state()), (seed, n)
+                # an odd number of 32-bit words in between (a float32 uniform_ takes one word per element below 16 elements)
+                assert torch.equal(torch.empty(3).uniform_(generator=g1), torch.empty(3).uniform_(generator=g2))
+            assert torch.equal(torch.empty(11).normal_(generator=g1), torch.empty(11).normal_(generator=g2))
+    # refusals: not a generator state
+    junk = torch.zeros(5056, dtype=torch.uint8)
+    assert lib.wnv_mt19937_uniform53(junk.data_ptr(), junk.numel(), torch.empty(4, dtype=torch.float64).data_ptr(), 4) != 0
+    assert lib.wnv_mt19937_uniform53(junk.data_ptr(), 100, None, 0) != 0
+    # ... and through the tape: the default generator, chunked requests
+    assert noise._native_uniform_ok()
+    torch.manual_seed(99)
+    a = torch.empty(70_000).exponential_(1.0)
+    torch.manual_seed(99)
+    b = torch.empty(70_000)
+    assert noise.exponential_draws(b) and torch.equal(a, b)
+    assert torch.equal(torch.rand(5), (torch.manual_seed(99), torch.empty(70_000).exponential_(1.0), torch.rand(5))[2])
+
+
 def test_native_handles_do_not_travel_with_copies():
     """copy.deepcopy / pickle of a module that has already run (train.py keeps an EMA copy of the model, synthesis code pickles
     models): the native handle and the pinned tape buffers stay with the original -- a copy that shared them would free them twice --

@@ -114,6 +114,7 @@ _PROTOS = {
     "wnv_pinned_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
     "wnv_pinned_free": (C.c_int, [C.c_void_p]),
     "wnv_exponential_from_uniform": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32]),
+    "wnv_mt19937_uniform53": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]),
     "wnv_last_error": (C.c_char_p, []),
     "wnv_create": (C.c_int, [C.POINTER(Config), C.c_int32, C.POINTER(C.c_void_p)]),
     "wnv_destroy": (C.c_int, [C.c_void_p]),

@@ -209,6 +209,74 @@ extern "C" wnv_status wnv_exponential_from_uniform(const double* u, float* out, 
     for (auto& th : pool) th.join();
     return WNV_OK;
 }
+// torch's CPU generator, natively.  at::mt19937 (ATen/core/MT19937RNGEngine.h) is the 32-bit Mersenne Twister of Matsumoto & Nishimura;
+// CPUGeneratorImpl::random64() joins two consecutive outputs, the first one high, and uniform_real_distribution<double> maps
+// x -> (x & (2^53 - 1)) * 2^-53 * (to - from) + from (ATen/core/DistributionsHelper.h).  `state` is the blob torch.Generator.get_state()
+// returns for a CPU generator: seed u64 @0, left i32 @8, seeded i32 @12, next u64 @16, state[624] as u64 @24 (one 32-bit word each).
+// The engine's call is  if (--left == 0) next_state();  y = state[next++];  temper(y)  -- reproduced call for call, in bulk: the blob
+// is advanced as n draws of uniform_(0, 1) on a float64 tensor would advance it.  (Why: that uniform_ call walks the generator element
+// by element at 2.3 ns per draw alone and 5-10 ns inside incremental_forward on the GPU box's host -- the replay tape of a one-hot model
+// needs B x 256 draws per step, and since the categorical head got faster the host was what bounded the public path.)
+namespace {
+constexpr int MT_N = 624, MT_M = 397;
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#define WNV_SIMD_CLONES __attribute__((target_clones("avx2", "default")))
+#else
+#define WNV_SIMD_CLONES
+#endif
+inline uint32_t mt_twist(uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((0u - (v & 1u)) & 0x9908b0dfu); }
+WNV_SIMD_CLONES void mt_next_state(uint32_t* __restrict st) {                  // at::mt19937::next_state(): three runs, each reads only words not yet rewritten
+    for (int i = 0; i < MT_N - MT_M; ++i) st[i] = st[i + MT_M] ^ mt_twist(st[i], st[i + 1]);
+    for (int i = MT_N - MT_M; i < MT_N - 1; ++i) st[i] = st[i + MT_M - MT_N] ^ mt_twist(st[i], st[i + 1]);
+    st[MT_N - 1] = st[MT_M - 1] ^ mt_twist(st[MT_N - 1], st[0]);
+}
+WNV_SIMD_CLONES void mt_temper_run(const uint32_t* __restrict st, uint32_t* __restrict out, int k) {
+    for (int i = 0; i < k; ++i) {
+        uint32_t y = st[i];
+        y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+        out[i] = y;
+    }
+}
+WNV_SIMD_CLONES void mt_join53(const uint32_t* __restrict w, double* __restrict out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        const uint64_t x = ((uint64_t)w[2 * i] << 32) | w[2 * i + 1];          // random64(): the first output is the high half
+        out[i] = (double)(x & ((1ULL << 53) - 1)) * 0x1.0p-53;                 // uniform_real_distribution<double>, from 0 to 1
+    }
+}
+}  // namespace
+extern "C" wnv_status wnv_mt19937_uniform53(void* state, int64_t state_bytes, double* out, int64_t n) {
+    if (!state || (!out && n > 0)) return fail(WNV_ERR_INVALID_ARG, "NULL buffer");
+    if (n < 0 || state_bytes < 24 + 8 * MT_N) return fail(WNV_ERR_INVALID_ARG, "not a CPU generator state");
+    unsigned char* blob = static_cast<unsigned char*>(state);
+    int32_t left, seeded;
+    uint64_t next, w64[MT_N];
+    std::memcpy(&left, blob + 8, 4); std::memcpy(&seeded, blob + 12, 4); std::memcpy(&next, blob + 16, 8); std::memcpy(w64, blob + 24, sizeof w64);
+    if (!seeded || left < 1 || left > MT_N || next + (uint64_t)(left - 1) > (uint64_t)MT_N) return fail(WNV_ERR_INVALID_ARG, "not a CPU generator state");
+    uint32_t st[MT_N];
+    for (int i = 0; i < MT_N; ++i) st[i] = (uint32_t)w64[i];
+    // The engine's call is  if (--left == 0) next_state();  y = temper(state[next++]):  left - 1 words can be read before the next twist; the
+    // call that finds left == 1 twists (left = N, next = 0) and reads word 0.  2 n words, run by run, then joined pairwise.
+    thread_local std::vector<uint32_t> words;
+    constexpr int64_t PIECE = 1 << 16;                                         // values per piece: the word buffer stays in the L2
+    if ((int64_t)words.size() < 2 * PIECE) words.resize(2 * PIECE);
+    for (int64_t done = 0; done < n; done += PIECE) {
+        const int64_t m = std::min<int64_t>(PIECE, n - done), need = 2 * m;
+        int64_t w = 0;
+        const int64_t head = std::min<int64_t>(need, left - 1);
+        mt_temper_run(st + next, words.data(), (int)head);
+        next += (uint64_t)head; left -= (int32_t)head; w = head;
+        while (w < need) {                                                      // left == 1 here
+            mt_next_state(st);
+            const int k = (int)std::min<int64_t>(MT_N, need - w);
+            mt_temper_run(st, words.data() + w, k);
+            w += k; left = MT_N + 1 - k; next = (uint64_t)k;
+        }
+        mt_join53(words.data(), out + done, m);
+    }
+    for (int i = 0; i < MT_N; ++i) w64[i] = st[i];
+    std::memcpy(blob + 8, &left, 4); std::memcpy(blob + 16, &next, 8); std::memcpy(blob + 24, w64, sizeof w64);
+    return WNV_OK;
+}
 thread_local std::string wnv_g_err;
 extern "C" const char* wnv_last_error(void) { return wnv_g_err.c_str(); }
 

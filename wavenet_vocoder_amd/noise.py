@@ -98,11 +98,47 @@ def exponential_draws(out: torch.Tensor, generator: Optional[torch.Generator] = 
         u = _U_SCRATCH.u = torch.empty(max(need, 1 << 19), dtype=torch.float64)
     flat = out.view(-1)
     nthreads = min(os.cpu_count() or 1, 16)
+    native = _native_uniform_ok()
+    gen = generator if generator is not None else torch.default_generator
     for a in range(0, n, _U_CHUNK):
         m = min(_U_CHUNK, n - a)
-        uu = u[:m].uniform_(0.0, 1.0, **kw)
+        if native:
+            # the same draws from the library's own Mersenne Twister (wnv_mt19937_uniform53: ~1.5 ns per value against the 5-10 ns torch's
+            # element-by-element walk costs inside a busy process), the generator advanced through its state blob
+            st = gen.get_state()
+            _lib.check(_lib.lib().wnv_mt19937_uniform53(st.data_ptr(), st.numel(), u.data_ptr(), m))
+            gen.set_state(st)
+            uu = u[:m]
+        else:
+            uu = u[:m].uniform_(0.0, 1.0, **kw)
         _lib.check(_lib.lib().wnv_exponential_from_uniform(uu.data_ptr(), flat[a:a + m].data_ptr(), m, nthreads))
     return True
+
+
+def _native_uniform_ok() -> bool:
+    """One-time probe: does wnv_mt19937_uniform53 produce torch's float64 uniform_ draws AND leave the generator where torch would
+    (values, state blob, the draws that follow)?  It reads CPUGeneratorImpl's state layout -- another torch build may lay it out
+    differently: then the probe says no and the draws come from uniform_ itself."""
+    ok = _BULK_OK.get("mt_native")
+    if ok is None:
+        try:
+            from . import _lib
+            lib = _lib.lib()
+            ok = True
+            for seed, sizes in ((4321, (1, 311, 5000, 7)), (77, (624, 313))):
+                g1, g2 = torch.Generator().manual_seed(seed), torch.Generator().manual_seed(seed)
+                for m in sizes:
+                    a = torch.empty(m, dtype=torch.float64).uniform_(0.0, 1.0, generator=g1)
+                    st = g2.get_state()
+                    b = torch.empty(m, dtype=torch.float64)
+                    _lib.check(lib.wnv_mt19937_uniform53(st.data_ptr(), st.numel(), b.data_ptr(), m))
+                    g2.set_state(st)
+                    ok = ok and bool(torch.equal(a, b)) and bool(torch.equal(g1.get_state(), g2.get_state()))
+                ok = ok and bool(torch.equal(torch.empty(9).normal_(generator=g1), torch.empty(9).normal_(generator=g2)))
+        except Exception:
+            ok = False
+        _BULK_OK["mt_native"] = ok
+    return ok
 
 
 def noise_width(scalar_input: bool, output_distribution: str, out_channels: int) -> int:
