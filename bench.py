@@ -529,10 +529,17 @@ def main():
             # built on the host first), upsampling included
             try:
                 torch.manual_seed(0)
-                model.incremental_forward(c=c_dev, g=None if gids is None else gids.to(dev), T=T)      # warm: engine + scratch exist
+                init = None
+                if c_dev is None and gids is None:                # (unconditioned: the batch size comes with the initial input, wavenet.py:283-289)
+                    if kw.get("scalar_input", False):
+                        init = torch.zeros(B, 1, 1, device=dev)
+                    else:
+                        init = torch.zeros(B, kw["out_channels"], 1, device=dev)
+                        init[:, 127] = 1.0
+                model.incremental_forward(initial_input=init, c=c_dev, g=None if gids is None else gids.to(dev), T=T)      # warm: engine + scratch exist
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                model.incremental_forward(c=c_dev, g=None if gids is None else gids.to(dev), T=T)
+                model.incremental_forward(initial_input=init, c=c_dev, g=None if gids is None else gids.to(dev), T=T)
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t1
                 line["api_path"] = {"entry": "WaveNet.incremental_forward(c, T) [rng='replay']", "kSamples_per_s_per_gpu": round(B * T / dt / 1e3, 1),
