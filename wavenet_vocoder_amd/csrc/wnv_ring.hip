@@ -1897,8 +1897,9 @@ __device__ __attribute__((always_inline)) void run_head(const RingParams& p, int
 // ---- head of one-hot (mu-law categorical) models: wavenet.py:315-319 head, :332-335 softmax + OneHotCategorical, :297-308
 // first_conv on the fed-back one-hot vector.  first_conv's matrix lives in LDS K-major, so the fed-back class is ONE row
 // gather (bit-identical to F.linear with a one-hot input); teacher-forced inputs and fed-back probabilities
-// (quantize = False, tests only) take the dense mat-vec.  Sampling is sample_categorical() of the generic kernel
-// (argmax(p_hat / e), e ~ Exp(1): what torch.multinomial does), wave 0.
+// (quantize = False, tests only) take the dense mat-vec.  Sampling is sample_categorical()'s arithmetic (wnv_sample.h:
+// argmax_k exp(logit_k - max) / e_k, e ~ Exp(1) -- torch.multinomial's argmax(p_hat / e) without the common normalising factors), one
+// class per lane on all eight waves since round 4; the general path (no softmax / quantize = False) calls sample_categorical() in wave 0.
 struct CatLds {
     float* vs; float* hid; float* obuf; float* nzb; float* vin; float* part; int* ints; float* wfl;
 };
