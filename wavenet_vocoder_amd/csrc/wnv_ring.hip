@@ -1027,6 +1027,9 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
     const int rd1 = ring + (sidx + 1) * p.rstride, rd2 = ring + (sidx + 2 <= p.S ? sidx + 2 : sidx + 1) * p.rstride;
     const bool fast = same_xcd_as(p, rd1, last_stage ? p.NH : sidx == p.S - 2 ? 1 + p.NH : 1, rd2, s.flags + 1);
 
+#ifdef WNV_DBG_MARK
+    unsigned miss_pre = 0, miss_g = 0, miss_q = 0;                      // (diagnostic build) what the throughput prologue's first look did not find
+#endif
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
         const int par = t & 1;
@@ -1079,8 +1082,14 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
                     q_ok = sidx != 1 && __all(rd.y == tag && rd.w == tag);
                     pvv[0] = __uint_as_float(ra.x); pvv[1] = __uint_as_float(ra.z); pvv[2] = __uint_as_float(rb2.x); pvv[3] = __uint_as_float(rb2.z);
                     g0 = __uint_as_float(rc.x); g1 = __uint_as_float(rc.z); q0 = __uint_as_float(rd.x); q1 = __uint_as_float(rd.z);
+#ifdef WNV_DBG_MARK
+                    miss_pre += !pre_ok; miss_g += !g_ok; miss_q += (sidx != 1 && !q_ok);
+#endif
                 }
                 if (!pre_ok && !rec_recv<2>(prec, tag, pvv, p.status, 0x700u + (unsigned)sidx, lane, p.xcc + 256 + blockIdx.x)) s.flags[0] = 1;
+#ifdef WNV_DBG_MARK
+                if (MULTI && lane == 0 && t == p.T - 1) { p.xcc[256 + blockIdx.x] = miss_pre; p.xcc[512 + blockIdx.x] = miss_g; p.xcc[768 + blockIdx.x] = miss_q; }
+#endif
                 const float4 pv = make_float4(pvv[0], pvv[1], pvv[2], pvv[3]);
                 *reinterpret_cast<float4*>(s.pre + 4 * lane) = pv;
                 if constexpr (zmsg) {                                           // rows 4 lane .. 4 lane + 3 of N_1 h_0, plus pre_1: zin is complete;
@@ -2841,6 +2850,15 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
             fclose(f);
         }
     }
+#ifdef WNV_DBG_MARK
+    if (status == 0 && getenv("WNV_RING_MISS_COUNT")) {             // (diagnostic build) the throughput prologue's first look: what was not there yet
+        std::vector<unsigned> mk(1024);
+        (void)hipMemcpy(mk.data(), p.xcc, 4096, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[wnv miss] of %d utterance-steps per stage, ring 0, by stage: pre / h_{l-2} / q not there at the first look:", p.T * upr);
+        for (int k = 0; k < 256; k += p.rstride) if (mk[256 + k] | mk[512 + k] | mk[768 + k]) fprintf(stderr, " %d:%u/%u/%u", k / p.rstride, mk[256 + k], mk[512 + k], mk[768 + k]);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (status != 0) {
         if (getenv("WNV_RING_DEBUG_DUMP")) {                        // (failure path only) where did the records of utterance 0 get to?
             std::vector<u64> f(n_f / B), q(n_p / B);
