@@ -106,9 +106,11 @@ def exponential_draws(out: torch.Tensor, generator: Optional[torch.Generator] = 
             # the same draws from the library's own Mersenne Twister (wnv_mt19937_uniform53: ~1.5 ns per value against the 5-10 ns torch's
             # element-by-element walk costs inside a busy process), the generator advanced through its state blob
             st = gen.get_state()
-            _lib.check(_lib.lib().wnv_mt19937_uniform53(st.data_ptr(), st.numel(), u.data_ptr(), m))
-            gen.set_state(st)
-            uu = u[:m]
+            if _lib.lib().wnv_mt19937_uniform53(st.data_ptr(), st.numel(), u.data_ptr(), m) == 0:
+                gen.set_state(st)
+                uu = u[:m]
+            else:                                                 # (a state blob the library does not recognise: nothing was drawn, torch draws)
+                uu = u[:m].uniform_(0.0, 1.0, **kw)
         else:
             uu = u[:m].uniform_(0.0, 1.0, **kw)
         _lib.check(_lib.lib().wnv_exponential_from_uniform(uu.data_ptr(), flat[a:a + m].data_ptr(), m, nthreads))
