@@ -54,3 +54,21 @@ def test_a_dying_rank_takes_the_job_down():
     """Rank 1 refuses to start (bad LOCAL_RANK handling is simulated by an impossible --steps): nobody is left waiting."""
     r, lines = run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "not-a-number"])
     assert r.returncode != 0 and not lines
+
+
+def test_cpu_baseline_takes_an_unconditioned_workload():
+    """BASELINE configs[0] (mu-law, 8 layers, no conditioning) through bench.py's bounded oracle leg: no mel to slice or upsample, one
+    utterance (the batch of an unconditioned call comes with its initial input; the oracle then runs B = 1)."""
+    import importlib
+    import torch
+    from tests._configs import CONFIGS, build, inputs
+    bench = importlib.import_module("bench")
+    name = "cfg0_mulaw256_small"
+    c, g = inputs(name, 8, 2048)
+    assert c is None and g is None
+    threads = torch.get_num_threads()
+    try:
+        r = bench.cpu_baseline(build(name, seed=0), CONFIGS[name], c, 64, budget_s=1.0)
+    finally:
+        torch.set_num_threads(threads)
+    assert r["value"] > 0 and r["unit"] == "kSamples/s" and r["kind"] == "port" and "B=1" in r["sample"]
