@@ -27,9 +27,12 @@ roofline : the dominant kernel is the sample-loop kernel.  achieved = algorithmi
            by scripts/ubench_hop2.hip + the on-chain 256x128 mat-vec at the CU's fp32 FMA peak) + the head.
            `traffic` (HBM/fabric bytes per launch from rocprofv3 PMC passes) cannot be collected from inside this
            process: it is quoted from profiles/traffic_latest.json together with its source file and commit.
-cpu_baseline : the CPU oracle (oracle/wavenet_oracle.py, a torch-CPU restatement of the reference's op
-           sequence incl. its per-step queue shift) timed on rank 0's host cores on a bounded sample of the SAME
-           workload (same weights, mel, batch 8; T_cpu steps), reference thread setting (4) and all cores.
+cpu_baseline : kind "reference" -- the UNMODIFIED reference package (oracle/_ref: byte-compiled from /root/reference by
+           oracle/build_ref.py, shipped with the tree like the built .so) timed on rank 0's host cores in this same run:
+           WaveNet.incremental_forward after make_generation_fast_(), no_grad, the SAME weights / mel / batch 8, a bounded sample
+           (T_cpu steps or 12 s per thread setting through the reference's own tqdm hook), 1 / 4 (the reference's own
+           setting, synthesis.py:37) / 16 threads, each pinned to one NUMA node.  Only when oracle/_ref is absent:
+           kind "port" (oracle/wavenet_oracle.py with the ratio measured in the authoring container).
 """
 import argparse
 import json
@@ -71,34 +74,23 @@ def numa_local_cpus(want):
     return None
 
 
-def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0, B=None):
-    """Time the oracle on the host (checker used as the measured CPU path -- the one place that is allowed).
-    Bounded: each thread setting gets at most `budget_s` seconds of wall time (the per-step cost is constant
-    once the history buffers exist, so a truncated run measures the same rate)."""
-    from oracle.wavenet_oracle import Oracle
-    from tests._golden import oracle_config
-    from wavenet_vocoder_amd.noise import make_noise_tape
-    o = Oracle(oracle_config(kw), model_cpu.state_dict())
-    B = c.shape[0] if c is not None else 1                # (BASELINE configs[0] has no conditioning: the oracle then runs one utterance)
-    frames = T_cpu // 256
-    c_cpu = None if c is None else c[:, :, : frames + 2 * kw["cin_pad"]].contiguous()
-    tape = make_noise_tape(T_cpu, B, scalar_input=kw.get("scalar_input", False),
-                           output_distribution=kw.get("output_distribution", "Logistic"), out_channels=kw["out_channels"],
-                           generator=torch.Generator().manual_seed(2))
-    results, steps = {}, {}
+def _thread_settings():
     ncores = os.cpu_count() or 1
-    c_up = None if c_cpu is None else o.upsample(c_cpu).contiguous()   # upsampled once; the timed loop is the sample loop
-    saved = o.cfg.upsample_conditional_features
-    o.cfg.upsample_conditional_features = False
-    # Every thread setting runs on CPUs of ONE NUMA node, nearest first (round 3 measured 4 threads SLOWER than 1 on the GPU box's
-    # two-socket, 256-CPU host: the intra-op workers were scheduled anywhere and the 600-KB layer weights bounced between sockets).
+    return ncores, sorted({1, 4, min(ncores, 16)})       # 4 = the reference's own setting (synthesis.py:37)
+
+
+def _pinned_runs(run_one):
+    """run_one(threads) -> (kSamples/s, steps) for every thread setting, each on CPUs of ONE NUMA node, nearest first (round 3 measured
+    4 threads SLOWER than 1 on the GPU box's two-socket, 256-CPU host: the intra-op workers were scheduled anywhere and the 600-KB
+    layer weights bounced between sockets)."""
+    ncores, settings = _thread_settings()
     affinity0 = None
     try:
         affinity0 = os.sched_getaffinity(0)
     except Exception:
         pass
-    pinned = {}
-    for threads in sorted({1, 4, min(ncores, 16)}):       # 4 = the reference's own setting (synthesis.py:37)
+    results, steps, pinned = {}, {}, {}
+    for threads in settings:
         local = numa_local_cpus(threads) if affinity0 is not None else None
         if local:
             try:
@@ -107,20 +99,97 @@ def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0, B=None):
             except Exception:
                 pass
         torch.set_num_threads(threads)
-        with torch.no_grad():
-            o.incremental_forward(c=None if c_up is None else c_up[:, :, :32], T=32, noise=tape)     # warm-up
-            o.incremental_forward(c=c_up, T=T_cpu, noise=tape, max_seconds=budget_s)
-        results[threads] = B * o.last_steps / o.last_seconds / 1e3
-        steps[threads] = o.last_steps
+        results[threads], steps[threads] = run_one(threads)
         if affinity0 is not None:
             try:
                 os.sched_setaffinity(0, affinity0)
             except Exception:
                 pass
+    return ncores, results, steps, pinned
+
+
+def cpu_baseline_reference(model_cpu, kw, c, gids, T_cpu, budget_s=12.0, B=8):
+    """kind = "reference": the UNMODIFIED reference package (oracle/_ref, byte-compiled from /root/reference by oracle/build_ref.py;
+    it travels with the tree like the built .so) timed on this box's host cores: `WaveNet.incremental_forward` (wavenet.py:215-343)
+    after `make_generation_fast_()` (wavenet.py:355-361), under `torch.no_grad()`, same weights / mel / speaker ids / batch as the
+    GPU run, upsampling included, torch's own generator for the noise.  Bounded through the reference's own `tqdm` hook
+    (wavenet.py:217,296): the iterator it wraps around `range(T)` stops handing out steps after `budget_s` seconds -- the per-step
+    cost is constant once the history buffers exist (conv.py:34-36), so a truncated run measures the same rate."""
+    from oracle import reference as R
+    rm = R.build_model(kw, model_cpu.state_dict(), fast=True)
+    frames = T_cpu // 256
+    c_cpu = None if c is None else c[:B, :, : frames + 2 * kw["cin_pad"]].contiguous()
+    g_cpu = None if gids is None else gids[:B]
+    # the reference learns the batch size from test_inputs / c only (wavenet.py:253,273): one forced first step -- the default
+    # first input itself (zeros / one-hot 127, wavenet.py:281-289) -- tells it B for unconditioned and speaker-conditioned models
+    if kw.get("scalar_input", False):
+        first = torch.zeros(B, 1, 1)
+    else:
+        first = torch.zeros(B, kw["out_channels"], 1)
+        first[:, 127] = 1.0
+    done = {}
+
+    def bounded(rng):
+        t0 = time.perf_counter()
+        n = 0
+        for t in rng:
+            if n >= 16 and time.perf_counter() - t0 > budget_s:
+                break
+            yield t
+            n += 1
+        done["steps"], done["seconds"] = n, time.perf_counter() - t0
+
+    def run_one(threads):
+        import warnings
+        with torch.no_grad(), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            rm.incremental_forward(c=None if c_cpu is None else c_cpu[:, :, : 1 + 2 * kw["cin_pad"]], g=g_cpu, T=256 if c_cpu is not None else 32,
+                                   test_inputs=first, tqdm=lambda r: (t for t in r if t < 32), log_scale_min=-16.0)      # warm-up
+            torch.manual_seed(2)
+            rm.incremental_forward(c=c_cpu, g=g_cpu, T=T_cpu, test_inputs=first, tqdm=bounded, softmax=True, quantize=True,
+                                   log_scale_min=-16.0)
+        return B * done["steps"] / done["seconds"] / 1e3, done["steps"]
+
+    ncores, results, steps, pinned = _pinned_runs(run_one)
+    best = max(results, key=results.get)
+    return {"value": round(results[best], 4), "unit": "kSamples/s", "cores": best, "kind": "reference",
+            "sample": f"the unmodified reference WaveNet.incremental_forward (oracle/_ref: r9y9/wavenet_vocoder byte-compiled by "
+                      f"oracle/build_ref.py) after make_generation_fast_(), no_grad, same weights/mel, B={B}, up to T={T_cpu} steps or "
+                      f"{budget_s:.0f} s per thread setting through its tqdm hook (steps done: {steps}); host has {ncores} cores, each thread "
+                      f"setting pinned to CPUs of one NUMA node ({pinned}); 4 threads is the reference's own setting (synthesis.py:37)",
+            "all_threads_kSamples_s": {str(k): round(v, 4) for k, v in results.items()}}
+
+
+def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0, B=8, gids=None):
+    """The CPU leg of the line.  kind "reference" (oracle/_ref present: the real reference package, see cpu_baseline_reference) or,
+    only when that build product is absent, kind "port": the oracle (oracle/wavenet_oracle.py -- checker used as the measured CPU
+    path, the one place that is allowed) with the ratio to the real reference measured in the authoring container."""
+    from oracle import reference as R
+    if R.available():
+        return cpu_baseline_reference(model_cpu, kw, c, gids, T_cpu, budget_s, B)
+    from oracle.wavenet_oracle import Oracle
+    from tests._golden import oracle_config
+    from wavenet_vocoder_amd.noise import make_noise_tape
+    o = Oracle(oracle_config(kw), model_cpu.state_dict())
+    frames = T_cpu // 256
+    c_cpu = None if c is None else c[:B, :, : frames + 2 * kw["cin_pad"]].contiguous()
+    Bo = B if c is not None else 1                       # (the oracle takes the batch size from c; unconditioned: one utterance)
+    tape = make_noise_tape(T_cpu, Bo, scalar_input=kw.get("scalar_input", False),
+                           output_distribution=kw.get("output_distribution", "Logistic"), out_channels=kw["out_channels"],
+                           generator=torch.Generator().manual_seed(2))
+    c_up = None if c_cpu is None else o.upsample(c_cpu).contiguous()   # upsampled once; the timed loop is the sample loop
+    saved = o.cfg.upsample_conditional_features
+    o.cfg.upsample_conditional_features = False
+
+    def run_one(threads):
+        with torch.no_grad():
+            o.incremental_forward(c=None if c_up is None else c_up[:, :, :32], T=32, noise=tape)     # warm-up
+            o.incremental_forward(c=c_up, T=T_cpu, noise=tape, max_seconds=budget_s)
+        return Bo * o.last_steps / o.last_seconds / 1e3, o.last_steps
+
+    ncores, results, steps, pinned = _pinned_runs(run_one)
     o.cfg.upsample_conditional_features = saved
     best = max(results, key=results.get)
-    # the oracle is a little FASTER than the reference it restates (no module dispatch, no tqdm); the ratio was measured where both
-    # run (scripts/cpu_ref_vs_oracle.py in the authoring container -> profiles/cpu_ref_ratio.json)
     ratio, est = None, None
     try:
         rj = json.load(open(os.path.join(ROOT, "profiles", "cpu_ref_ratio.json")))["by_threads"]
@@ -129,11 +198,12 @@ def cpu_baseline(model_cpu, kw, c, T_cpu, budget_s=12.0, B=None):
         est = round(results[best] / r_best, 4)
     except Exception:
         pass
-    return {"value": round(results[best], 4), "unit": "kSamples/s", "cores": best, "kind": "port",
-            "sample": f"oracle/wavenet_oracle.py (torch-CPU restatement of the reference op sequence incl. its per-step "
-                      f"queue shift), same weights/mel, B={B}, up to T={T_cpu} steps or {budget_s:.0f} s per thread setting "
-                      f"(steps done: {steps}); host has {ncores} cores, each thread setting pinned to CPUs of one NUMA node ({pinned}); the oracle runs {ratio} x the real reference's speed by thread "
-                      f"count (profiles/r02_cpu_reference_vs_oracle.txt), so the reference itself would measure ~{est} kSamples/s here",
+    return {"value": round(results[best], 4), "unit": "kSamples/s", "cores": best, "kind": "port", "batch": Bo,
+            "sample": f"oracle/_ref ABSENT (run oracle/build_ref.py where /root/reference exists) -> oracle/wavenet_oracle.py (torch-CPU "
+                      f"restatement of the reference op sequence incl. its per-step queue shift), same weights/mel, B={Bo}, up to T={T_cpu} "
+                      f"steps or {budget_s:.0f} s per thread setting (steps done: {steps}); host has {ncores} cores, pinned ({pinned}); the oracle "
+                      f"runs {ratio} x the real reference's speed by thread count (profiles/r02_cpu_reference_vs_oracle.txt), so the "
+                      f"reference itself would measure ~{est} kSamples/s here",
             "oracle_over_reference_speed": ratio, "reference_estimate_kSamples_s": est,
             "all_threads_kSamples_s": {str(k): round(v, 4) for k, v in results.items()}}
 
@@ -217,14 +287,36 @@ def dry_run(args, world, rank):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ranks = rank_report(dist, torch.device("cpu"), 2.0 * (1 + rank), 2)          # (the same gather as the real run; "kernel" 2 = ring)
+    job = None
+    if args.job > 0:
+        # JOB dry run: the scheduler's decisions for this job on `world` ranks (what the multi-GPU BASELINE jobs -- configs[3]: 64
+        # utterances, configs[4]: 128 -- would launch), gathered exactly as job_mode gathers its per-rank figures; strong scaling
+        from tests._configs import CONFIGS
+        kw = CONFIGS[args.workload]
+        slots = args.job_group if args.job_group > 0 else (32 if kw["skip_out_channels"] > 256 else 48)       # = sharding.packed_group_size
+        mine = list(job_plan(args, kw, world, rank, slots))
+        if dist is not None:
+            rows = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(rows, torch.tensor(mine, dtype=torch.float64))
+            per_rank = [[int(x) for x in r.tolist()] for r in rows]
+        else:
+            per_rank = [mine]
+        true_total, padded_total = sum(r[0] for r in per_rank), sum(r[1] for r in per_rank)
+        job = {"utterances": args.job, "true_samples": true_total, "padded_samples": padded_total,
+               "padding_loss": round(1.0 - true_total / max(padded_total, 1), 4), "per_rank_true_padded_launches": per_rank,
+               "load_imbalance": round(max(r[1] for r in per_rank) / (padded_total / world), 4),
+               "scheduler": ("packed slots x%d" % slots) if args.packed else "padded groups"}
     if rank == 0:
-        print(json.dumps({"metric": "audio kSamples/sec (24 kHz MoL egs/mol, batch=8 per GPU), whole job", "value": 0.0,
-                          "unit": "kSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)", "dry_run": True,
-                          "config": {"workload": f"{args.workload} dry run, B={B} x T={T}", "parallelism": f"utterance-sharded x{world}"},
-                          "ranks": ranks}),
-              flush=True)
+        line = {"metric": "audio kSamples/sec (24 kHz MoL egs/mol, batch=8 per GPU), whole job", "value": 0.0,
+                "unit": "kSamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True,
+                "scaling": "strong" if job else "weak", "vs_baseline": None, "dtype": "f32", "data": "none (dry run)", "dry_run": True,
+                "config": {"workload": f"{args.workload} dry run, " + (f"JOB of {args.job} utterances" if job else f"B={B} x T={T}"),
+                           "parallelism": f"utterance-sharded x{world}"},
+                "ranks": ranks}
+        if job:
+            line["job"] = job
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
     return 0
@@ -246,6 +338,14 @@ def latency_floor_us(kw, n_head_parts=1, hop=0.276):
     return stages * layer + head
 
 
+def dist_info(dist, world, args):
+    """Which collective library carried the barriers / reduces of this line (None: a single process without --force-dist)."""
+    if dist is None:
+        return None
+    return {"backend": str(dist.get_backend()), "world_size": world, "forced_single_rank": bool(getattr(args, "force_dist", False) and world == 1),
+            "collectives": "barrier x2, all_reduce(MAX), all_gather (rank report)" + (", gather_object (waveforms)" if getattr(args, "job", 0) > 0 else "")}
+
+
 def rank_report(dist, dev, kernel_ms, last_kernel):
     """What every rank ran, gathered on all ranks: a rank that silently fell back to the generic kernel would otherwise hide inside a
     MAX-reduced time.  Returns {"kernel_ms": [...], "last_kernel": [...]} by rank."""
@@ -261,6 +361,34 @@ def rank_report(dist, dev, kernel_ms, last_kernel):
             "last_kernel_by_rank": [names.get(int(r[1]), "?") for r in rows]}
 
 
+def job_inputs(args, kw):
+    """The seeded job: frames per utterance (1.0 .. 8.0 s at 24 kHz, hop 256), mels, speaker ids (speaker-conditioned models)."""
+    gen = torch.Generator().manual_seed(2024)
+    frames = torch.randint(94, 751, (args.job,), generator=gen).tolist()
+    mels = [torch.randn(kw["cin_channels"], f, generator=gen) for f in frames]
+    spk = None
+    if kw.get("gin_channels", -1) > 0:
+        spk = torch.randint(0, kw["n_speakers"], (args.job,), generator=gen).tolist()
+    return frames, mels, spk
+
+
+def job_plan(args, kw, world, rank, slots):
+    """What the scheduler does with the job on this rank, without synthesising anything: (true samples, padded samples, launches) --
+    sharding.lpt_assign over the ranks, then packed slots (plan_slots: a slot's cost is the SUM of its utterances) or padded groups
+    (pack_groups: a group runs to its longest member)."""
+    from wavenet_vocoder_amd import sharding
+    frames, _, _ = job_inputs(args, kw)
+    lengths = [f * 256 for f in frames]
+    mine = sharding.lpt_assign(lengths, world)[rank]
+    true = sum(lengths[i] for i in mine)
+    if args.packed:
+        bins = sharding.plan_slots([lengths[i] for i in mine], slots) if mine else []
+        T = max((sum(lengths[mine[k]] for k in b) for b in bins), default=0)
+        return true, len(bins) * T, 1 if mine else 0
+    groups = sharding.pack_groups(mine, lengths, args.job_group if args.job_group > 0 else None)
+    return true, sum(len(g) * max(lengths[i] for i in g) for g in groups if len(g)), len(groups)
+
+
 def job_mode(args, model, kw, dev, dist, world, rank):
     """N utterances of different lengths through the scheduler the evaluate front end uses (wavenet_vocoder_amd/sharding.py;
     reference evaluate.py:51-92,204-215 + egs/mol/run.sh:31): longest-first assignment to the ranks, groups of neighbouring length
@@ -269,9 +397,7 @@ def job_mode(args, model, kw, dev, dist, world, rank):
     Strong scaling: the job is the same whatever the number of ranks."""
     from wavenet_vocoder_amd import sharding
     hop, pad = 256, int(kw.get("cin_pad", 0))
-    gen = torch.Generator().manual_seed(2024)
-    frames = torch.randint(94, 751, (args.job,), generator=gen).tolist()                      # 1.0 .. 8.0 s at 24 kHz, hop 256
-    mels = [torch.randn(kw["cin_channels"], f, generator=gen) for f in frames]
+    frames, mels, spk = job_inputs(args, kw)
     lengths = [f * hop for f in frames]
     model.rng = "philox"                                                                      # in-kernel noise, as the fixed-batch line
     launches = []
@@ -279,7 +405,8 @@ def job_mode(args, model, kw, dev, dist, world, rank):
     def synth(c, idx):
         T = (c.shape[-1] - 2 * pad) * hop
         launches.append((len(idx), T))
-        y = model.incremental_forward(c=c.to(dev), T=T)
+        g = None if spk is None else torch.tensor([[spk[i]] for i in idx], dtype=torch.long, device=dev)
+        y = model.incremental_forward(c=c.to(dev), g=g, T=T)
         return y[:, 0]
 
     group = args.job_group if args.job_group > 0 else None
@@ -295,7 +422,8 @@ def job_mode(args, model, kw, dev, dist, world, rank):
         st = {}
         launches.clear()
         mine = sharding.lpt_assign(lengths, world)[rank]
-        outs = sharding.synthesize_packed(model, mels, hop_size=hop, cin_pad=pad, slots=group, indices=mine, stats=st, seed=4321)
+        outs = sharding.synthesize_packed(model, mels, hop_size=hop, cin_pad=pad, slots=group, indices=mine, stats=st, seed=4321,
+                                          speaker_ids=spk)
         launches.append((st.get("slots", 0), st.get("slot_steps", 0)))
         st["groups"] = [mine]
         local = {i: o[0].detach().to("cpu") for i, o in zip(mine, outs)}
@@ -334,6 +462,7 @@ def job_mode(args, model, kw, dev, dist, world, rank):
         per_rank = [[int(x) for x in r.tolist()] for r in rows]
     else:
         per_rank = [mine]
+    ranks = rank_report(dist, dev, elapsed / args.steps * 1e3, model._get_engine().last_kernel())     # (every rank: an all_gather)
     if rank == 0:
         assert wavs is not None and len(wavs) == args.job and all(w.numel() == n for w, n in zip(wavs, lengths))
         assert all(torch.isfinite(w).all() and float(w.std()) > 1e-3 for w in wavs), "dead or non-finite waveform in the job"
@@ -345,7 +474,7 @@ def job_mode(args, model, kw, dev, dist, world, rank):
                 "dtype": "f32", "data": "synthetic (seeded N(0,1) mels of seeded lengths 1-8 s, random-init weights, in-kernel Philox noise)",
                 "config": {"workload": f"{args.workload}: {describe(kw)}; JOB of {args.job} utterances, {min(frames)}-{max(frames)} frames "
                                        f"({true_total / 24000.0:.1f} s of audio), scheduler = "
-                                       + (f"lpt_assign + PACKED SLOTS (continuous batching, {'48' if group is None else group} slots per GPU)" if args.packed
+                                       + (f"lpt_assign + PACKED SLOTS (continuous batching, {sharding.packed_group_size(model) if group is None else group} slots per GPU)" if args.packed
                                           else f"lpt_assign + pack_groups({'auto' if group is None else group})"),
                            "parallelism": f"utterance-sharded x{world}"},
                 "job": {"utterances": args.job, "true_samples": true_total, "padded_samples": padded_total,
@@ -353,7 +482,8 @@ def job_mode(args, model, kw, dev, dist, world, rank):
                         "kSamples_per_s_incl_padding": round(padded_total * args.steps / elapsed / 1e3, 1),
                         "rank0_launches_B_x_T": launches, "per_rank_true_padded_groups": per_rank,
                         "load_imbalance": round(max(r[1] for r in per_rank) / (padded_total / world), 4),
-                        "x_real_time_24k_whole_job": round(true_total / 24000.0 / (elapsed / args.steps), 2)}}
+                        "x_real_time_24k_whole_job": round(true_total / 24000.0 / (elapsed / args.steps), 2)},
+                "ranks": ranks, "distributed": dist_info(dist, world, args)}
         print(json.dumps(line), flush=True)
     return 0
 
@@ -376,6 +506,10 @@ def main():
     ap.add_argument("--job-group", type=int, default=0, help="job mode: utterances per launch (0 = sharding.auto_group_size)")
     ap.add_argument("--packed", action="store_true",
                     help="job mode: PACKED SLOTS (continuous batching, sharding.synthesize_packed) instead of padded groups")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the distributed leg even with ONE rank: init_process_group('nccl') = RCCL with world size 1, both barriers, "
+                         "the MAX all_reduce, the all_gather of the rank report and (job mode) the gather_object -- what a multi-GPU "
+                         "launch executes, on one GPU (tests/test_gpu_zz_boundary.py)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (no throughput_mode, no cpu_baseline): what the rocprofv3 summaries are taken with")
     args = ap.parse_args()
@@ -392,9 +526,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                                     # --force-dist without a launcher: a rendezvous of one
+            os.environ.setdefault("MASTER_PORT", str(free_port()))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
 
     from tests._configs import CONFIGS, build, inputs
@@ -468,11 +607,9 @@ def main():
         # the MEASURED LDS read peak of this box next to the nominal one (csrc/wnv_ubench.hip, ~5 ms)
         peak_meas, peak_cus = None, None
         try:
-            import ctypes
             from wavenet_vocoder_amd import _lib
-            gbs, ncu = ctypes.c_double(0.0), ctypes.c_int32(0)
-            _lib.check(_lib.lib().wnv_measure_lds_read_peak(local_rank, ctypes.byref(gbs), ctypes.byref(ncu)))
-            peak_meas, peak_cus = round(gbs.value, 1), int(ncu.value)
+            gbs, peak_cus = _lib.measure_lds_read_peak(local_rank)           # a bench tool of libwnv_test.so (include/wnv_test.h), not product
+            peak_meas = round(gbs, 1)
         except Exception as e:
             peak_meas = None
             print(f"[bench] LDS peak microbenchmark failed: {e}", file=sys.stderr)
@@ -506,6 +643,7 @@ def main():
                                           "on-chain 256x128 mat-vec at the fp32 FMA peak 0.107 us) + head (2 hops + KxK and OxK mat-vecs)",
                                  "floor_us_per_step_hop2_0p444": round(floor_hop2, 3), "frac_hop2_0p444": round(floor_hop2 / us_step, 4)},
             "ranks": ranks,
+            "distributed": dist_info(dist, world, args),
         }
         if world == 1 and args.batch == B_PER_GPU and args.workload == WORKLOAD and not args.no_extras:
             # informative only (not `value`): the same kernel with 48 utterances per GPU -- the rings pipeline six
@@ -594,8 +732,12 @@ def main():
             except Exception as e:
                 line["wide_model"] = {"error": str(e)[:120]}
         if world == 1 and args.cpu_steps > 0 and not args.no_extras:
-            line["cpu_baseline"] = cpu_baseline(model_cpu, kw, c, args.cpu_steps)
-            line["speedup_vs_cpu_baseline"] = round(value / line["cpu_baseline"]["value"], 1)
+            line["cpu_baseline"] = cpu_baseline(model_cpu, kw, c, args.cpu_steps, B=B, gids=gids)
+            line["cpu_baseline"]["batch"] = line["cpu_baseline"].get("batch", B)
+            # like for like: aggregate rate of the SAME number of utterances on both sides (a "port" leg of an unconditioned model
+            # runs one utterance: then the per-utterance rates are compared)
+            cb = line["cpu_baseline"]
+            line["speedup_vs_cpu_baseline"] = round((value / world / B) / (cb["value"] / cb["batch"]), 1)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define WNV_ABI_VERSION 4
+#define WNV_ABI_VERSION 5
 #define WNV_MAX_UPSAMPLE_STAGES 8
 
 typedef enum wnv_status {
@@ -176,8 +176,13 @@ typedef struct wnv_generate_args {
                                /* before its first step reads as zeros (conv.py:34-36), the first input is zeros / one-hot 127          */
                                /* (wavenet.py:281-289); the in-kernel noise stream is addressed with (seg_uid, t - seg_start), so a   */
                                /* waveform does not depend on how the job was packed.  c_up is the slots' concatenated conditioning.  */
-                               /* Ring kernel only, models without global conditioning, in-kernel noise (noise, teacher, initial,      */
-                               /* g, g_ids NULL); otherwise WNV_ERR_UNSUPPORTED / WNV_ERR_INVALID_ARG.  NULL: one utterance per row.  */
+                               /* Ring kernel only, in-kernel noise (noise, teacher, initial NULL); otherwise WNV_ERR_UNSUPPORTED /    */
+                               /* WNV_ERR_INVALID_ARG.  NULL: one utterance per row.                                                  */
+    const int32_t* seg_gid;    /* ABI 5, packed slots of a model WITH global conditioning (BASELINE configs[4]: speaker embedding,    */
+    int32_t n_g;               /* wavenet.py:262-269): g / g_ids then have n_g rows -- one per speaker or per utterance of the job,   */
+                               /* not per slot -- and seg_gid[b][t] (device (B, T)) is the row of the utterance occupying slot b at   */
+                               /* step t: the hoisted bias table conv.bias + conv1x1g(g) (modules.py:146-150) has n_g rows and the    */
+                               /* tap workgroups pick the row per slot and step.  NULL / 0 otherwise.                                 */
 } wnv_generate_args;
 
 /* The pipelined ring kernel is a persistent launch whose workgroups wait for each other; every wait is bounded and a
@@ -201,9 +206,6 @@ wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* args);
 wnv_status wnv_wait(wnv_handle h);
 /* Which kernel served the last wnv_generate of this handle: 1 generic, 2 ring, 3 group ring (wide models), 0 none yet. */
 int32_t wnv_last_kernel(wnv_handle h);
-/* Test hook: the next n persistent (ring) launches this handle would make in auto mode (kernel = 0) report WNV_ERR_TIMEOUT
- * without being launched -- drives the retry policy described at wnv_reset without a device that loses its CUs.  n = 0 clears. */
-wnv_status wnv_debug_inject_timeouts(wnv_handle h, int32_t n);
 
 /* WaveNet.clear_buffer (wavenet.py:345-353): the engine re-zeroes its history at the start of every
  * wnv_generate (as incremental_forward does at :241), so this only releases scratch. */
@@ -344,10 +346,11 @@ int32_t wnv_abi_version(void);
  * group (weights once + ring taps + conditioning row + output) and MACs per sample. */
 int64_t wnv_bytes_per_step(wnv_handle h, int32_t B);
 int64_t wnv_macs_per_sample(wnv_handle h);
-/* The MEASURED on-chip peak the sample loop's roofline is priced against: LDS read bandwidth of the whole device in
- * GB/s from a microbenchmark launch (every CU: 16 waves of conflict-free ds_read_b128; csrc/wnv_ubench.hip), ~5 ms.  *n_cu (optional)
- * receives the CU count the figure covers.  Synchronous; needs a GPU. */
-wnv_status wnv_measure_lds_read_peak(int32_t device, double* gb_per_s, int32_t* n_cu);
+/* Which configurations a sample-loop kernel covers, from the configuration alone (pure host code): "supported", or the reason
+ * wnv_generate would report with WNV_ERR_UNSUPPORTED.  kernel: 1 generic (everything the reference can express), 2 pipelined ring,
+ * 3 group ring (wide models).  ABI 5. */
+const char* wnv_kernel_coverage(const wnv_config* cfg, int32_t kernel, int32_t B);
+/* (ABI 5: the LDS-peak microbenchmark and the time-out injection hook left the product ABI: include/wnv_test.h, libwnv_test.so.) */
 
 #ifdef __cplusplus
 }

@@ -57,10 +57,12 @@ def test_a_dying_rank_takes_the_job_down():
 
 
 def test_cpu_baseline_takes_an_unconditioned_workload():
-    """BASELINE configs[0] (mu-law, 8 layers, no conditioning) through bench.py's bounded oracle leg: no mel to slice or upsample, one
-    utterance (the batch of an unconditioned call comes with its initial input; the oracle then runs B = 1)."""
+    """BASELINE configs[0] (mu-law, 8 layers, no conditioning) through bench.py's bounded CPU leg: no mel to slice or upsample.  With
+    oracle/_ref built the leg times the REAL reference at the bench's batch (one forced first step tells it B, wavenet.py:253); without
+    it the oracle port runs one utterance and says so (`batch`), so that speedup_vs_cpu_baseline compares like with like."""
     import importlib
     import torch
+    from oracle import reference as R
     from tests._configs import CONFIGS, build, inputs
     bench = importlib.import_module("bench")
     name = "cfg0_mulaw256_small"
@@ -68,7 +70,43 @@ def test_cpu_baseline_takes_an_unconditioned_workload():
     assert c is None and g is None
     threads = torch.get_num_threads()
     try:
-        r = bench.cpu_baseline(build(name, seed=0), CONFIGS[name], c, 64, budget_s=1.0)
+        r = bench.cpu_baseline(build(name, seed=0), CONFIGS[name], c, 64, budget_s=1.0, B=8)
+        assert r["value"] > 0 and r["unit"] == "kSamples/s"
+        if R.available():
+            assert r["kind"] == "reference" and "B=8" in r["sample"]
+        # the port leg (what a tree without oracle/_ref reports)
+        saved, R.available = R.available, (lambda: False)
+        try:
+            r = bench.cpu_baseline(build(name, seed=0), CONFIGS[name], c, 64, budget_s=1.0, B=8)
+        finally:
+            R.available = saved
+        assert r["kind"] == "port" and r["batch"] == 1 and "B=1" in r["sample"] and r["value"] > 0
     finally:
         torch.set_num_threads(threads)
-    assert r["value"] > 0 and r["unit"] == "kSamples/s" and r["kind"] == "port" and "B=1" in r["sample"]
+
+
+@pytest.mark.parametrize("workload,n_utt,packed", [("cfg3b_gaussian30", 64, True), ("cfg4_mol_multispeaker", 128, True), ("cfg4_mol_multispeaker", 128, False)])
+def test_job_dry_run_of_the_multi_gpu_baseline_jobs(workload, n_utt, packed):
+    """BASELINE.json configs[3] (64 utterances over 8 GPUs) and configs[4] (128) as `--job` lines on 1 / 2 / 4 / 8 gloo ranks: the
+    scheduler's decisions (lpt_assign over the ranks, packed slots or padded groups per rank), gathered by the collectives the GPU run
+    uses -- strong scaling: the same job on every world size, load imbalance and padding loss reported."""
+    true = None
+    for n in (1, 2, 4, 8):
+        cmd = [sys.executable, BENCH, "--gpus", str(n), "--dry-run", "--job", str(n_utt), "--workload", workload, "--steps", "1"]
+        r, lines = run(cmd + (["--packed"] if packed else []))
+        assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+        j = json.loads(lines[0])
+        job = j["job"]
+        assert j["n_gpus"] == n and j["scaling"] == "strong" and job["utterances"] == n_utt and len(job["per_rank_true_padded_launches"]) == n
+        true = true or job["true_samples"]
+        assert job["true_samples"] == true == sum(r_[0] for r_ in job["per_rank_true_padded_launches"])      # the same job whatever the world size
+        assert all(r_[0] > 0 and r_[1] >= r_[0] for r_ in job["per_rank_true_padded_launches"])
+        tr = [r_[0] for r_ in job["per_rank_true_padded_launches"]]
+        assert max(tr) / (sum(tr) / n) < 1.02 and job["load_imbalance"] < 1.15, job                        # longest-first keeps the ranks level
+        if packed:
+            slots = 32 if "cfg4" in workload else 48
+            assert all(r_[2] == 1 for r_ in job["per_rank_true_padded_launches"]) and f"x{slots}" in job["scheduler"], job
+            # (a rank with fewer utterances than slots gives every utterance a slot of its own: its launch runs as long as its longest
+            #  utterance -- idle slots cost no time, the step is the chain's latency --, so "padding" only measures loss once slots are shared)
+            if n_utt // n >= 2 * slots:
+                assert job["padding_loss"] < 0.15, job

@@ -20,7 +20,17 @@ def job(n, cin, seed, lo=2, hi=9):
     return [torch.randn(cin, f, generator=g) for f in frames]
 
 
-@pytest.mark.parametrize("name,slots", [("cfg2_mol", 5), ("cfg3_gaussian", 8), ("cfg1_mulaw256", 3), ("cfg1b_mulaw256_intree", 4)])
+def own_conditioning(eng, mels, pad):
+    """(B, T_max, cin): row i = utterance i's conditioning upsampled on its own (sharding.upsample_each), zeros behind its end."""
+    lengths = [mm.shape[-1] * HOP for mm in mels]
+    c_up = torch.zeros(len(mels), max(lengths), mels[0].shape[0], device="cuda")
+    for k, cu in sharding.upsample_each(eng, mels, list(range(len(mels))), pad, HOP):
+        c_up[k, :lengths[k]] = cu
+    return c_up
+
+
+@pytest.mark.parametrize("name,slots", [("cfg2_mol", 5), ("cfg3_gaussian", 8), ("cfg1_mulaw256", 3), ("cfg1b_mulaw256_intree", 4),
+                                        ("cfg4_mol_multispeaker", 4)])
 def test_packed_slots_reproduce_the_padded_batch(name, slots):
     kw = CONFIGS[name]
     m = build(name).to("cuda")
@@ -28,12 +38,15 @@ def test_packed_slots_reproduce_the_padded_batch(name, slots):
     mels = job(19, 80, 7)                                       # 19 utterances of 2-9 frames (512 ... 2304 samples)
     pad = kw["cin_pad"]
     lengths = [mm.shape[-1] * HOP for mm in mels]
-    # reference run: ONE padded batch, row i = utterance i (in-kernel noise stream (step, i))
-    c = sharding.pad_group(mels, pad).cuda()
+    spk, extra, gids = None, {}, None
+    if kw.get("gin_channels", -1) > 0:                          # (round 5) a speaker per utterance: BASELINE configs[4]
+        spk = torch.randint(0, kw["n_speakers"], (len(mels),), generator=torch.Generator().manual_seed(3)).tolist()
+        extra, gids = {"speaker_ids": spk}, torch.tensor(spk, dtype=torch.int64).cuda()
+    # comparison run: ONE batch, row i = utterance i on its own conditioning and speaker (in-kernel noise stream (step, i))
     T = max(lengths)
-    want, _, _ = eng.generate(B=len(mels), T=T, c_up=eng.upsample(c, T_expected=T), seed=99, kernel=2)
+    want, _, _ = eng.generate(B=len(mels), T=T, c_up=own_conditioning(eng, mels, pad), g_ids=gids, seed=99, kernel=2)
     st = {}
-    got = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=pad, slots=slots, seed=99, stats=st)
+    got = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=pad, slots=slots, seed=99, stats=st, **extra)
     assert st["slots"] == slots and sum(st["utterances_per_slot"]) == len(mels) and max(st["utterances_per_slot"]) >= 3
     assert st["padding_loss"] < 0.25
     for i, (y, n) in enumerate(zip(got, lengths)):
@@ -50,19 +63,30 @@ def test_a_long_job_runs_as_several_launches_with_the_same_waveforms():
     st = {}
     many = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=5, max_slot_steps=6000, stats=st)
     assert len(st["launches"]) >= 2
-    # (the conditioning is upsampled in padded groups of neighbours, as the reference's padded batches are: an utterance that is not the
-    #  longest of its group sees zeros behind its last frame instead of its replicated edge -- the last cin_pad frames and the FIR
-    #  half-widths of its conditioning depend on its neighbours; everything before that is equal, sample for sample)
+    # (round 5: every utterance's conditioning is upsampled on its own -- no neighbour can reach it --, so the waveforms are equal to the
+    #  last sample; until round 4 the tail of an utterance depended on the padded group it was upsampled in)
     for a, b in zip(one, many):
-        n = a.shape[-1] - 4 * HOP
-        assert n > 0 and torch.equal(a[..., :n], b[..., :n])
+        assert torch.equal(a, b)
+    # ... and the byte bound of a launch splits the same way (a 256-way one-hot output is 1 KB per slot-step)
+    st2 = {}
+    capped = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=5, max_launch_bytes=3 * 6000 * st["step_bytes"], stats=st2)
+    assert len(st2["launches"]) >= 2 and all(torch.equal(a, b) for a, b in zip(one, capped))
+    # sink: results are handed over launch by launch instead of being kept
+    seen = {}
+    res = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=5, max_slot_steps=6000, sink=lambda i, y: seen.__setitem__(i, y.clone()))
+    assert all(r is None for r in res) and sorted(seen) == list(range(len(mels))) and all(torch.equal(seen[i], one[i]) for i in seen)
     m.to("cpu")
 
 
 def test_packed_slots_refuse_what_they_do_not_cover():
-    m = build("cfg4_mol_multispeaker").to("cuda")                # a speaker embedding: one bias table per row
-    with pytest.raises(NotImplementedError):
+    m = build("cfg4_mol_multispeaker").to("cuda")                # a speaker embedding: every utterance names its speaker
+    with pytest.raises(ValueError):
         sharding.synthesize_packed(m, job(4, 80, 1), hop_size=HOP, cin_pad=2)
+    with pytest.raises(IndexError):
+        sharding.synthesize_packed(m, job(4, 80, 1), hop_size=HOP, cin_pad=2, speaker_ids=[0, 1, 7, 2])
+    assert sharding.packed_unsupported_reason(build("wide_mol_512").to("cuda")) is not None      # the ring kernel does not take wide models
+    with pytest.raises(NotImplementedError):
+        sharding.synthesize_packed(build("wide_mol_512").to("cuda"), job(2, 80, 1), hop_size=HOP, cin_pad=2)
     m2 = build("cfg2_mol").to("cuda")
     eng = m2._get_engine()
     T, B = 512, 2

@@ -5,6 +5,7 @@ import torch
 
 import wavenet_vocoder_amd as wnv
 from oracle.wavenet_oracle import Oracle
+from tests._testlib import needs_test_lib
 from tests._configs import CONFIGS, build, inputs, tame_head_
 from tests._golden import oracle_config
 from tests._margins import assert_free_run_agrees_until_near_tie, assert_match_or_near_tie
@@ -68,6 +69,7 @@ def test_ring_equals_generic_kernel(B):
 
 
 @pytest.mark.parametrize("name,B", [("cfg2_mol", 8), ("cfg2_mol", 3), ("cfg3_gaussian", 5)])
+@needs_test_lib                                             # (the knobs exist in libwnv_test.so only: the test re-runs itself there)
 def test_split_rings_vs_oracle_and_generic(name, B, monkeypatch):
     """WNV_RING_SPLIT=1: two CUs per layer (run_stage_split; measured and not the default -- profiles/r03_ring_split_fine_timeline.txt).
     Teacher-forced head outputs against the oracle, then a free run against the generic kernel, and the layer-0-in-the-head switch
@@ -255,6 +257,7 @@ def test_ring_narrow_models_zero_padded_vs_oracle_and_generic(name):
     assert eng.last_kernel() == 2, "auto must pick the ring kernel for a model that fits its geometry after padding"
 
 
+@needs_test_lib
 def test_ring_slow_path_is_bit_identical(monkeypatch):
     """WNV_RING_FAST=0 forces the placement-independent write-through hand-offs; same arithmetic, same bits."""
     name = "cfg2_mol"

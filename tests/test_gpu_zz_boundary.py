@@ -15,6 +15,7 @@ import pytest
 import torch
 
 from tests._configs import CONFIGS, build, inputs
+from tests._testlib import TEST_LIB, needs_test_lib
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,6 +57,8 @@ print("RESULT " + json.dumps(res), flush=True)
 def run_child(env_extra, timeout=240, name="cfg2_mol", B=8, T=256, forced=2):
     env = dict(os.environ)
     env.update(env_extra)
+    if "WNV_RING_CENSUS" in env_extra:                       # a knob: the census REPORT on stderr exists in the test library only
+        env["WNV_LIB"] = TEST_LIB
     p = subprocess.Popen([sys.executable, "-c", CHILD % {"root": ROOT, "name": name, "B": B, "T": T, "forced": forced}], env=env,
                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     try:
@@ -95,6 +98,7 @@ def test_cu_mask_clean_timeout_then_fallback():
         assert res["forced"] == "ran" and res["forced_vs_generic"] < 1e-3, res
 
 
+@needs_test_lib                                                 # wnv_debug_inject_timeouts: include/wnv_test.h, libwnv_test.so
 def test_fast_path_comes_back_after_a_transient_timeout():
     """A handle whose ring launch timed out ONCE must not stay on the generic kernel for the rest of its life.
     Policy (wnv_host.cpp, persist_cooldown): the call that timed out and the next 2 are served by the generic kernel, then the
@@ -276,3 +280,23 @@ def test_streamed_replay_tape_equals_the_tape_drawn_up_front():
     del twin
     torch.manual_seed(77)
     assert torch.equal(m.incremental_forward(c=c, T=T), want)
+
+
+@pytest.mark.parametrize("extra", [[], ["--job", "6", "--packed"], ["--job", "6"]], ids=["fixed_batch", "job_packed", "job_padded"])
+def test_bench_distributed_leg_runs_on_rccl_with_one_rank(extra):
+    """The collectives a multi-GPU bench line executes -- init_process_group("nccl") = RCCL, both barriers around the timed region, the
+    MAX all_reduce, the all_gather of the rank report and, in job mode, the gather_object of the waveforms -- have run on a GPU at
+    least once, next to the persistent kernel, before a multi-GPU node ever sees them: `bench.py --force-dist`
+    forms a process group of ONE rank.  One JSON line, served by the ring kernel."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "1", "--no-extras",
+           "--T", "2048", *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, f"rc {r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 1 and j["value"] > 0
+    assert j["distributed"]["backend"] == "nccl" and j["distributed"]["forced_single_rank"] is True
+    assert j["ranks"]["last_kernel_by_rank"] == ["ring"], j["ranks"]
+    if extra:
+        assert j["job"]["utterances"] == 6 and "gather_object" in j["distributed"]["collectives"]

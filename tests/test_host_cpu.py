@@ -100,6 +100,56 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().wnv_abi_version() == _lib.WNV_ABI_VERSION
 
 
+def _dynamic_symbols(path):
+    import subprocess
+    out = subprocess.run(["nm", "-D", path], capture_output=True, text=True, check=True).stdout
+    return [ln.split() for ln in out.splitlines()]
+
+
+def test_product_library_reads_no_environment_and_has_no_test_hooks():
+    """The product library neither imports getenv / secure_getenv (csrc/wnv_knobs.h: the WNV_* measurement knobs are compiled out) nor
+    exports the hooks of include/wnv_test.h; the test library (libwnv_test.so, same sources + -DWNV_KNOBS -DWNV_TEST_HOOKS) has both."""
+    prod = os.path.join(ROOT, "wavenet_vocoder_amd", "libwnv_hip.so")
+    test = _lib.TEST_LIB_PATH
+    assert os.path.exists(prod) and os.path.exists(test), "run __graft_entry__.build() first"
+    psyms, tsyms = _dynamic_symbols(prod), _dynamic_symbols(test)
+    undefined = {s[-1].split("@")[0] for s in psyms if len(s) >= 2 and s[-2] == "U"}
+    assert not {"getenv", "secure_getenv", "setenv", "putenv"} & undefined, undefined & {"getenv", "secure_getenv"}
+    pexp = {s[-1] for s in psyms if len(s) == 3 and s[1] == "T" and s[2].startswith("wnv_")}
+    texp = {s[-1] for s in tsyms if len(s) == 3 and s[1] == "T" and s[2].startswith("wnv_")}
+    assert pexp == set(_lib.EXPORTED_SYMBOLS), pexp ^ set(_lib.EXPORTED_SYMBOLS)
+    assert texp == set(_lib.EXPORTED_SYMBOLS) | set(_lib.TEST_HOOK_SYMBOLS), texp ^ (set(_lib.EXPORTED_SYMBOLS) | set(_lib.TEST_HOOK_SYMBOLS))
+    # no getenv() call in the sources outside the knob header either
+    csrc = os.path.join(ROOT, "wavenet_vocoder_amd", "csrc")
+    for fn in os.listdir(csrc):
+        if fn != "wnv_knobs.h":
+            assert not re.search(r"\bgetenv\s*\(", open(os.path.join(csrc, fn), errors="ignore").read()), fn
+    hdr = open(os.path.join(ROOT, "include", "wnv_test.h")).read()
+    for n in _lib.TEST_HOOK_SYMBOLS:
+        assert n in hdr
+
+
+def test_kernel_coverage_is_a_host_decision():
+    from tests._configs import CONFIGS
+    import wavenet_vocoder_amd as wnv
+    from wavenet_vocoder_amd.engine import make_config
+    L = _lib.lib()
+    want = {"cfg2_mol": (b"supported", None), "cfg4_mol_multispeaker": (b"supported", None), "cfg0_mulaw256_small": (b"supported", None),
+            "wide_mol_512": (None, b"supported")}
+    for name, (ring, wide) in want.items():
+        m = wnv.WaveNet(**CONFIGS[name])
+        cfg = make_config(**m._wnv_config_kwargs())
+        r, w = L.wnv_kernel_coverage(ctypes.byref(cfg), 2, 8), L.wnv_kernel_coverage(ctypes.byref(cfg), 3, 8)
+        assert L.wnv_kernel_coverage(ctypes.byref(cfg), 1, 8) == b"supported"
+        if ring is not None:
+            assert r == ring, (name, r)
+        else:
+            assert r != b"supported" and b"residual_channels" in r, (name, r)
+        if wide is not None:
+            assert w == wide, (name, w)
+    assert L.wnv_kernel_coverage(ctypes.byref(cfg), 9, 8) == b"unknown kernel selector"
+
+
 def test_pure_host_entry_points():
     L = _lib.lib()
     assert L.wnv_receptive_field(30, 3, 3) == 6139 and L.wnv_receptive_field(24, 4, 3) == 505

@@ -13,11 +13,14 @@ from typing import Optional
 __all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "ForwardArgs", "MelConfig", "LogmelArgs", "LIB_PATH",
            "WNV_ABI_VERSION", "DIST", "UPSAMPLE"]
 
-WNV_ABI_VERSION = 4
+WNV_ABI_VERSION = 5
 WNV_MAX_UPSAMPLE_STAGES = 8
 WNV_GEN_ASYNC = 1
-# WNV_LIB selects another build of the same sources (debug/trace builds: python -m wavenet_vocoder_amd.build --out ... --flags ...)
-LIB_PATH = os.environ.get("WNV_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libwnv_hip.so")
+# WNV_LIB selects another build of the same sources: the TEST library (libwnv_test.so: knobs + the hooks of include/wnv_test.h) or a
+# debug / trace build (python -m wavenet_vocoder_amd.build --out ... --flags ...)
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("WNV_LIB") or os.path.join(_HERE, "libwnv_hip.so")
+TEST_LIB_PATH = os.path.join(_HERE, "libwnv_test.so")
 
 DIST = {"categorical": 0, "Logistic": 1, "Normal": 2}
 UPSAMPLE = {None: 0, "none": 0, "ConvInUpsampleNetwork": 1, "UpsampleNetwork": 2}
@@ -69,6 +72,7 @@ class GenerateArgs(C.Structure):
         ("seed", C.c_uint64), ("softmax", C.c_int32), ("quantize", C.c_int32), ("out", C.c_void_p),
         ("params_out", C.c_void_p), ("index_out", C.c_void_p), ("kernel", C.c_int32), ("flags", C.c_int32),
         ("stream", C.c_void_p), ("noise_ready", C.c_void_p), ("seg_start", C.c_void_p), ("seg_uid", C.c_void_p),
+        ("seg_gid", C.c_void_p), ("n_g", C.c_int32),
     ]
 
 
@@ -127,8 +131,7 @@ _PROTOS = {
     "wnv_reset": (C.c_int, [C.c_void_p]),
     "wnv_wait": (C.c_int, [C.c_void_p]),
     "wnv_last_kernel": (C.c_int32, [C.c_void_p]),
-    "wnv_debug_inject_timeouts": (C.c_int, [C.c_void_p, C.c_int32]),
-    "wnv_measure_lds_read_peak": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "wnv_kernel_coverage": (C.c_char_p, [C.POINTER(Config), C.c_int32, C.c_int32]),
     "wnv_qconv_create": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "wnv_qconv_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "wnv_qconv_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
@@ -151,7 +154,14 @@ _PROTOS = {
     "wnv_macs_per_sample": (C.c_int64, [C.c_void_p]),
 }
 
+# include/wnv_test.h: exported by the TEST library only (a product library that exports them is a build error: tests/test_host_cpu.py)
+_TEST_PROTOS = {
+    "wnv_debug_inject_timeouts": (C.c_int, [C.c_void_p, C.c_int32]),
+    "wnv_measure_lds_read_peak": (C.c_int, [C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+}
+
 EXPORTED_SYMBOLS = tuple(sorted(_PROTOS))
+TEST_HOOK_SYMBOLS = tuple(sorted(_TEST_PROTOS))
 
 _lib: Optional[C.CDLL] = None
 
@@ -174,10 +184,42 @@ def lib() -> C.CDLL:
             raise WnvError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in _TEST_PROTOS.items():           # present in a test / knob build only
+        fn = getattr(handle, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     if handle.wnv_abi_version() != WNV_ABI_VERSION:
         raise WnvError(f"{LIB_PATH} has ABI {handle.wnv_abi_version()}, this package needs {WNV_ABI_VERSION}")
     _lib = handle
     return handle
+
+
+def has_test_hooks() -> bool:
+    """True when the loaded library is a test / knob build (WNV_LIB=.../libwnv_test.so)."""
+    return hasattr(lib(), "wnv_debug_inject_timeouts")
+
+
+_bench_tool: Optional[C.CDLL] = None
+
+
+def measure_lds_read_peak(device: int):
+    """(GB/s, CUs) from the microbenchmark of include/wnv_test.h.  A bench tool, not product: it lives in libwnv_test.so, which is
+    loaded here (RTLD_LOCAL, next to the product library) for this one call when the process runs on the product library."""
+    global _bench_tool
+    h = lib() if has_test_hooks() else _bench_tool
+    if h is None:
+        if not os.path.exists(TEST_LIB_PATH):
+            raise WnvError(f"{TEST_LIB_PATH} is missing (python -m wavenet_vocoder_amd.build builds it next to the product library)")
+        h = _bench_tool = C.CDLL(TEST_LIB_PATH, mode=C.RTLD_LOCAL)
+        h.wnv_measure_lds_read_peak.restype, h.wnv_measure_lds_read_peak.argtypes = _TEST_PROTOS["wnv_measure_lds_read_peak"]
+        h.wnv_last_error.restype = C.c_char_p
+    gbs, ncu = C.c_double(0.0), C.c_int32(0)
+    st = h.wnv_measure_lds_read_peak(int(device), C.byref(gbs), C.byref(ncu))
+    if st != 0:
+        msg = h.wnv_last_error()
+        raise WnvError(msg.decode("utf-8", "replace") if msg else f"wnv status {st}")
+    return gbs.value, int(ncu.value)
 
 
 def check(status: int) -> None:

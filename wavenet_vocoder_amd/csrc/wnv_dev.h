@@ -55,6 +55,7 @@ struct WnvGenArgs {
     int* index_out;          // (B, T) or null
     const unsigned* noise_ready = nullptr;   // streamed tape: steps [0, *noise_ready) are valid (coherent host memory); ring kernel only
     const int *seg_start = nullptr, *seg_uid = nullptr;   // packed slots (wnv_generate_args): (B, T) each; ring kernel only
+    const int* seg_gid = nullptr;                         // packed slots + global conditioning: (B, T) row of zbias (which then has n_g rows, not B)
     int b0 = 0, noise_B = 0; // a slice [b0, b0 + B) of a larger call (host-side chunking): the utterance index the noise tape /
                              // Philox stream is addressed with is b0 + b, the tape's batch stride is noise_B (0: B)
 };

@@ -19,6 +19,9 @@
 #include <vector>
 
 #include "../../include/wnv.h"
+#ifdef WNV_TEST_HOOKS
+#include "../../include/wnv_test.h"
+#endif
 #include "wnv_internal.h"
 #include "wnv_store.h"
 #include "wnv_ring.h"
@@ -26,6 +29,7 @@
 #include "wnv_forward.h"
 
 #include "wnv_hostutil.h"
+#include "wnv_knobs.h"
 
 struct wnv_engine {
     wnv_config cfg{};
@@ -356,10 +360,26 @@ extern "C" wnv_status wnv_wait(wnv_handle h) {
 }
 
 extern "C" int32_t wnv_last_kernel(wnv_handle h) { return h ? h->last_kernel : 0; }
+#ifdef WNV_TEST_HOOKS      // include/wnv_test.h: the test library only (libwnv_test.so)
 extern "C" wnv_status wnv_debug_inject_timeouts(wnv_handle h, int32_t n) {
     if (!h || n < 0) return fail(WNV_ERR_INVALID_ARG, "bad arguments to wnv_debug_inject_timeouts");
     h->inject_timeouts = n;
     return WNV_OK;
+}
+#endif
+
+// Which configurations a sample-loop kernel covers, decided from the configuration alone (pure host code, no device): "supported" or
+// the reason -- the same strings wnv_generate reports with WNV_ERR_UNSUPPORTED.  kernel: 1 generic (covers everything), 2 pipelined
+// ring, 3 group ring (wide models).
+extern "C" const char* wnv_kernel_coverage(const wnv_config* cfg, int32_t kernel, int32_t B) {
+    if (!cfg) return "cfg is NULL";
+    if (cfg->abi_version != WNV_ABI_VERSION) return "abi_version mismatch";
+    switch (kernel) {
+        case 1: return "supported";
+        case 2: return wnv_ring_why_not(*cfg, B);
+        case 3: return wnv_wide_why_not(*cfg, B);
+        default: return "unknown kernel selector";
+    }
 }
 
 extern "C" wnv_status wnv_reset(wnv_handle h) {
@@ -639,7 +659,7 @@ struct PersistentTurn {
 PersistentTurn g_turns[64];
 class TurnGuard {                   // construct with the device current (DeviceGuard)
   public:
-    TurnGuard(int device, hipStream_t s) : t_(g_turns[device & 63]), s_(s), on_(!std::getenv("WNV_NO_TURN")) {   // (diagnostic knob:
+    TurnGuard(int device, hipStream_t s) : t_(g_turns[device & 63]), s_(s), on_(!wnv_knob("WNV_NO_TURN")) {   // (diagnostic knob:
         if (!on_) return;                                                // tests/test_gpu_zz_boundary.py shows what the turn prevents)
         t_.m.lock();
         if (t_.done) (void)hipStreamWaitEvent(s_, t_.done, 0);
@@ -679,11 +699,15 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         return fail(WNV_ERR_INVALID_ARG, "a streamed noise tape (noise_ready) needs noise, kernel = 2 and WNV_GEN_ASYNC: the caller fills the tape while the kernel runs");
     if ((a->seg_start == nullptr) != (a->seg_uid == nullptr)) return fail(WNV_ERR_INVALID_ARG, "seg_start and seg_uid come together (packed slots)");
     if (a->seg_start) {
-        if (a->noise || a->teacher || a->initial || a->g || a->g_ids)
-            return fail(WNV_ERR_INVALID_ARG, "packed slots take in-kernel noise and no teacher / initial input / global conditioning (one bias table per slot)");
+        if (a->noise || a->teacher || a->initial)
+            return fail(WNV_ERR_INVALID_ARG, "packed slots take in-kernel noise and no teacher / initial input");
+        if (m.gin > 0 && (!a->seg_gid || a->n_g <= 0))
+            return fail(WNV_ERR_INVALID_ARG, "packed slots of a model with global conditioning need seg_gid (B, T) and n_g > 0 rows of g / g_ids");
+        if (m.gin == 0 && (a->seg_gid || a->n_g != 0)) return fail(WNV_ERR_INVALID_ARG, "seg_gid / n_g given but the model has no global conditioning");
         if (a->kernel != 0 && a->kernel != 2) return fail(WNV_ERR_UNSUPPORTED, "packed slots run on the pipelined ring kernel only");
         if (!(wnv_ring_supported(c, a->B) && wnv_ring_default())) return fail(WNV_ERR_UNSUPPORTED, "packed slots need the pipelined ring kernel: %s", wnv_ring_why_not(c, a->B));
     }
+    if (!a->seg_start && (a->seg_gid || a->n_g != 0)) return fail(WNV_ERR_INVALID_ARG, "seg_gid / n_g belong to packed slots (seg_start, seg_uid)");
     if ((a->flags & WNV_GEN_ASYNC) && a->B > 64) return fail(WNV_ERR_INVALID_ARG, "WNV_GEN_ASYNC takes at most 64 utterances per call (larger batches run as several launches)");
     DeviceGuard g(h->device);
     hipStream_t s = (hipStream_t)a->stream;
@@ -694,7 +718,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         if (pst != WNV_OK) return fail(pst, "deferred from the previous asynchronous call: %s", err.c_str());
     }
     const bool has_g = m.gin > 0;
-    const int Bz = has_g ? a->B : 1;
+    const int Bz = has_g ? (a->seg_gid ? a->n_g : a->B) : 1;         // (packed slots: one row per speaker / utterance of the job, picked through seg_gid)
     HIP_TRY(h->zbias.ensure((size_t)Bz * m.L * m.Gp * sizeof(float)));
     HIP_TRY(wnv_launch_zbias(m, h->d_layers, h->d_W, has_g ? a->g : nullptr, (has_g && !a->g) ? (const long long*)a->g_ids : nullptr,
                              h->embed_off >= 0 ? h->d_W + h->embed_off : nullptr, Bz, (float*)h->zbias.p, s));
@@ -710,7 +734,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     ga.seed = a->seed; ga.softmax = a->softmax; ga.quantize = c.scalar_input ? 1 : a->quantize;
     ga.nz = wnv_noise_width(&c);
     ga.noise_ready = a->noise_ready;
-    ga.seg_start = a->seg_start; ga.seg_uid = a->seg_uid;
+    ga.seg_start = a->seg_start; ga.seg_uid = a->seg_uid; ga.seg_gid = a->seg_gid;
     ga.out = a->out; ga.params_out = a->params_out; ga.index_out = a->index_out;
     // asynchronous ring launches only when the caller chose the ring explicitly: auto mode must see the status to fall back
     ga.async = (a->flags & WNV_GEN_ASYNC) && a->kernel == 2;
@@ -752,11 +776,14 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
         HIP_TRY(zero_onehot_out());
         std::string err;
         wnv_status st;
+#ifdef WNV_TEST_HOOKS
         if (a->kernel == 0 && h->inject_timeouts > 0) {              // test hook (wnv_debug_inject_timeouts): exercises the time-out policy
             --h->inject_timeouts;                                     // below without a device that cannot keep the launch resident
             st = WNV_ERR_TIMEOUT;                                     // (tests/test_gpu_zz_boundary.py; the real thing: the CU-mask tests)
             err = "injected by wnv_debug_inject_timeouts";
-        } else {
+        } else
+#endif
+        {
             TurnGuard turn(h->device, s);
             st = wnv_ring_generate(&h->ring_state, h->device, c, h->store, ga, s, err);
         }

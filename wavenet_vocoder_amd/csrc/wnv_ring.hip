@@ -44,6 +44,7 @@
 #include <cstring>
 #include <vector>
 
+#include "wnv_knobs.h"
 #include "wnv_matvec.h"
 #include "wnv_sample.h"
 
@@ -97,6 +98,8 @@ struct RingParams {
     const int *seg_start, *seg_uid;    // PACKED SLOTS (wnv_generate_args, ABI 4): [B][T] each -- the step at which the utterance occupying slot b at step t
                                        // began, and its id in the job; null: one utterance per row.  An utterance's history before its first step reads as
                                        // zeros (tap workgroups), its first input is zeros / one-hot 127 and its noise stream is (uid, t - start) (heads)
+    const int* seg_gid;                // packed slots of a model with global conditioning: [B][T] row of zbias (speaker / utterance of the job) of the
+                                       // utterance occupying slot b at step t; zbias then has one row per speaker / utterance, not per slot
     float *out, *params_out;
     unsigned int* status;
     unsigned long long* trace;         // optional [T_trace][upr][S+1][16] wall-clock stamps of ring 0's utterances (debug)
@@ -836,7 +839,8 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
             const int rb = b0 + u0 + pu;
             float zb0 = 0.f, zb1 = 0.f;                                      // the utterance's effective conv bias: requested ahead of the FMAs
             if (pub) {
-                const float* zrow = zbase + (size_t)rb * p.zbias_bstride;
+                // (packed slots: the bias row of the utterance that occupies the slot at step tp -- its speaker)
+                const float* zrow = zbase + (size_t)((PACKED && p.seg_gid) ? p.seg_gid[(size_t)rb * p.T + tp] : rb) * p.zbias_bstride;
                 if (z0) zb0 = zrow[0];
                 if (z1) zb1 = zrow[1];
             }
@@ -2206,7 +2210,7 @@ static const char* why_not(const wnv_config& c, int B) {
 }
 bool wnv_ring_supported(const wnv_config& c, int B) { return why_not(c, B) == nullptr; }
 bool wnv_ring_default() {
-    const char* e = getenv("WNV_RING");
+    const char* e = wnv_knob("WNV_RING");
     if (e && *e) return e[0] != '0';
     return WNV_RING_IS_DEFAULT != 0;
 }
@@ -2349,7 +2353,7 @@ wnv_status wnv_placement_census(int device, int* ncu_out, int* n_xcd_out, bool* 
     const int n_xcd = __builtin_popcount(seen & ~1u);
     bool map_ok = n_xcd >= 1;
     for (int b = 0; b < n && map_ok; ++b) map_ok = x[b] != 0u && x[b] == x[b % n_xcd];
-    if (const char* e = getenv("WNV_RING_CENSUS"); e && e[0] == '1')
+    if (const char* e = wnv_knob("WNV_RING_CENSUS"); e && e[0] == '1')
         fprintf(stderr, "[wnv] device %d: %d CUs, %d XCDs, block -> XCD (b %% %d) mapping %s\n", device, ncu, n_xcd, n_xcd,
                 map_ok ? "verified" : "NOT as assumed");
     *ncu_out = ncu; *n_xcd_out = n_xcd; *map_ok_out = map_ok;
@@ -2581,11 +2585,12 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
             if (ga.c_up) g.c_up = ga.c_up + (size_t)b0 * ga.T * cin;
             if (ga.initial) g.initial = ga.initial + (size_t)b0 * cin1;
             if (ga.teacher) g.teacher = ga.teacher + (size_t)b0 * ga.Tt * cin1;
-            if (ga.zbias_bstride != 0) g.zbias = ga.zbias + (size_t)b0 * ga.zbias_bstride;
+            if (ga.zbias_bstride != 0 && !ga.seg_gid) g.zbias = ga.zbias + (size_t)b0 * ga.zbias_bstride;
             g.out = ga.out + (size_t)b0 * cin1 * ga.T;
             if (ga.params_out) g.params_out = ga.params_out + (size_t)b0 * O * ga.T;
             if (ga.index_out) g.index_out = ga.index_out + (size_t)b0 * ga.T;
             if (ga.seg_start) { g.seg_start = ga.seg_start + (size_t)b0 * ga.T; g.seg_uid = ga.seg_uid + (size_t)b0 * ga.T; }
+            if (ga.seg_gid) g.seg_gid = ga.seg_gid + (size_t)b0 * ga.T;
             const wnv_status s0 = wnv_ring_generate(pst, device, c, store, g, stream, err);
             if (s0 != WNV_OK) return s0;
         }
@@ -2614,7 +2619,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     const int P = st->S + NK;                                      // workgroups (grid positions) of one ring
     // scalar-input models with 128 skip channels: the head evaluates layer 0 (run_head), position 0 of every ring exits at once
     bool head_l0 = st->cin1 == 1 && NK == 1 && st->S >= 2;
-    { const char* e = getenv("WNV_RING_L0"); if (e && e[0] == '0') head_l0 = false; }
+    { const char* e = wnv_knob("WNV_RING_L0"); if (e && e[0] == '0') head_l0 = false; }
     const int Plive = P - (head_l0 ? 1 : 0);
     auto rings_that_fit = [&](int parts) {
         for (int n = std::min(B, 8); n >= 1; --n) {
@@ -2627,7 +2632,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     int tap_parts = B > TB ? 2 : 1;
     int tb = TB;                                                   // utterances per tap pass
     // WNV_RING_TAP=<parts>,<utterances per pass>: measurement knob (profiles/r04_tap_parts.txt)
-    if (const char* e = getenv("WNV_RING_TAP")) {
+    if (const char* e = wnv_knob("WNV_RING_TAP")) {
         int a = 0, b = 0;
         if (sscanf(e, "%d,%d", &a, &b) == 2 && a >= 1 && a <= 4 && b >= 1 && b <= TB) { tap_parts = a; tb = b; }
     }
@@ -2645,7 +2650,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     // ring crosses XCDs (u, the residual partials and the skip sums: 0.5-0.8 us each): 441-453 against 472-479 kSamples/s on one box.
     // WNV_RING_SPLIT=1 selects it (parity-tested: tests/test_gpu_ring.py::test_split_rings_vs_oracle_and_generic).
     bool split = false;
-    { const char* e = getenv("WNV_RING_SPLIT"); if (e && e[0] == '1') split = head_l0 && st->has_split && st->S >= 3 && B <= 16; }
+    { const char* e = wnv_knob("WNV_RING_SPLIT"); if (e && e[0] == '1') split = head_l0 && st->has_split && st->S >= 3 && B <= 16; }
     int sA = 0, max_slots = 0;
     if (split) {
         sA = (2 * (st->S - 1) + 1) / 4;
@@ -2669,7 +2674,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.pstride = std::max(GC, st->Kp);
     p.hist_floats = st->hist_floats;
     p.skip_scale = (float)std::sqrt(1.0 / st->L);
-    { const char* e = getenv("WNV_RING_FAST"); p.allow_fast = !(e && e[0] == '0'); }
+    { const char* e = wnv_knob("WNV_RING_FAST"); p.allow_fast = !(e && e[0] == '0'); }
     const float* w = st->d_w;
     p.w2img = w + st->o_w2; p.wnimg = w + st->o_wn; p.cvec = w + st->o_cvec; p.woimg = w + st->o_wo; p.bo = w + st->o_bo; p.wpre = w + st->o_wpre;
     p.wsimg = w + st->o_ws; p.bskip = w + st->o_bskip; p.wh1img = w + st->o_wh1; p.bh1 = w + st->o_bh1;
@@ -2725,7 +2730,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.c_up = ga.c_up; p.initial = ga.initial; p.teacher = ga.teacher; p.noise = ga.noise; p.seed = ga.seed;
     p.b0 = ga.b0; p.noise_B = ga.noise_B > 0 ? ga.noise_B : B;
     p.noise_ready = ga.noise_ready;
-    p.seg_start = ga.seg_start; p.seg_uid = ga.seg_uid;
+    p.seg_start = ga.seg_start; p.seg_uid = ga.seg_uid; p.seg_gid = ga.seg_gid;
     p.out = ga.out; p.params_out = ga.params_out;
     // LDS: the stage carve is the larger one
     // tap workgroups: K rows per wave (a multiple of 4), first in VGPRs, then in LDS, the remainder streams from L2
@@ -2743,7 +2748,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     // (K = 512: a stage is busy ~3.8 us per utterance -- four skip passes, two of them streamed --, so its occupancy counts from two utterances per
     //  ring on: the throughput instantiation measured +1-2 % at B = 16 / 32 (WNV_RING_MODE knob; both settings in profiles/r04_final_numbers.txt))
     int mode = ga.seg_start ? 2 : (upr > 4 || (NK == 4 && upr >= 2)) ? 1 : 0;
-    if (const char* e = getenv("WNV_RING_MODE")) { if (mode != 2 && (e[0] == '0' || e[0] == '1')) mode = e[0] - '0'; }   // measurement knob
+    if (const char* e = wnv_knob("WNV_RING_MODE")) { if (mode != 2 && (e[0] == '0' || e[0] == '1')) mode = e[0] - '0'; }   // measurement knob
     if (split && mode == 2) { err = "ring kernel: packed slots and split rings do not combine"; return WNV_ERR_UNSUPPORTED; }
 #define WNV_PICK(NKV, L0V) (mode == 2 ? (const void*)wnv_ring_kernel<NKV, L0V, 2> : mode == 1 ? (const void*)wnv_ring_kernel<NKV, L0V, 1> : (const void*)wnv_ring_kernel<NKV, L0V, 0>)
     const void* kfn = split ? (const void*)wnv_ring_kernel_split
@@ -2771,7 +2776,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         }
     }
     // optional timeline (WNV_RING_TRACE=<file>): wall-clock stamps of utterance 0 for 8 steps in mid-run
-    const char* trace_path = getenv("WNV_RING_TRACE");
+    const char* trace_path = wnv_knob("WNV_RING_TRACE");
     unsigned long long* d_trace = nullptr;
     const int trace_n = 8;
     size_t trace_words = 0;
@@ -2851,7 +2856,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
         }
     }
 #ifdef WNV_DBG_MARK
-    if (status == 0 && getenv("WNV_RING_MISS_COUNT")) {             // (diagnostic build) the throughput prologue's first look: what was not there yet
+    if (status == 0 && wnv_knob("WNV_RING_MISS_COUNT")) {             // (diagnostic build) the throughput prologue's first look: what was not there yet
         std::vector<unsigned> mk(1024);
         (void)hipMemcpy(mk.data(), p.xcc, 4096, hipMemcpyDeviceToHost);
         fprintf(stderr, "[wnv miss] of %d utterance-steps per stage, ring 0, by stage: pre / h_{l-2} / q not there at the first look:", p.T * upr);
@@ -2860,7 +2865,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     }
 #endif
     if (status != 0) {
-        if (getenv("WNV_RING_DEBUG_DUMP")) {                        // (failure path only) where did the records of utterance 0 get to?
+        if (wnv_knob("WNV_RING_DEBUG_DUMP")) {                        // (failure path only) where did the records of utterance 0 get to?
             std::vector<u64> f(n_f / B), q(n_p / B);
             (void)hipMemcpy(f.data(), p.fmail, f.size() * sizeof(u64), hipMemcpyDeviceToHost);
             (void)hipMemcpy(q.data(), p.pmail, q.size() * sizeof(u64), hipMemcpyDeviceToHost);

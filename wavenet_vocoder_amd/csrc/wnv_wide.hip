@@ -37,6 +37,7 @@
 #include <cstring>
 #include <vector>
 
+#include "wnv_knobs.h"
 #include "wnv_sample.h"
 
 namespace {
@@ -1319,7 +1320,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
     p.head_x = head_x; p.head_li = head_li;
     p.NB = st->NB; p.KW = KWD * st->NB;
     p.cin1 = st->cin1; p.softmax = ga.softmax; p.quantize = ga.quantize; p.index_out = ga.index_out;
-    { const char* e = getenv("WNV_RING_FAST"); p.fast = !(e && e[0] == '0'); }
+    { const char* e = wnv_knob("WNV_RING_FAST"); p.fast = !(e && e[0] == '0'); }
     p.skip_scale = (float)std::sqrt(1.0 / L);
     const float* w = st->d_w;
     p.wn = w + st->o_wn; p.wm = w + st->o_wm; p.wo = w + st->o_wo; p.ws = w + st->o_ws; p.wsl = w + st->o_wsl; p.bo = w + st->o_bo; p.bs = w + st->o_bs;
@@ -1377,7 +1378,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
         }
     }
     // optional timeline (WNV_WIDE_TRACE=<file>): wall-clock stamps of utterance 0 at slice 0 of every group, 8 steps in mid-run
-    const char* trace_path = getenv("WNV_WIDE_TRACE");
+    const char* trace_path = wnv_knob("WNV_WIDE_TRACE");
     unsigned long long* d_trace = nullptr;
     const int trace_n = 8;
     size_t trace_words = 0;
@@ -1386,7 +1387,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
         WIDE_HIP(hipMalloc((void**)&d_trace, trace_words * sizeof(unsigned long long)));
         WIDE_HIP(hipMemsetAsync(d_trace, 0, trace_words * sizeof(unsigned long long), stream));
         p.trace = d_trace; p.trace_t0 = std::min(p.T / 2, 1000); p.trace_n = trace_n;
-        { const char* e = getenv("WNV_WIDE_TRACE_B"); p.trace_b = e ? std::min(std::max(atoi(e), 0), B - 1) : 0; }
+        { const char* e = wnv_knob("WNV_WIDE_TRACE_B"); p.trace_b = e ? std::min(std::max(atoi(e), 0), B - 1) : 0; }
     }
     const int max_li = std::max(nL * PG - 1, head_li + n_head - 1);
     const int grid = 8 * (max_li + 1);

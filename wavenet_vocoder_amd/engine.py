@@ -253,11 +253,13 @@ class Engine:
     def generate(self, *, B: int, T: int, c_up=None, g=None, g_ids=None, initial=None, teacher=None,
                  noise=None, seed: int = 0, softmax: bool = True, quantize: bool = True,
                  want_params: bool = False, want_index: bool = False, kernel: int = 0, asynchronous: bool = False,
-                 noise_ready=None, seg_start=None, seg_uid=None):
+                 noise_ready=None, seg_start=None, seg_uid=None, seg_gid=None):
         """Runs the whole autoregressive loop.  Returns (out (B,C,T), params (B,O,T)|None, index (B,T)|None).
         ``asynchronous`` (ring kernel chosen explicitly, kernel=2): return right after the launch; ``wait()`` or the next
         call reports a bounded-spin timeout (WNV_GEN_ASYNC in include/wnv.h).  ``noise`` / ``noise_ready`` may be device
-        addresses (ints) of a PinnedBuffer: a tape the caller keeps filling while the kernel runs (needs kernel=2, asynchronous)."""
+        addresses (ints) of a PinnedBuffer: a tape the caller keeps filling while the kernel runs (needs kernel=2, asynchronous).
+        ``seg_start`` / ``seg_uid`` (+ ``seg_gid`` for models with global conditioning: ``g`` / ``g_ids`` then hold one row per speaker or
+        per utterance of the job and ``seg_gid[b][t]`` picks the row): packed slots, include/wnv.h."""
         dev = self.device
         cfg = self.cfg
         C_out = 1 if cfg.scalar_input else cfg.out_channels
@@ -285,6 +287,16 @@ class Engine:
                 if tns.dtype != torch.int32 or not tns.is_contiguous() or tuple(tns.shape) != (B, T):
                     raise ValueError(f"{name} must be a contiguous int32 (B, T) = {(B, T)} tensor, got {tns.dtype} {tuple(tns.shape)}")
             a.seg_start, a.seg_uid = _ptr(seg_start), _ptr(seg_uid)
+            if seg_gid is not None:
+                require_gpu_tensor(seg_gid, "seg_gid")
+                if seg_gid.dtype != torch.int32 or not seg_gid.is_contiguous() or tuple(seg_gid.shape) != (B, T):
+                    raise ValueError(f"seg_gid must be a contiguous int32 (B, T) = {(B, T)} tensor, got {seg_gid.dtype} {tuple(seg_gid.shape)}")
+                rows = g if g is not None else g_ids
+                if rows is None:
+                    raise ValueError("seg_gid needs g or g_ids (one row per speaker / utterance of the job)")
+                a.seg_gid, a.n_g = _ptr(seg_gid), int(rows.shape[0])
+        elif seg_gid is not None:
+            raise ValueError("seg_gid belongs to packed slots (seg_start, seg_uid)")
         check(_lib.lib().wnv_generate(self._h, C.byref(a)))
         return out, params, index
 
@@ -297,12 +309,20 @@ class Engine:
         kernel that timed out be tried again by the very next call (include/wnv.h).  The weights stay loaded."""
         check(_lib.lib().wnv_reset(self._h))
 
+    def kernel_coverage(self, kernel: int, B: int = 1) -> str:
+        """``wnv_kernel_coverage``: "supported", or why the kernel (2 ring, 3 group ring) does not take this configuration."""
+        why = _lib.lib().wnv_kernel_coverage(C.byref(self.cfg), int(kernel), int(B))
+        return why.decode("utf-8", "replace") if why else "supported"
+
     def last_kernel(self) -> int:
         """1 = generic kernel, 2 = pipelined ring kernel served the last ``generate`` (0: none yet)."""
         return int(_lib.lib().wnv_last_kernel(self._h))
 
     def inject_timeouts(self, n: int) -> None:
-        """Test hook (``wnv_debug_inject_timeouts``): the next ``n`` ring launches of auto mode report a time-out unlaunched."""
+        """Test hook (``wnv_debug_inject_timeouts``, include/wnv_test.h): the next ``n`` ring launches of auto mode report a time-out
+        unlaunched.  Exists in the TEST library only (WNV_LIB=.../libwnv_test.so)."""
+        if not _lib.has_test_hooks():
+            raise RuntimeError("wnv_debug_inject_timeouts is a hook of the test library: run with WNV_LIB=" + _lib.TEST_LIB_PATH)
         check(_lib.lib().wnv_debug_inject_timeouts(self._h, int(n)))
 
 

@@ -92,41 +92,22 @@ def write_wav(path: str, sample_rate: int, pcm: np.ndarray) -> None:
         f.write(data)
 
 
-def _synthesize_packed(model, mels, hparams, group):
-    """The job as packed slots: every rank packs its share (longest-first over the ranks), the post-chain of synthesis.py:66-84 runs
-    per UTTERANCE (the inverse pre-emphasis is an IIR: its state must not leak across a slot's boundaries) on padded batches of the
-    finished waveforms, rank 0 gathers.  Returns the list of clipped float waveforms on rank 0, None elsewhere."""
-    import torch.distributed as dist
+def _packed_local(model, mels, hparams, mine, speaker_ids=None) -> dict:
+    """This rank's utterances ``mine`` as packed slots -> {utterance index: clipped float waveform on the CPU}.  The post-chain of
+    synthesis.py:66-84 runs per UTTERANCE (the inverse pre-emphasis is an IIR: its state must not leak across a slot's boundaries) as
+    soon as the utterance's launch is done (``sink``): only one launch's buffers live on the device, whatever the size of the job
+    (a 256-way one-hot output is 1 KB per sample).  No collective in here: a rank may fall back to padded groups on its own."""
     from . import synthesis
-    distributed = dist.is_available() and dist.is_initialized()
-    rank = dist.get_rank(group) if distributed else 0
-    world = dist.get_world_size(group) if distributed else 1
-    model.eval()
-    lengths = [int(m.shape[-1]) * hparams.hop_size for m in mels]
-    mine = sharding.lpt_assign(lengths, world)[rank]
-    with torch.no_grad():
-        outs = sharding.synthesize_packed(model, mels, hop_size=hparams.hop_size, cin_pad=hparams.cin_pad, indices=mine)
     local = {}
-    order = sorted(range(len(mine)), key=lambda k: -lengths[mine[k]])
-    for a in range(0, len(order), 32):                              # post-chain on padded batches of neighbouring length
-        grp = order[a:a + 32]
-        Tm = max(lengths[mine[k]] for k in grp)
-        y = torch.zeros(len(grp), outs[grp[0]].shape[0], Tm, device=outs[grp[0]].device)
-        for row, k in enumerate(grp):
-            y[row, :, :lengths[mine[k]]] = outs[k]
-        wav = synthesis.postprocess(y, hparams).clamp_(-1.0, 1.0)
-        for row, k in enumerate(grp):
-            local[mine[k]] = wav[row, :lengths[mine[k]]].detach().to("cpu")
-    if not distributed:
-        return [local[i] for i in range(len(mels))]
-    parts = [None] * world if rank == 0 else None
-    dist.gather_object(local, parts, dst=0, group=group)
-    if rank != 0:
-        return None
-    merged = {}
-    for part in parts:
-        merged.update(part)
-    return [merged[i] for i in range(len(mels))]
+
+    def sink(i, y):
+        wav = synthesis.postprocess(y.unsqueeze(0), hparams).clamp_(-1.0, 1.0)
+        local[i] = wav[0, : y.shape[-1]].detach().to("cpu")
+
+    with torch.no_grad():
+        sharding.synthesize_packed(model, mels, hop_size=hparams.hop_size, cin_pad=hparams.cin_pad, indices=mine, sink=sink,
+                                   speaker_ids=speaker_ids)
+    return local
 
 
 def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterances: int = -1,
@@ -139,10 +120,14 @@ def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterance
     set (the reference's recipes pass 32, egs/mol/run.sh:31), otherwise from the measured throughput curve
     (``sharding.auto_group_size``: up to 48 per GPU).
 
-    ``packed`` (round 4): run the job as PACKED SLOTS -- continuous batching, ``sharding.synthesize_packed``: no padding to a group's
-    longest member, every waveform is what the utterance gives on its own -- instead of padded groups.  None (default): when nothing
-    fixes the grouping (no ``synth_group``, no ``hparams.batch_size``), the model has no speaker embedding and the ring kernel takes
-    it; a model or device the packed path does not cover falls back to padded groups."""
+    ``packed``: run the job as PACKED SLOTS -- continuous batching, ``sharding.synthesize_packed``: no padding to a group's longest
+    member, every waveform is what the utterance gives on its own -- instead of padded groups.  Packed slots draw their noise IN THE
+    KERNEL (Philox streams addressed by utterance and step) and leave the kernel choice to the engine, so None (default) packs only when
+    that is what the model is set to anyway -- ``model.rng == "philox"`` and ``model.kernel`` in (0, 2) --, nothing fixes the grouping
+    (no ``synth_group``, no ``hparams.batch_size``), the job is larger than one launch per GPU and the ring kernel covers the model
+    (speaker-conditioned models included since round 5: the utterances' speaker ids from train.txt).  ``packed=True`` asks for it
+    explicitly (a ``rng = "replay"`` model then still draws in-kernel noise).  A rank whose packed run cannot proceed (model or device
+    not covered, time-out, out of memory) runs its share as padded groups; every rank meets in the one gather at the end."""
     from . import synthesis
     utts = collect_features(data_dir, speaker_id=speaker_id, num_utterances=num_utterances)
     assert len(utts) > 0, f"no *-feats.npy under {data_dir}"
@@ -155,22 +140,34 @@ def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterance
         wav = synthesis.batch_wavegen(model, c=c, g=g, hparams=hparams)          # (B, T) float32, post-chain applied
         return torch.from_numpy(np.clip(wav, -1.0, 1.0))                         # evaluate.py:238
 
-    wavs = None
-    if packed is None:                                    # (nothing to pack while every utterance can have a row of its own)
-        import torch.distributed as dist
-        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-        packed = synth_group is None and getattr(hparams, "batch_size", None) is None and not model.has_speaker_embedding() \
-            and next(model.parameters()).is_cuda and len(mels) > sharding.THROUGHPUT_GROUP * world
+    _, rank, world, lengths, mine = sharding._local_share(mels, hparams.hop_size, group)
+    has_spk = bool(model is not None and model.has_speaker_embedding())      # (model None: the caller's synth_group does the synthesis)
+    spk = [u.speaker_id for u in utts] if has_spk and all(u.speaker_id is not None for u in utts) else None
+    if packed is None:
+        # automatic only where it changes nothing the caller set: nothing fixes the grouping, the model draws its noise in the kernel
+        # anyway (rng = "philox"; the class default "replay" reproduces the reference's CPU stream for a seed -- packed slots cannot) and
+        # leaves the kernel choice to the engine, the job is larger than one launch per GPU, and the packed path covers the model
+        # (decided from the configuration alone: identical on every rank)
+        packed = (model is not None and synth_group is None and getattr(hparams, "batch_size", None) is None
+                  and getattr(model, "rng", "replay") == "philox" and int(getattr(model, "kernel", 0)) in (0, 2)
+                  and (not has_spk or spk is not None)
+                  and len(mels) > sharding.packed_group_size(model) * world
+                  and sharding.packed_unsupported_reason(model) is None)
+    local = None
     if packed:
         try:
-            wavs = _synthesize_packed(model, mels, hparams, group)
-        except (NotImplementedError, TimeoutError) as e:          # not a ring configuration / the ring does not fit: padded groups
-            print(f"[wnv] packed slots not used ({str(e)[:120]}); falling back to padded groups", flush=True)
-            wavs = None
-            packed = False
-    if not packed:
-        wavs = sharding.synthesize_sharded(mels, synth_group or default_group, hop_size=hparams.hop_size,
-                                           cin_pad=hparams.cin_pad, group_size=getattr(hparams, "batch_size", None), group=group)
+            local = _packed_local(model, mels, hparams, mine, spk)
+        except (NotImplementedError, TimeoutError, RuntimeError) as e:   # not a ring configuration / the ring does not fit / out of
+            # memory (torch.cuda.OutOfMemoryError is a RuntimeError): THIS rank runs its share as padded groups -- neither path holds a
+            # collective, the one gather below is reached by every rank whichever path it took
+            print(f"[wnv] rank {rank}: packed slots not used ({type(e).__name__}: {str(e)[:160]}); falling back to padded groups", flush=True)
+            local = None
+            if torch.cuda.is_available():
+                torch.cuda.empty_cache()
+    if local is None:
+        local = sharding.synthesize_local_padded(mels, synth_group or default_group, mine, lengths, cin_pad=hparams.cin_pad,
+                                                 group_size=getattr(hparams, "batch_size", None))
+    wavs = sharding.gather_results(local, len(mels), group=group, gather_to=0)
     if wavs is None:
         return []
     os.makedirs(dst_dir, exist_ok=True)

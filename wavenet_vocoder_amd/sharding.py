@@ -19,7 +19,8 @@ from typing import Callable, List, Optional, Sequence
 import torch
 
 __all__ = ["lpt_assign", "pack_groups", "pad_group", "broadcast_weights", "synthesize_sharded", "auto_group_size",
-           "padding_loss", "THROUGHPUT_GROUP", "plan_slots", "synthesize_packed"]
+           "padding_loss", "THROUGHPUT_GROUP", "plan_slots", "synthesize_packed", "synthesize_local_padded", "gather_results",
+           "packed_group_size", "packed_unsupported_reason", "upsample_each"]
 
 # Utterances per launch at which the ring kernel's aggregate rate stops growing.  Round 4 (profiles/r04_final_numbers.txt; kSamples/s
 # per GPU at B = 8 / 16 / 32 / 40 / 48 / 56 / 64): 504 / 1000 / 2014 / 2257 / 2712 / 2388 / 2703 -- up to 32 utterances every utterance advances at
@@ -98,23 +99,18 @@ def broadcast_weights(model: torch.nn.Module, src: int = 0, group=None) -> None:
             m.invalidate_engine()
 
 
-def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torch.Tensor, List[int]], torch.Tensor],
-                       *, hop_size: int, cin_pad: int, group_size: Optional[int] = None, group=None,
-                       gather_to: Optional[int] = 0, stats: Optional[dict] = None) -> Optional[List[torch.Tensor]]:
-    """Distribute ``mels`` (list of (cin, frames) tensors, identical on every rank) over the ranks.
-
-    ``synth_group(c, idx)`` receives the padded batch ``c`` (B, cin, frames + 2*cin_pad) and the global utterance
-    indices, and returns the waveforms (B, T) -- on the GPU box that is
-    ``model.incremental_forward(c=c.cuda(), T=frames*hop)[:, 0]``.  Returns the list of trimmed waveforms in the
-    original order on rank ``gather_to`` (on every rank if ``gather_to`` is None), None elsewhere.
-    ``group_size=None`` (default): from the measured throughput curve, ``auto_group_size`` -- up to 48 utterances per launch; a
-    number (``hparams.batch_size`` of the caller) wins.  ``stats``: filled with this rank's groups, true / padded samples."""
+def _local_share(mels, hop_size, group=None):
     import torch.distributed as dist
     distributed = dist.is_available() and dist.is_initialized()
     rank = dist.get_rank(group) if distributed else 0
     world = dist.get_world_size(group) if distributed else 1
     lengths = [int(m.shape[-1]) * hop_size for m in mels]
-    mine = lpt_assign(lengths, world)[rank]
+    return distributed, rank, world, lengths, lpt_assign(lengths, world)[rank]
+
+
+def synthesize_local_padded(mels, synth_group, mine, lengths, *, cin_pad: int, group_size: Optional[int] = None,
+                            stats: Optional[dict] = None) -> dict:
+    """This rank's utterances ``mine`` as padded groups of neighbouring length: {utterance index: trimmed CPU waveform}.  No collective."""
     local = {}
     groups = pack_groups(mine, lengths, group_size)
     if stats is not None:
@@ -126,8 +122,15 @@ def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torc
         wav = synth_group(c, list(grp))
         for row, i in enumerate(grp):
             local[i] = wav[row, : lengths[i]].detach().to("cpu")
-    if not distributed:
-        return [local[i] for i in range(len(mels))]
+    return local
+
+
+def gather_results(local: dict, n: int, *, group=None, gather_to: Optional[int] = 0) -> Optional[List[torch.Tensor]]:
+    """The ONE collective of a job: every rank's {utterance index: waveform} to rank ``gather_to`` (every rank if None), in job order."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [local[i] for i in range(n)]
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
     if gather_to is None:
         parts = [None] * world
         dist.all_gather_object(parts, local, group=group)
@@ -139,7 +142,23 @@ def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torc
     merged = {}
     for part in parts:
         merged.update(part)
-    return [merged[i] for i in range(len(mels))]
+    return [merged[i] for i in range(n)]
+
+
+def synthesize_sharded(mels: Sequence[torch.Tensor], synth_group: Callable[[torch.Tensor, List[int]], torch.Tensor],
+                       *, hop_size: int, cin_pad: int, group_size: Optional[int] = None, group=None,
+                       gather_to: Optional[int] = 0, stats: Optional[dict] = None) -> Optional[List[torch.Tensor]]:
+    """Distribute ``mels`` (list of (cin, frames) tensors, identical on every rank) over the ranks.
+
+    ``synth_group(c, idx)`` receives the padded batch ``c`` (B, cin, frames + 2*cin_pad) and the global utterance
+    indices, and returns the waveforms (B, T) -- on the GPU box that is
+    ``model.incremental_forward(c=c.cuda(), T=frames*hop)[:, 0]``.  Returns the list of trimmed waveforms in the
+    original order on rank ``gather_to`` (on every rank if ``gather_to`` is None), None elsewhere.
+    ``group_size=None`` (default): from the measured throughput curve, ``auto_group_size`` -- up to 48 utterances per launch; a
+    number (``hparams.batch_size`` of the caller) wins.  ``stats``: filled with this rank's groups, true / padded samples."""
+    _, _, _, lengths, mine = _local_share(mels, hop_size, group)
+    local = synthesize_local_padded(mels, synth_group, mine, lengths, cin_pad=cin_pad, group_size=group_size, stats=stats)
+    return gather_results(local, len(mels), group=group, gather_to=gather_to)
 
 
 # ---- packed slots: continuous batching ---------------------------------------------------------------------------------------------
@@ -156,40 +175,107 @@ def plan_slots(lengths: Sequence[int], n_slots: int) -> List[List[int]]:
     return [b for b in lpt_assign(lengths, n_slots) if b]
 
 
+def packed_group_size(model) -> int:
+    """Slots per launch for THIS model: where its throughput curve stops growing (profiles/r04_final_numbers.txt).  128 skip channels
+    (egs/mol, egs/gaussian) and the 256-way one-hot models gain up to 48 utterances per GPU; with 512 skip channels (BASELINE
+    configs[4]) a stage is busy 3.8 us per utterance and the curve is flat from 32 on (1.37 MSamples/s; below real time per utterance at 64)."""
+    k = int(getattr(model, "skip_out_channels", 0) or 0)
+    if k <= 0:
+        try:
+            k = int(model.conv_layers[0].conv1x1_skip.out_channels)
+        except Exception:
+            k = 128
+    return 32 if k > 256 else THROUGHPUT_GROUP
+
+
+def packed_unsupported_reason(model) -> Optional[str]:
+    """Why ``synthesize_packed`` would refuse this model -- decided WITHOUT a launch, identically on every rank (the ranks of a job must
+    agree on packed versus padded before anybody enters a collective); None when it is covered."""
+    p = next(model.parameters(), None)
+    if p is None or not p.is_cuda:
+        return "the model is not on a GPU"
+    if int(getattr(model, "gin_channels", -1) or -1) > 0 and getattr(model, "embed_speakers", None) is None:
+        return "global conditioning without a speaker embedding (external g vectors per utterance are not packed)"
+    if getattr(model, "upsample_net", None) is None and int(getattr(model, "cin_channels", -1) or -1) > 0:
+        return "local conditioning without an upsampling network"
+    try:
+        eng = model._get_engine()
+        why = eng.kernel_coverage(2)
+        if why != "supported":
+            return "the pipelined ring kernel does not cover the model: " + why
+    except Exception as e:       # (no engine on this device: the launch would say so too)
+        return str(e)[:160]
+    return None
+
+
 def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin_pad: int, slots: Optional[int] = None,
                       seed: Optional[int] = None, indices: Optional[Sequence[int]] = None, stats: Optional[dict] = None,
-                      upsample_batch: int = 32, max_slot_steps: int = 1 << 20) -> List[torch.Tensor]:
+                      max_slot_steps: int = 1 << 20, max_launch_bytes: int = 6 << 30, params_out: Optional[list] = None,
+                      speaker_ids: Optional[Sequence[int]] = None,
+                      sink: Optional[Callable[[int, torch.Tensor], None]] = None) -> List[Optional[torch.Tensor]]:
     """The waveforms (network outputs ``(C, T_i)`` on the model's device, one per mel of ``mels[i] for i in indices``) of a job run as
-    PACKED SLOTS on this process's GPU.  ``model``: an ``EngineHost`` WaveNet on the device, without global conditioning, that the ring
-    kernel covers (otherwise NotImplementedError: the caller falls back to padded groups).  ``slots``: rows of a launch (default
-    THROUGHPUT_GROUP); ``seed``: of the in-kernel noise streams (default: drawn from torch's generator, as ``rng = "philox"`` does).
-    A job longer than ``slots x max_slot_steps`` samples runs as several launches (the slots' conditioning is resident for a launch:
-    320 bytes per sample -- 16 GB at the default bound of 2**20 steps x 48 slots); an utterance's noise stream does not depend on that."""
-    if getattr(model, "embed_speakers", None) is not None or int(getattr(model, "gin_channels", -1) or -1) > 0:
-        raise NotImplementedError("packed slots: models with global conditioning keep one bias table per row")
+    PACKED SLOTS on this process's GPU.  ``model``: an ``EngineHost`` WaveNet on the device that the ring kernel covers (otherwise
+    NotImplementedError: the caller falls back to padded groups).  ``slots``: rows of a launch (default ``packed_group_size(model)``);
+    ``seed``: of the in-kernel noise streams (default: drawn from torch's generator, as ``rng = "philox"`` does).
+    ``speaker_ids`` (round 5; one per mel of ``mels``, for models with a speaker embedding -- BASELINE configs[4],
+    wavenet.py:262-269): the hoisted bias table gets one row per SPEAKER of the embedding and every slot-step names its row (``seg_gid``).
+    ``params_out``: a list that receives, per utterance, the head outputs ``(O, T_i)`` the sampler was handed at every step (parity tests).
+    ``sink(i, y)``: called with utterance ``i`` (index into ``mels``) and its ``(C, T_i)`` output as soon as its launch is done, INSTEAD
+    of keeping the output (the returned list then holds None): a long job keeps only one launch's buffers on the device.
+    One launch is bounded by ``max_slot_steps`` steps per slot AND by ``max_launch_bytes`` of resident per-step buffers -- the slots'
+    conditioning (``cin`` floats per step), the output (``C`` floats per step: 1 KB for a 256-way one-hot model) and the maps; a longer
+    job runs as several launches.  An utterance's waveform does not depend on any of this: its conditioning is upsampled on its own
+    (what ``incremental_forward`` gives for the utterance alone, its edges replicate-padded as evaluate.py:163-164 does for a batch of
+    one), its noise stream is (utterance id, step within the utterance)."""
+    why = packed_unsupported_reason(model)
+    if why is not None:
+        raise NotImplementedError("packed slots: " + why)
+    has_spk = getattr(model, "embed_speakers", None) is not None
+    if has_spk:
+        if speaker_ids is None or len(speaker_ids) != len(mels):
+            raise ValueError("packed slots: a model with a speaker embedding needs speaker_ids, one per mel")
+        n_spk = int(model.embed_speakers.weight.shape[0])
+        bad = [int(g) for g in speaker_ids if not 0 <= int(g) < n_spk]
+        if bad:
+            raise IndexError(f"speaker id {bad[0]} outside the embedding table of {n_spk} speakers")
+    elif speaker_ids is not None:
+        raise ValueError("speaker_ids given but the model has no speaker embedding")
     idx = list(range(len(mels))) if indices is None else list(indices)
     if not idx:
         return []
-    n_slots = THROUGHPUT_GROUP if slots is None else int(slots)
+    n_slots = packed_group_size(model) if slots is None else int(slots)
     if seed is None:
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    eng = model._get_engine()
+    cin = int(mels[idx[0]].shape[0])
+    c_out = 1 if eng.cfg.scalar_input else int(eng.cfg.out_channels)
+    step_bytes = 4 * (cin + c_out + 2 + (1 if has_spk else 0) + (int(eng.cfg.out_channels) if params_out is not None else 0))
+    steps_cap = max(hop_size, min(int(max_slot_steps), int(max_launch_bytes) // (n_slots * step_bytes)))
     lengths_all = [int(mels[i].shape[-1]) * hop_size for i in idx]
-    # launches: longest first, a launch closes when its slots would have to run more than max_slot_steps steps on average
+    # launches: longest first, a launch closes when its slots would have to run more than steps_cap steps on average
     order = sorted(range(len(idx)), key=lambda k: (-lengths_all[k], k))
     launches, cur, tot = [], [], 0
     for k in order:
-        if cur and (tot + lengths_all[k]) > n_slots * max_slot_steps:
+        if cur and (tot + lengths_all[k]) > n_slots * steps_cap:
             launches.append(cur)
             cur, tot = [], 0
         cur.append(k)
         tot += lengths_all[k]
     launches.append(cur)
     res: List[Optional[torch.Tensor]] = [None] * len(idx)
-    agg = dict(slots=0, slot_steps=0, true_samples=0, padded_samples=0, utterances_per_slot=[], launches=[])
+    par: Optional[list] = None if params_out is None else [None] * len(idx)
+    agg = dict(slots=0, slot_steps=0, true_samples=0, padded_samples=0, utterances_per_slot=[], launches=[], step_bytes=step_bytes)
     for members in launches:
-        out_m, st_m = _packed_launch(model, mels, [idx[k] for k in members], hop_size, cin_pad, n_slots, seed, upsample_batch)
-        for k, y in zip(members, out_m):
-            res[k] = y
+        out_m, st_m, par_m = _packed_launch(model, mels, [idx[k] for k in members], hop_size, cin_pad, n_slots, seed,
+                                            want_params=params_out is not None, speaker_ids=speaker_ids)
+        for j, (k, y) in enumerate(zip(members, out_m)):
+            if sink is not None:
+                sink(idx[k], y)
+            else:
+                res[k] = y.clone()                                                   # (a copy: the launch's output buffer goes away)
+            if par is not None:
+                par[k] = par_m[j].clone()
+        del out_m, par_m
         agg["slots"] = max(agg["slots"], st_m["slots"])
         agg["slot_steps"] += st_m["slot_steps"]
         agg["true_samples"] += st_m["true_samples"]
@@ -199,11 +285,30 @@ def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin
     if stats is not None:
         agg["padding_loss"] = 1.0 - agg["true_samples"] / float(max(agg["padded_samples"], 1))
         stats.update(agg)
+    if params_out is not None:
+        params_out[:] = par
     return res
 
 
-def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, upsample_batch):
-    """One launch of packed slots over the utterances ``ids`` (indices into ``mels``, which are also their ids in the job)."""
+def upsample_each(eng, mels: Sequence[torch.Tensor], ids: Sequence[int], cin_pad: int, hop_size: int):
+    """Yields (position in ``ids``, (T_i, cin) conditioning on the device) -- every utterance upsampled ON ITS OWN: its edges
+    replicate-padded (evaluate.py:163-164 for a batch of one), zeros nowhere.  Utterances of equal length share a launch (their padded
+    batch has no zero padding, so rows do not see each other)."""
+    by_frames = {}
+    for k, i in enumerate(ids):
+        by_frames.setdefault(int(mels[i].shape[-1]), []).append(k)
+    for f, ks in by_frames.items():
+        for a in range(0, len(ks), 32):
+            grp = ks[a:a + 32]
+            c = pad_group([mels[ids[k]] for k in grp], cin_pad).to(eng.device)
+            cu = eng.upsample(c, T_expected=f * hop_size)                            # (len(grp), T, cin) time-major
+            for row, k in enumerate(grp):
+                yield k, cu[row]
+
+
+def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, want_params=False, speaker_ids=None):
+    """One launch of packed slots over the utterances ``ids`` (indices into ``mels``, which are also their ids in the job).
+    Returns views into the launch's output buffers (the caller copies or consumes them before the next launch)."""
     eng = model._get_engine()
     dev = eng.device
     cin = int(mels[ids[0]].shape[0])
@@ -212,8 +317,11 @@ def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, upsample_
     bins = plan_slots(lengths, n_slots)                                               # positions into ids
     n, T = len(bins), max(sum(lengths[k] for k in b) for b in bins)
     c_slot = torch.zeros(n, T, cin, device=dev, dtype=torch.float32)
+    # per-slot-step maps (int32 each: 8-12 bytes per slot-step next to 4 cin of conditioning; the kernel's roles look a step up without
+    # carrying a cursor per slot in registers they do not have)
     seg_start = torch.zeros(n, T, dtype=torch.int32)
     seg_uid = torch.zeros(n, T, dtype=torch.int32)
+    seg_gid = torch.zeros(n, T, dtype=torch.int32) if speaker_ids is not None else None
     where = {}
     for s, b in enumerate(bins):
         off = 0
@@ -221,21 +329,22 @@ def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, upsample_
             where[k] = (s, off)
             seg_start[s, off:] = off            # (the tail of a slot that ends early keeps its last utterance running: ignored)
             seg_uid[s, off:] = ids[k]
+            if seg_gid is not None:
+                seg_gid[s, off:] = int(speaker_ids[ids[k]])
             off += lengths[k]
-    # the conditioning of every utterance, upsampled in padded groups of neighbouring length (as the reference's padded batches,
-    # evaluate.py:55-57,163-164), copied to its place in its slot
-    order = sorted(range(len(ids)), key=lambda k: -frames[k])
-    for a in range(0, len(order), upsample_batch):
-        grp = order[a:a + upsample_batch]
-        c = pad_group([mels[ids[k]] for k in grp], cin_pad).to(dev)
-        cu = eng.upsample(c, T_expected=max(lengths[k] for k in grp))               # (B, T_max, cin) time-major
-        for row, k in enumerate(grp):
-            s, off = where[k]
-            c_slot[s, off:off + lengths[k]] = cu[row, :lengths[k]]
-    out, _, _ = eng.generate(B=n, T=T, c_up=c_slot, seed=seed, seg_start=seg_start.to(dev), seg_uid=seg_uid.to(dev), kernel=0)
+    for k, cu in upsample_each(eng, mels, ids, cin_pad, hop_size):
+        s, off = where[k]
+        c_slot[s, off:off + lengths[k]] = cu
+    g_rows = None
+    if seg_gid is not None:                     # one bias row per speaker of the embedding table (tiny: n_speakers x L x G floats)
+        g_rows = torch.arange(int(model.embed_speakers.weight.shape[0]), dtype=torch.int64, device=dev)
+    out, params, _ = eng.generate(B=n, T=T, c_up=c_slot, seed=seed, seg_start=seg_start.to(dev), seg_uid=seg_uid.to(dev),
+                                  seg_gid=None if seg_gid is None else seg_gid.to(dev), g_ids=g_rows, kernel=0, want_params=want_params)
     st = dict(slots=n, slot_steps=T, true_samples=sum(lengths), padded_samples=n * T, utterances_per_slot=[len(b) for b in bins])
-    res = []
+    res, par = [], []
     for k in range(len(ids)):
         s, off = where[k]
-        res.append(out[s, :, off:off + lengths[k]].clone())                          # (a copy: the launch's output buffer goes away)
-    return res, st
+        res.append(out[s, :, off:off + lengths[k]])
+        if want_params:
+            par.append(params[s, :, off:off + lengths[k]])
+    return res, st, par
