@@ -13,6 +13,11 @@ Tape layout per (t, b), NZ floats:
   Normal, C in {2, 3}   : n ~ N(0, 1)
   Normal, C = 3k > 3    : u1[0..nr_mix), then n ~ N(0, 1)
   one-hot (categorical) : e[0..C) ~ Exp(1)            (torch.multinomial draws argmax(p / e))
+
+Threads: the fast replay path advances the generator through ``get_state()`` / a native draw / ``set_state()`` under a module lock, not
+under the generator's own mutex (torch's ``uniform_`` holds that for the whole draw).  Calls of this module from several threads are
+serialised; a generator that another thread draws from THROUGH TORCH at the same time must not be shared with it (its draws could be
+duplicated or lost) -- give the replay its own ``torch.Generator``.
 """
 from __future__ import annotations
 
@@ -55,6 +60,7 @@ def _bulk_matches_per_step(kind: str) -> bool:
 
 import threading
 
+_NATIVE_DRAW_LOCK = threading.Lock()   # serialises get_state -> native draw -> set_state of the replay path (the generator itself is the caller's)
 _U_SCRATCH = threading.local()     # per thread: uniform_ and the ctypes call release the GIL, two callers must not share the staging buffer
 _U_CHUNK = 1 << 21                 # values per staging pass: 16 MB of float64, whatever the size of the request
 
@@ -105,9 +111,15 @@ def exponential_draws(out: torch.Tensor, generator: Optional[torch.Generator] = 
         if native:
             # the same draws from the library's own Mersenne Twister (wnv_mt19937_uniform53: ~1.5 ns per value against the 5-10 ns torch's
             # element-by-element walk costs inside a busy process), the generator advanced through its state blob
-            st = gen.get_state()
-            if _lib.lib().wnv_mt19937_uniform53(st.data_ptr(), st.numel(), u.data_ptr(), m) == 0:
-                gen.set_state(st)
+            # (torch's own uniform_ holds the generator's mutex for the whole draw; get_state / draw / set_state do not -- this module's
+            #  lock keeps two threads of THIS path from reading the same state twice, and a generator that another thread draws from
+            #  through torch itself at the same time must not be handed to this function: module docstring)
+            with _NATIVE_DRAW_LOCK:
+                st = gen.get_state()
+                drawn = _lib.lib().wnv_mt19937_uniform53(st.data_ptr(), st.numel(), u.data_ptr(), m) == 0
+                if drawn:
+                    gen.set_state(st)
+            if drawn:
                 uu = u[:m]
             else:                                                 # (a state blob the library does not recognise: nothing was drawn, torch draws)
                 uu = u[:m].uniform_(0.0, 1.0, **kw)
