@@ -18,6 +18,11 @@
 //   7  as 0 with s_setprio 3 on the chain waves
 //   8  as 0, the four reads as eight ds_read_b64 (first FMA after 8 bytes)
 //   9  as 5 + the zin addends read with the first x read and added into the accumulators' init (no add behind the reduce)
+// DEPTH of the dependent tail (round 5: variants 5 / 9 said that instruction ORDER buys nothing and every dependent level ~7 ns):
+//  10  row-pair accumulators: a packed FMA holds two ROWS against a broadcast x (op_sel), 4 accumulators x 16 k -- the x + y add level is gone
+//  11  10 + the last DPP level as ONE v_add_f32_dpp in every lane (the compiler splits it into v_mov_dpp + v_add when only the writer lanes gate)
+//  12  11 + zin in the accumulators' init
+//  13  12 + gate as (2 rcp(1 + e1) - 1) rcp(1 + e2) with the exp2 scales folded into the weights: exp -> add -> rcp -> fma -> mul
 // hipcc --offload-arch=gfx950 -O3 -o scripts/ubench_phase.bin scripts/ubench_phase.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -79,6 +84,44 @@ __global__ void __launch_bounds__(512) k(int reps, u64* mail, u64* result, float
                 const float n0 = dpp_fold<0x4E>(q4[0], q4[2]), n1 = dpp_fold<0x4E>(q4[1], q4[3]);      // lane j <-> j ^ 2
                 const float a = dpp_fold<0xB1>(n0, n0), g = dpp_fold<0xB1>(n1, n1);                      // lane j <-> j ^ 1
                 u = gate(a + xq[33], g + xq[34]);
+            } else if constexpr (V >= 10) {
+                float x[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(xs + 4 * q);
+                    x[4 * q] = v.x; x[4 * q + 1] = v.y; x[4 * q + 2] = v.z; x[4 * q + 3] = v.w;
+                }
+                const float2 z = *reinterpret_cast<const float2*>(lds + 1024 + 2 * (tid >> 1));
+                // row pairs: acc[p] = rows (2p, 2p + 1) of this lane's eight; w[p][c] and w[p + 4][c] stand in for the 16 k of a pair
+                f2 acc[4];
+#pragma unroll
+                for (int pq = 0; pq < 4; ++pq) acc[pq] = f2{accum * 1e-30f, 0.f};
+                if constexpr (V >= 12) { acc[0].x += z.x; acc[0].y += z.y; }
+#pragma unroll
+                for (int c = 0; c < 16; ++c)
+#pragma unroll
+                    for (int pq = 0; pq < 4; ++pq) acc[pq] = __builtin_elementwise_fma(w[pq + 4 * (c >> 3)][c & 7], f2{x[c], x[c]}, acc[pq]);
+                // reduce-scatter over the 8 K lanes: slots 0..7 = acc[0].x, acc[0].y, acc[1].x, ... ; level 1 sends slots 4-7, level 2 slots 2-3
+                const float n0 = dpp_fold<0x141>(acc[0].x, acc[2].x), n1 = dpp_fold<0x141>(acc[0].y, acc[2].y);
+                const float n2 = dpp_fold<0x141>(acc[1].x, acc[3].x), n3 = dpp_fold<0x141>(acc[1].y, acc[3].y);
+                const float m0 = dpp_fold<0x4E>(n0, n2), m1 = dpp_fold<0x4E>(n1, n3);
+                float a, g;
+                if constexpr (V == 10) {
+                    a = dpp_fold<0xB1>(m0, m0) + z.x; g = dpp_fold<0xB1>(m1, m1) + z.y;
+                } else {
+                    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                                 "v_add_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                                 : "=&v"(a), "=&v"(g) : "v"(m0), "v"(m1));
+                    if constexpr (V == 11) { a += z.x; g += z.y; }
+                }
+                if constexpr (V == 13) {
+                    // (the weights carry -2 log2 e / -log2 e: a, g ARE the exp2 arguments) tanh(a') sigmoid(g') = (2 r1 - 1) r2
+                    const float e1 = __builtin_amdgcn_exp2f(a), e2 = __builtin_amdgcn_exp2f(g);
+                    const float r1 = __builtin_amdgcn_rcpf(1.0f + e1), r2 = __builtin_amdgcn_rcpf(1.0f + e2);
+                    u = __builtin_fmaf(2.0f, r1, -1.0f) * r2;
+                } else {
+                    u = gate(a, g);
+                }
             } else {
                 float x[16];
                 if constexpr (V == 1 || V == 4) {
@@ -206,13 +249,16 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&result, 64)); CK(hipMalloc(&sink, 4096 * 4));
     const char* names[] = {"0 the phase as compiled (baseline)", "1 no LDS read (x in registers)", "2 no reduce / gate", "3 barrier + store only",
                            "4 FMAs only (no read, no tail)", "5 hand-scheduled tail (asm)", "6 4-lane K split, two quad_perm levels", "7 baseline, s_setprio 3",
-                           "8 reads as eight ds_read_b64", "9 hand-scheduled tail + zin in the accumulators"};
-    double ns[10];
+                           "8 reads as eight ds_read_b64", "9 hand-scheduled tail + zin in the accumulators", "10 row-pair accumulators (no x + y level)",
+                           "11 = 10 + last DPP level as one instruction", "12 = 11 + zin in the accumulators", "13 = 12 + gate as (2 r1 - 1) r2, scales folded"};
+    double ns[14];
     ns[0] = run<0>(reps, mail, result, sink); ns[1] = run<1>(reps, mail, result, sink); ns[2] = run<2>(reps, mail, result, sink);
     ns[3] = run<3>(reps, mail, result, sink); ns[4] = run<4>(reps, mail, result, sink); ns[5] = run<5>(reps, mail, result, sink);
     ns[6] = run<6>(reps, mail, result, sink); ns[7] = run<7>(reps, mail, result, sink); ns[8] = run<8>(reps, mail, result, sink);
     ns[9] = run<9>(reps, mail, result, sink);
-    for (int v = 0; v < 10; ++v) printf("variant %-52s %7.1f ns per phase (+ barrier)\n", names[v], ns[v]);
+    ns[10] = run<10>(reps, mail, result, sink); ns[11] = run<11>(reps, mail, result, sink); ns[12] = run<12>(reps, mail, result, sink);
+    ns[13] = run<13>(reps, mail, result, sink);
+    for (int v = 0; v < 14; ++v) printf("variant %-52s %7.1f ns per phase (+ barrier)\n", names[v], ns[v]);
     printf("derived: barrier+store floor %.1f | FMA phase alone %.1f (256 x 128 MACs at 128 FMA/clk = 106.7) | LDS read on the chain %.1f | reduce+gate tail %.1f\n",
            ns[3], ns[4] - ns[3], ns[0] - ns[1], ns[0] - ns[2]);
     return 0;

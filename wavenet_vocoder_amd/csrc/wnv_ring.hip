@@ -648,18 +648,18 @@ constexpr int KL_MAX = 16;         // further K rows per wave held in LDS
 constexpr int TB = 8;              // utterances per pass (one polling wave each; their latencies overlap)
 struct TapLds {
     float* xin;      // [2][TB][8 * kper] mat-vec inputs (two buffers: the next pass's gather lands in the other one): tap rows then conditioning row, zero padded
-    int* flags;
+    int* flags;      // [32]: 0 = give-up flag; 8 + buf * TB + u = packed slots: bias row (seg_gid) of utterance u of the pass whose inputs are in buffer buf
     float4* wl;      // [8 waves][klds_rows][64 lanes] LDS-resident rows
 };
 __device__ __forceinline__ TapLds carve_tap(float* smem, const RingParams& p) {
     TapLds s;
     s.xin = smem;
     s.flags = reinterpret_cast<int*>(smem + (size_t)2 * TB * RW * p.kper);
-    s.wl = reinterpret_cast<float4*>(s.flags + 16);
+    s.wl = reinterpret_cast<float4*>(s.flags + 32);
     return s;
 }
 __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
-    return (size_t)2 * TB * RW * kper + 16 + (size_t)RW * klds_rows * 64 * 4;
+    return (size_t)2 * TB * RW * kper + 32 + (size_t)RW * klds_rows * 64 * 4;
 }
 
 // EXPERIMENT BUILDS ONLY (-DWNV_EXP_NOPRE=1|2; results are WRONG on purpose, timing only): 1 = stages and head do not wait for the tap
@@ -750,12 +750,18 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
     // registers -- next to 128 weight registers there are none to spare: the register-staged form spilled 27) into the OTHER input
     // buffer; the issuing wave waits for its own DMAs (vmcnt) in [B] of the pass that uses them, in front of the barrier.
     u64 hx0 = 0, hx1 = 0;
-    auto gather_issue = [&](int t_, int b, float* xu) {
+    auto gather_issue = [&](int t_, int b, float* xu, int buf) {
         const int tp_ = t_ + 1, tf_ = early ? t_ - 1 : t_, kf = fresh_tap(tf_);
         const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
         const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
         // packed slots: the utterance that occupies the slot at step tp_ began at step st_; what lies before reads as zeros (conv.py:34-36)
         const int st_ = PACKED ? p.seg_start[(size_t)b * p.T + tp_] : INT_MIN;
+        // ... and its bias row (speaker-conditioned models): fetched HERE, a pass ahead and next to seg_start, and parked in LDS -- read in
+        // [D] it would put a miss of the (B, T) map in front of the bias load in front of the publish (round 5: the first form did)
+        if (PACKED && p.seg_gid) {
+            const int gid_ = p.seg_gid[(size_t)b * p.T + tp_];
+            if (lane == 0) s.flags[8 + buf * TB + wave] = gid_;
+        }
 #pragma unroll
         for (int q = 0; q < GQ; ++q) {
             const int i = 64 * q + lane;
@@ -779,7 +785,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
     };
 
     int t = -1, b0 = bfirst, cur = 0;                              // pass (t, b0) consumes h_l[tf], produces pre_l[t + 1]; its inputs: buffer cur
-    if (wave < min(p.tb, p.B - b0)) gather_issue(t, b0 + wave, s.xin + (size_t)wave * kx);
+    if (wave < min(p.tb, p.B - b0)) gather_issue(t, b0 + wave, s.xin + (size_t)wave * kx, 0);
     for (;;) {
         const int tp = t + 1;
         const int nb = min(p.tb, p.B - b0);
@@ -827,7 +833,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         int tn = t, bn = b0 + pstride;
         if (bn >= p.B) { bn = bfirst; tn = t + 1; }
         const bool more = tn + 1 < p.T;
-        if (more && wave < min(p.tb, p.B - bn)) gather_issue(tn, bn + wave, s.xin + ((size_t)(cur ^ 1) * TB + wave) * kx);
+        if (more && wave < min(p.tb, p.B - bn)) gather_issue(tn, bn + wave, s.xin + ((size_t)(cur ^ 1) * TB + wave) * kx, cur ^ 1);
         // ---- [D] mat-vec for all utterances of the pass, four at a time (accumulators + weights must fit the register file):
         //      VGPR rows, then LDS rows, then whatever streams; no barrier inside (the inputs are read-only here, the next
         //      pass's land in the other buffer, and its [B] barrier is behind every wave's last read of this one) -----------
@@ -840,7 +846,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
             float zb0 = 0.f, zb1 = 0.f;                                      // the utterance's effective conv bias: requested ahead of the FMAs
             if (pub) {
                 // (packed slots: the bias row of the utterance that occupies the slot at step tp -- its speaker)
-                const float* zrow = zbase + (size_t)((PACKED && p.seg_gid) ? p.seg_gid[(size_t)rb * p.T + tp] : rb) * p.zbias_bstride;
+                const float* zrow = zbase + (size_t)((PACKED && p.seg_gid) ? s.flags[8 + cur * TB + u0 + pu] : rb) * p.zbias_bstride;
                 if (z0) zb0 = zrow[0];
                 if (z1) zb1 = zrow[1];
             }
