@@ -109,6 +109,12 @@ struct RingParams {
 
 using u64 = unsigned long long;
 
+// A wave-uniform int from memory the kernel never writes (the packed-slot maps): through the CONSTANT address space, so that the load is
+// a scalar one (s_load_dword: no vector register, its own counter -- a wait for it does not wait for the acknowledgement of the chain
+// stores in flight, as a wait for a vector load does on gfx9).  The caller makes the address uniform (readfirstlane where it is not provably so).
+typedef const int __attribute__((address_space(4))) wnv_cint;
+__device__ __forceinline__ int uniform_ld(const int* p) { return *reinterpret_cast<wnv_cint*>(reinterpret_cast<size_t>(p)); }
+
 __device__ __forceinline__ u64 ld_granule(const u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // global_load_dwordx2 ... sc1 (L1 bypass)
 }
@@ -520,6 +526,25 @@ __device__ __forceinline__ float fast_gate(float a, float g) {
     return copysignf((1.0f - e) * r, a);
 }
 
+// ROUND 5 (WNV_PHASE2): the gate on PRE-SCALED pre-activations.  The host folds the exp2 scales into everything that sums into z
+// (gate_scale(): tanh rows x -2 log2 e, sigmoid rows x -log2 e -- M, N, c, the tap matrix, layer 0's affine terms; the tap workgroups
+// scale the bias row they add), so a' and g' ARE the exp2 arguments, and tanh(a) sigmoid(g) = (2 r1 - 1) r2 with r1 = 1 / (1 + 2^a'),
+// r2 = 1 / (1 + 2^g'): exp -> add -> rcp -> fma -> mul, five dependent levels instead of eight (mul, exp, add, mul, rcp, mul, select;
+// scripts/ubench_phase.hip variant 13: -35 ns per chain phase).  2^a' = inf gives r1 = 0 -> tanh = -1, 2^g' = inf gives 0: no NaN.
+#ifndef WNV_PHASE2
+#define WNV_PHASE2 1
+#endif
+constexpr float GATE_SCALE_TANH = -2.8853900817779268f, GATE_SCALE_SIGM = -1.4426950408889634f;
+__device__ __forceinline__ float ring_gate(float a, float g) {
+#if WNV_PHASE2
+    const float r1 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a));
+    const float r2 = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(g));
+    return fmaf(2.0f, r1, -1.0f) * r2;
+#else
+    return fast_gate(a, g);
+#endif
+}
+
 __device__ __forceinline__ void lds_read32(const float* p, float (&x)[32]) {
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
@@ -720,6 +745,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
     const float2 cvl = *reinterpret_cast<const float2*>(p.cvec + (size_t)l * GC + po);
     const float* zbase = p.zbias + (size_t)l * p.zb_ld + (size_t)zhalf * p.gh + zch;
     const bool z0 = zch < p.gh, z1 = zch + 1 < p.gh;
+    const float zsc = WNV_PHASE2 ? (zhalf ? GATE_SCALE_SIGM : GATE_SCALE_TANH) : 1.0f;
     for (int i = tid; i < 2 * TB * kx; i += RT) s.xin[i] = 0.f;
     if (tid == 0) s.flags[0] = 0;
     __syncthreads();
@@ -755,13 +781,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
         const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
         // packed slots: the utterance that occupies the slot at step tp_ began at step st_; what lies before reads as zeros (conv.py:34-36)
-        const int st_ = PACKED ? p.seg_start[(size_t)b * p.T + tp_] : INT_MIN;
-        // ... and its bias row (speaker-conditioned models): fetched HERE, a pass ahead and next to seg_start, and parked in LDS -- read in
-        // [D] it would put a miss of the (B, T) map in front of the bias load in front of the publish (round 5: the first form did)
-        if (PACKED && p.seg_gid) {
-            const int gid_ = p.seg_gid[(size_t)b * p.T + tp_];
-            if (lane == 0) s.flags[8 + buf * TB + wave] = gid_;
-        }
+        const int st_ = PACKED ? uniform_ld(p.seg_start + (size_t)__builtin_amdgcn_readfirstlane(b) * p.T + tp_) : INT_MIN;   // (scalar: no register held across the DMA issue)
 #pragma unroll
         for (int q = 0; q < GQ; ++q) {
             const int i = 64 * q + lane;
@@ -819,7 +839,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
                     *reinterpret_cast<float2*>(hist + (size_t)(tf % rows) * RC + 2 * lane) = make_float2(hv[0], hv[1]);
                     if (kfresh >= 0) {
                         // (packed slots: the row is the previous utterance's when the one at step tp began later than tf)
-                        const bool mine = !PACKED || tf >= p.seg_start[(size_t)b * p.T + tp];
+                        const bool mine = !PACKED || tf >= uniform_ld(p.seg_start + (size_t)__builtin_amdgcn_readfirstlane(b) * p.T + tp);
                         *reinterpret_cast<float2*>(xu + kfresh * RC + 2 * lane) = mine ? make_float2(hv[0], hv[1]) : make_float2(0.f, 0.f);
                     }
                 }
@@ -845,8 +865,9 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
             const int rb = b0 + u0 + pu;
             float zb0 = 0.f, zb1 = 0.f;                                      // the utterance's effective conv bias: requested ahead of the FMAs
             if (pub) {
-                // (packed slots: the bias row of the utterance that occupies the slot at step tp -- its speaker)
-                const float* zrow = zbase + (size_t)((PACKED && p.seg_gid) ? s.flags[8 + cur * TB + u0 + pu] : rb) * p.zbias_bstride;
+                // (packed slots: the bias row of the utterance that occupies the slot at step tp -- its speaker.  Read here, ahead of the
+                //  FMAs; parked in LDS a pass ahead it cost the packed instantiations 2-4 spilled registers and 3 % -- round 5, measured)
+                const float* zrow = zbase + (size_t)((PACKED && p.seg_gid) ? p.seg_gid[(size_t)rb * p.T + tp] : rb) * p.zbias_bstride;
                 if (z0) zb0 = zrow[0];
                 if (z1) zb1 = zrow[1];
             }
@@ -912,8 +933,9 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
                     acc[g][h] = f2{dpp_fold<0x141>(acc[g][h].x, acc[g + 2][1 - h].x), dpp_fold<0x141>(acc[g][h].y, acc[g + 2][1 - h].y)};   // (the mirror partner has the other parity: its OTHER pair holds these outputs)
 #pragma unroll
             for (int h = 0; h < 2; ++h) acc[0][h] = f2{dpp_fold<0x4E>(acc[0][h].x, acc[1][h].x), dpp_fold<0x4E>(acc[0][h].y, acc[1][h].y)};
-            const float v0 = dpp_fold<0xB1>(acc[0][0].x, acc[0][1].x) + (zb0 + cvl.x);
-            const float v1 = dpp_fold<0xB1>(acc[0][0].y, acc[0][1].y) + (zb1 + cvl.y);
+            // (WNV_PHASE2: everything that sums into z carries the gate's exp2 scale -- the matrix and c_l from the host, the bias row here)
+            const float v0 = dpp_fold<0xB1>(acc[0][0].x, acc[0][1].x) + fmaf(zb0, zsc, cvl.x);
+            const float v1 = dpp_fold<0xB1>(acc[0][0].y, acc[0][1].y) + fmaf(zb1, zsc, cvl.y);
             // pre_l[tp] of utterance rb leaves as tagged granules (write-through: the stage may sit on any XCD): no drain
             if (pub) st_granule2(p.pmail + pre_rec(p, rb, l, tp) + po, p.tag_base + (unsigned)tp + 1u, v0, v1, false);
             TAP_STAMP(min(3 + u0 / 4, 4));
@@ -967,6 +989,48 @@ __device__ __forceinline__ void group_matvec8(const f2 (&w)[8][8], const float* 
     g = dpp_fold<0xB1>(m1, m1) + z.y;
 }
 
+// ---- ROUND 5: the same mat-vec with a SHALLOWER dependent tail (scripts/ubench_phase.hip, profiles/r05_ubench_phase.txt) -----------
+// The chain phase is 77 ns of barrier + store, 51 ns of LDS read, 116 ns of FMAs -- and 133 ns of reduce + gate: ~30 instructions that
+// form ONE dependent chain of 14 levels on a SIMD that holds a single wave, ~7-10 ns per level whatever the instruction order (the
+// hand-scheduled tail of variant 5 is not faster than the compiler's).  What helps is fewer LEVELS:
+//   * ROW-PAIR accumulators: a packed FMA holds the {tanh, sigmoid} rows of one channel against a broadcast x (op_sel: free) instead of
+//     two K halves of one row -- the x + y level (and its 8 adds) is gone; 4 accumulators x 16 k, still 64 v_pk_fma_f32;
+//   * the gate on pre-scaled arguments as (2 r1 - 1) r2 (ring_gate: three levels less).
+// Register slots: pair p = image slots 2p (tanh) and 2p + 1 (sigmoid) of put_row8g -- the host image is unchanged, the pairs are formed
+// as the registers are loaded.
+__device__ __forceinline__ void load_pair8g(const float* img_slot0, int gtid, f2 (&w)[4][16]) {
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) {
+        const float4* sa = reinterpret_cast<const float4*>(img_slot0 + (size_t)(2 * pq) * 4 * GT * 4);
+        const float4* sb = reinterpret_cast<const float4*>(img_slot0 + (size_t)(2 * pq + 1) * 4 * GT * 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float4 va = sa[(size_t)c * GT + gtid], vb = sb[(size_t)c * GT + gtid];
+            w[pq][4 * c] = f2{va.x, vb.x}; w[pq][4 * c + 1] = f2{va.y, vb.y}; w[pq][4 * c + 2] = f2{va.z, vb.z}; w[pq][4 * c + 3] = f2{va.w, vb.w};
+        }
+    }
+}
+// (the addends za, zb are read ahead of the x slice and added behind the reduce: as the init of the accumulators -- variant 12 -- the
+//  first FMAs wait for them, +14 ns; the last DPP level as one hand-written instruction -- variant 11 -- buys nothing)
+__device__ __forceinline__ void group_matvec8r(const f2 (&w)[4][16], const float* xslice, const float* za, const float* zb, float& a, float& g) {
+    float2 z = make_float2(*za, *zb);
+    float x[16];
+    lds_read16(xslice, x);
+    f2 acc[4];
+#pragma unroll
+    for (int pq = 0; pq < 4; ++pq) acc[pq] = f2{0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k)
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) acc[pq] = __builtin_elementwise_fma(w[pq][k], f2{x[k], x[k]}, acc[pq]);
+    asm volatile("" : "+v"(z.x), "+v"(z.y));                     // the reads were issued up there, not behind the reduce
+    const float n0 = dpp_fold<0x141>(acc[0].x, acc[2].x), n1 = dpp_fold<0x141>(acc[0].y, acc[2].y);
+    const float n2 = dpp_fold<0x141>(acc[1].x, acc[3].x), n3 = dpp_fold<0x141>(acc[1].y, acc[3].y);
+    const float m0 = dpp_fold<0x4E>(n0, n2), m1 = dpp_fold<0x4E>(n1, n3);
+    a = dpp_fold<0xB1>(m0, m0) + z.x;
+    g = dpp_fold<0xB1>(m1, m1) + z.y;
+}
+
 // One stage = one gated layer on one CU, weights resident in VGPRs.
 //
 // GATE-TO-GATE CHAIN.  The reference's layer is  z_l = W_cur,l h_l + pre_l ;  u_l = tanh . sigmoid (z_l) ;
@@ -1011,10 +1075,15 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
     // ---- resident weights (registers), pairs along K (every FMA on or near the chain is a v_pk_fma_f32):
     //      wmn = the eight rows of M_l (waves 0-3) or N_l (waves 4-7) this lane contracts, wo rows = {c0, c1} of conv1x1_out;
     //      conv1x1_skip (nobody waits for it) is read from an LDS image ----------------------------------------------
+#if WNV_PHASE2
+    f2 wmn[4][16], wo[2][8];                   // row pairs {tanh, sigmoid} of a channel against a broadcast x (group_matvec8r)
+    load_pair8g((grp == 0 ? p.w2img : p.wnimg) + ((size_t)l * 8) * 4 * GT * 4, gtid, wmn);       // N_l is all zeros at stage 0
+#else
     f2 wmn[8][8], wo[2][8];
 #pragma unroll
     for (int slot = 0; slot < 8; ++slot)       // N_l is all zeros at stage 0
         load_image8g((grp == 0 ? p.w2img : p.wnimg) + ((size_t)l * 8 + slot) * 4 * GT * 4, gtid, wmn[slot]);
+#endif
     const float4* wsk_g = reinterpret_cast<const float4*>(p.wsimg) + (size_t)l * NK * 8 * RT;    // this layer's conv1x1_skip image
 #pragma unroll
     for (int row = 0; row < 2; ++row) {
@@ -1137,7 +1206,11 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
                 WNV_TSX(12);
                 __builtin_amdgcn_s_setprio(3);                                  // wave 4 shares its SIMD with the polling wave 0
                 float a, g;
+#if WNV_PHASE2
+                if (!first_stage) group_matvec8r(wmn, s.hb + ES * ks, s.pre + chc, s.pre + RC + chc, a, g);
+#else
                 if (!first_stage) group_matvec8(wmn, s.hb + ES * ks, s.pre + chc, s.pre + RC + chc, a, g);
+#endif
                 else { a = s.pre[chc]; g = s.pre[RC + chc]; }
                 if (gwriter) *reinterpret_cast<float2*>(s.zin + 2 * chc) = make_float2(a, g);
                 __builtin_amdgcn_s_setprio(0);
@@ -1156,8 +1229,12 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
             if (grp == 1) WNV_TS(0);                                            // (noted by the waves that are idle here)
             if (grp == 0) {
                 float a, g;
+#if WNV_PHASE2
+                group_matvec8r(wmn, s.hx + ES * ks, s.zin + 2 * chc, s.zin + 2 * chc + 1, a, g);
+#else
                 group_matvec8(wmn, s.hx + ES * ks, s.zin + 2 * chc, s.zin + 2 * chc + 1, a, g);
-                const float u = fast_gate(a, g);                                // modules.py:154
+#endif
+                const float u = ring_gate(a, g);                                // modules.py:154
                 if (gwriter) {
                     if (!last_stage) st_granule(x_out, tag, u, fast);           // send on: nothing else is on the chain
                     s.us[eidx(chc)] = u;
@@ -1447,7 +1524,7 @@ __device__ __attribute__((always_inline)) void run_stage_split(const RingParams&
             if (grp == 0) {
                 float a, g;
                 group_matvec4(wmn, s.hx + ES * ks, s.zin + 2 * lc, s.zin + 2 * lc + 1, a, g);
-                const float u = fast_gate(a, g);                                // modules.py:154
+                const float u = ring_gate(a, g);                                // modules.py:154
                 if (gwriter) {
                     if (!last_stage) st_granule(x_out, tag, u, fast);
                     s.us[eidx(lc)] = u;
@@ -1770,7 +1847,7 @@ __device__ __attribute__((always_inline)) void run_head(const RingParams& p, int
         if (wave < 2) {
             const float h0 = fmaf(wf, xs, bf);
             if (l0) {
-                const float u = fast_gate(fmaf(a_t, xs, pt), fmaf(a_s, xs, ps));
+                const float u = ring_gate(fmaf(a_t, xs, pt), fmaf(a_s, xs, ps));
                 st_granule(ad.x1, tg, u, fast);
                 // N_1 h_0 for stage 1 (it would otherwise run its N mat-vec ON the chain: h_0 is not known a layer early any more)
                 st_granule(ad.z, tg, fmaf(n_t, xs, d_t), fast);
@@ -1809,6 +1886,22 @@ __device__ __attribute__((always_inline)) void run_head(const RingParams& p, int
         feed(b, p.tag_base + 1u, feed_addr(b, 0), xs, l0 && tid < RC ? c_t + s.pre0[tid] : 0.f, l0 && tid < RC ? c_s + s.pre0[RC + tid] : 0.f);
     }
 
+    // packed slots: the maps' entries of the iteration about to run -- (utterance j, step t) -> pf_*; called with the CURRENT (j, t) it
+    // fetches the next iteration's: (j + 1, t) or (0, t + 1)
+    int pf_start = 0, pf_uid = 0, pf_next = -1;
+    const int nj_live = min(p.upr, (p.B - ring + p.n_rings - 1) / p.n_rings);
+    auto seg_fetch = [&](int jn, int tn) {
+        if constexpr (PACKED) {
+            if (tn < p.T) {
+                const int* base = p.seg_start + (size_t)(ring + jn * p.n_rings) * p.T + tn;
+                pf_start = uniform_ld(base);
+                pf_uid = uniform_ld(p.seg_uid + (size_t)(ring + jn * p.n_rings) * p.T + tn);
+                pf_next = tn + 1 < p.T ? uniform_ld(base + 1) : -1;
+            }
+        }
+    };
+    auto seg_prefetch = [&](int j, int t) { if (j + 1 < nj_live) seg_fetch(j + 1, t); else seg_fetch(0, t + 1); };
+    seg_fetch(0, 0);
     unsigned noise_seen = 0;
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
@@ -1821,9 +1914,11 @@ __device__ __attribute__((always_inline)) void run_head(const RingParams& p, int
             int tl = t, ub = p.b0 + b;                                              // coordinates of the noise stream
             bool next_starts = false;                                               // packed slots: step t + 1 is the first of another utterance
             if constexpr (PACKED) {
-                const size_t so = (size_t)b * p.T + t;
-                tl = t - p.seg_start[so]; ub = p.seg_uid[so];
-                next_starts = t + 1 < p.T && p.seg_start[so + 1] == t + 1;
+                // (the maps' entries of THIS iteration were asked for an iteration ago -- seg_prefetch: a ring that carries several
+                //  utterances is bound by its head's occupancy per utterance, and a load -> Philox -> log chain at the top of it was 1-2 us)
+                tl = t - pf_start; ub = pf_uid;
+                next_starts = pf_next == t + 1;
+                seg_prefetch(j, t);
             }
             float gum = 0.f, lr = 0.f, forced = 0.f;
             if (i < nmix && nz_ok) gum = -logf(-logf(head_noise(p, t, b, i, 0, tl, ub)));   // Gumbel noise (mixture.py:138-140)
@@ -1975,6 +2070,22 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
         send_input(b, dense, 127, p.tag_base + 1u);
     }
 
+    // packed slots: the maps' entries of the iteration about to run -- (utterance j, step t) -> pf_*; called with the CURRENT (j, t) it
+    // fetches the next iteration's: (j + 1, t) or (0, t + 1)
+    int pf_start = 0, pf_uid = 0, pf_next = -1;
+    const int nj_live = min(p.upr, (p.B - ring + p.n_rings - 1) / p.n_rings);
+    auto seg_fetch = [&](int jn, int tn) {
+        if constexpr (PACKED) {
+            if (tn < p.T) {
+                const int* base = p.seg_start + (size_t)(ring + jn * p.n_rings) * p.T + tn;
+                pf_start = uniform_ld(base);
+                pf_uid = uniform_ld(p.seg_uid + (size_t)(ring + jn * p.n_rings) * p.T + tn);
+                pf_next = tn + 1 < p.T ? uniform_ld(base + 1) : -1;
+            }
+        }
+    };
+    auto seg_prefetch = [&](int j, int t) { if (j + 1 < nj_live) seg_fetch(j + 1, t); else seg_fetch(0, t + 1); };
+    seg_fetch(0, 0);
     unsigned noise_seen = 0;
     for (int t = 0; t < p.T; ++t) {
         const unsigned tag = p.tag_base + (unsigned)t + 1u;
@@ -1987,9 +2098,9 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
             int tl = t, ub = p.b0 + b;
             bool next_starts = false;                                               // packed slots: step t + 1 is the first of another utterance
             if constexpr (PACKED) {
-                const size_t so = (size_t)b * p.T + t;
-                tl = t - p.seg_start[so]; ub = p.seg_uid[so];
-                next_starts = t + 1 < p.T && p.seg_start[so + 1] == t + 1;
+                tl = t - pf_start; ub = pf_uid;                                     // (asked for an iteration ago: seg_prefetch)
+                next_starts = pf_next == t + 1;
+                seg_prefetch(j, t);
             }
             if (tid < O) s.nzb[tid] = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
             if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.ints[0] = 1;
@@ -2385,6 +2496,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
     auto T = [&](const std::string& n) -> const HostTensor& { return *store.get(n); };
     // padded gate row o (tanh channels 0..127, then sigmoid channels 0..127) -> the model's gate row, or -1
     auto gate_row = [&](int o) { const int ch = o & (RC - 1); return ch < Gha ? (o >> 7) * Gha + ch : -1; };
+    // WNV_PHASE2: the gate's exp2 scales, folded into every term of z (ring_gate): padded row o is a tanh row (o < 128) or a sigmoid row
+    auto gate_scale = [](int o) -> double { return WNV_PHASE2 ? (double)(o < RC ? GATE_SCALE_TANH : GATE_SCALE_SIGM) : 1.0; };
     // a (rows x cols) row-major matrix zero-padded to (prow x pcol)
     auto padded = [](const float* M, int rows, int cols, int prow, int pcol) {
         std::vector<float> P((size_t)prow * pcol, 0.f);
@@ -2424,7 +2537,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
         // gate-to-gate chain (see run_stage): M_l = sqrt(.5) W_cur,l W_o,l-1, N_l = sqrt(.5) W_cur,l, c_l = N_l b_o,l-1, folded in
         // double and rounded once; layer 0 reads h_0 itself: M_0 = W_cur,0, no N term
         if (l == 0) {
-            mmat = cur;
+            for (int o = 0; o < GC; ++o)
+                for (int kk = 0; kk < RC; ++kk) mmat[(size_t)o * RC + kk] = (float)(gate_scale(o) * (double)cur[(size_t)o * RC + kk]);
         } else {
             const std::vector<float> wop = padded(T("conv_layers." + std::to_string(l - 1) + ".conv1x1_out.weight").data.data(), Ra, Gha, RC, RC);   // (R, G/2, 1)
             const std::vector<float> bop = padded(T("conv_layers." + std::to_string(l - 1) + ".conv1x1_out.bias").data.data(), 1, Ra, 1, RC);
@@ -2432,12 +2546,12 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
                 for (int kk = 0; kk < RC; ++kk) {
                     double acc = 0.0;
                     for (int m = 0; m < RC; ++m) acc += (double)cur[(size_t)o * RC + m] * (double)wop[(size_t)m * RC + kk];
-                    mmat[(size_t)o * RC + kk] = (float)(rs * acc);
-                    nmat[(size_t)o * RC + kk] = (float)(rs * (double)cur[(size_t)o * RC + kk]);
+                    mmat[(size_t)o * RC + kk] = (float)(gate_scale(o) * rs * acc);
+                    nmat[(size_t)o * RC + kk] = (float)(gate_scale(o) * rs * (double)cur[(size_t)o * RC + kk]);
                 }
                 double cb = 0.0;
                 for (int m = 0; m < RC; ++m) cb += (double)cur[(size_t)o * RC + m] * (double)bop[m];
-                blob[st->o_cvec + (size_t)l * GC + o] = (float)(rs * cb);
+                blob[st->o_cvec + (size_t)l * GC + o] = (float)(gate_scale(o) * rs * cb);
             }
         }
         const size_t rowsz = (size_t)4 * RT * 4;                   // one row image: 4 chunks x 512 threads x 4 floats
@@ -2464,10 +2578,10 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
             const int go = gate_row(o);
             if (go < 0) continue;
             for (int k = 0; k < kw - 1; ++k)
-                for (int ii = 0; ii < Ra; ++ii) wp[(size_t)(k * RC + ii) * GC + o] = wc.data[((size_t)go * Ra + ii) * kw + k];
+                for (int ii = 0; ii < Ra; ++ii) wp[(size_t)(k * RC + ii) * GC + o] = (float)(gate_scale(o) * (double)wc.data[((size_t)go * Ra + ii) * kw + k]);
             if (cin > 0) {
                 const HostTensor& wcc = T(pfx + "conv1x1c.weight");        // (G, cin, 1)
-                for (int jx = 0; jx < cin; ++jx) wp[(size_t)((kw - 1) * RC + jx) * GC + o] = wcc.data[(size_t)go * cin + jx];
+                for (int jx = 0; jx < cin; ++jx) wp[(size_t)((kw - 1) * RC + jx) * GC + o] = (float)(gate_scale(o) * (double)wcc.data[(size_t)go * cin + jx]);
             }
         }
         const std::vector<float> ws = padded(T(pfx + "conv1x1_skip.weight").data.data(), Ka, Gha, K, RC);   // (K, G/2, 1): pass pp = skip channels [128 pp, 128 pp + 128)
@@ -2530,8 +2644,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
                 a += wv * (double)wf.data[ii];
                 cc += wv * (double)bf.data[ii];
             }
-            blob[st->o_l0 + o] = (float)a;
-            blob[st->o_l0 + GC + o] = (float)cc;
+            blob[st->o_l0 + o] = (float)(gate_scale(o) * a);
+            blob[st->o_l0 + GC + o] = (float)(gate_scale(o) * cc);
             if (L >= 2) {                                                // N_1 = sqrt(.5) W_cur,1 (the tap workgroup adds c_1 = N_1 b_o,0)
                 const HostTensor& wc1 = T("conv_layers.1.conv.weight");
                 double a1 = 0.0, c1 = 0.0;
@@ -2540,8 +2654,8 @@ static wnv_status build_state(WnvRingState** out, int device, const wnv_config& 
                     a1 += wv * (double)wf.data[ii];
                     c1 += wv * (double)bf.data[ii];
                 }
-                blob[st->o_l0 + 2 * GC + o] = (float)a1;
-                blob[st->o_l0 + 3 * GC + o] = (float)c1;
+                blob[st->o_l0 + 2 * GC + o] = (float)(gate_scale(o) * a1);
+                blob[st->o_l0 + 3 * GC + o] = (float)(gate_scale(o) * c1);
             }
         }
     }
