@@ -23,6 +23,8 @@
 //  11  10 + the last DPP level as ONE v_add_f32_dpp in every lane (the compiler splits it into v_mov_dpp + v_add when only the writer lanes gate)
 //  12  11 + zin in the accumulators' init
 //  13  12 + gate as (2 rcp(1 + e1) - 1) rcp(1 + e2) with the exp2 scales folded into the weights: exp -> add -> rcp -> fma -> mul
+//  14  10 + the gate of 13, zin added behind the reduce = WHAT wnv_ring.hip RUNS since round 5 (WNV_PHASE2)
+//  15  14 with zin added to one accumulator pair in the MIDDLE of the FMA sequence (a level hidden under the other accumulators' FMAs)
 // hipcc --offload-arch=gfx950 -O3 -o scripts/ubench_phase.bin scripts/ubench_phase.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -96,11 +98,13 @@ __global__ void __launch_bounds__(512) k(int reps, u64* mail, u64* result, float
                 f2 acc[4];
 #pragma unroll
                 for (int pq = 0; pq < 4; ++pq) acc[pq] = f2{accum * 1e-30f, 0.f};
-                if constexpr (V >= 12) { acc[0].x += z.x; acc[0].y += z.y; }
+                if constexpr (V == 12 || V == 13) { acc[0].x += z.x; acc[0].y += z.y; }
 #pragma unroll
-                for (int c = 0; c < 16; ++c)
+                for (int c = 0; c < 16; ++c) {
 #pragma unroll
                     for (int pq = 0; pq < 4; ++pq) acc[pq] = __builtin_elementwise_fma(w[pq + 4 * (c >> 3)][c & 7], f2{x[c], x[c]}, acc[pq]);
+                    if constexpr (V == 15) { if (c == 9) acc[0] += ((tid & 1) == 0) ? f2{z.x, z.y} : f2{0.f, 0.f}; }
+                }
                 // reduce-scatter over the 8 K lanes: slots 0..7 = acc[0].x, acc[0].y, acc[1].x, ... ; level 1 sends slots 4-7, level 2 slots 2-3
                 const float n0 = dpp_fold<0x141>(acc[0].x, acc[2].x), n1 = dpp_fold<0x141>(acc[0].y, acc[2].y);
                 const float n2 = dpp_fold<0x141>(acc[1].x, acc[3].x), n3 = dpp_fold<0x141>(acc[1].y, acc[3].y);
@@ -112,9 +116,9 @@ __global__ void __launch_bounds__(512) k(int reps, u64* mail, u64* result, float
                     asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
                                  "v_add_f32_dpp %1, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
                                  : "=&v"(a), "=&v"(g) : "v"(m0), "v"(m1));
-                    if constexpr (V == 11) { a += z.x; g += z.y; }
+                    if constexpr (V == 11 || V == 14) { a += z.x; g += z.y; }
                 }
-                if constexpr (V == 13) {
+                if constexpr (V >= 13) {
                     // (the weights carry -2 log2 e / -log2 e: a, g ARE the exp2 arguments) tanh(a') sigmoid(g') = (2 r1 - 1) r2
                     const float e1 = __builtin_amdgcn_exp2f(a), e2 = __builtin_amdgcn_exp2f(g);
                     const float r1 = __builtin_amdgcn_rcpf(1.0f + e1), r2 = __builtin_amdgcn_rcpf(1.0f + e2);
@@ -250,15 +254,16 @@ int main(int argc, char** argv) {
     const char* names[] = {"0 the phase as compiled (baseline)", "1 no LDS read (x in registers)", "2 no reduce / gate", "3 barrier + store only",
                            "4 FMAs only (no read, no tail)", "5 hand-scheduled tail (asm)", "6 4-lane K split, two quad_perm levels", "7 baseline, s_setprio 3",
                            "8 reads as eight ds_read_b64", "9 hand-scheduled tail + zin in the accumulators", "10 row-pair accumulators (no x + y level)",
-                           "11 = 10 + last DPP level as one instruction", "12 = 11 + zin in the accumulators", "13 = 12 + gate as (2 r1 - 1) r2, scales folded"};
-    double ns[14];
+                           "11 = 10 + last DPP level as one instruction", "12 = 11 + zin in the accumulators", "13 = 12 + gate as (2 r1 - 1) r2, scales folded",
+                           "14 = 10 + gate of 13, zin behind the reduce (= WNV_PHASE2)", "15 = 14, zin added mid-sequence"};
+    double ns[16];
     ns[0] = run<0>(reps, mail, result, sink); ns[1] = run<1>(reps, mail, result, sink); ns[2] = run<2>(reps, mail, result, sink);
     ns[3] = run<3>(reps, mail, result, sink); ns[4] = run<4>(reps, mail, result, sink); ns[5] = run<5>(reps, mail, result, sink);
     ns[6] = run<6>(reps, mail, result, sink); ns[7] = run<7>(reps, mail, result, sink); ns[8] = run<8>(reps, mail, result, sink);
     ns[9] = run<9>(reps, mail, result, sink);
     ns[10] = run<10>(reps, mail, result, sink); ns[11] = run<11>(reps, mail, result, sink); ns[12] = run<12>(reps, mail, result, sink);
-    ns[13] = run<13>(reps, mail, result, sink);
-    for (int v = 0; v < 14; ++v) printf("variant %-52s %7.1f ns per phase (+ barrier)\n", names[v], ns[v]);
+    ns[13] = run<13>(reps, mail, result, sink); ns[14] = run<14>(reps, mail, result, sink); ns[15] = run<15>(reps, mail, result, sink);
+    for (int v = 0; v < 16; ++v) printf("variant %-52s %7.1f ns per phase (+ barrier)\n", names[v], ns[v]);
     printf("derived: barrier+store floor %.1f | FMA phase alone %.1f (256 x 128 MACs at 128 FMA/clk = 106.7) | LDS read on the chain %.1f | reduce+gate tail %.1f\n",
            ns[3], ns[4] - ns[3], ns[0] - ns[1], ns[0] - ns[2]);
     return 0;

@@ -318,28 +318,31 @@ def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, want_para
     n, T = len(bins), max(sum(lengths[k] for k in b) for b in bins)
     c_slot = torch.zeros(n, T, cin, device=dev, dtype=torch.float32)
     # per-slot-step maps (int32 each: 8-12 bytes per slot-step next to 4 cin of conditioning; the kernel's roles look a step up without
-    # carrying a cursor per slot in registers they do not have)
-    seg_start = torch.zeros(n, T, dtype=torch.int32)
-    seg_uid = torch.zeros(n, T, dtype=torch.int32)
-    seg_gid = torch.zeros(n, T, dtype=torch.int32) if speaker_ids is not None else None
+    # carrying a cursor per slot in registers they do not have).  Built ON THE DEVICE from one small segment table (start, id, speaker,
+    # length per segment; a slot that ends early keeps its last utterance running to T: ignored) -- as host arrays they were 8-12 T n
+    # bytes of fills and of pageable upload per launch
     where = {}
+    seg_rows = []                               # (start, uid, gid, run length) per segment, slot after slot
     for s, b in enumerate(bins):
         off = 0
-        for k in b:
+        for j, k in enumerate(b):
             where[k] = (s, off)
-            seg_start[s, off:] = off            # (the tail of a slot that ends early keeps its last utterance running: ignored)
-            seg_uid[s, off:] = ids[k]
-            if seg_gid is not None:
-                seg_gid[s, off:] = int(speaker_ids[ids[k]])
+            run = lengths[k] if j + 1 < len(b) else T - off
+            seg_rows.append((off, ids[k], int(speaker_ids[ids[k]]) if speaker_ids is not None else 0, run))
             off += lengths[k]
+    table = torch.tensor(seg_rows, dtype=torch.int32).to(dev)
+    runs = table[:, 3].to(torch.int64)
+    seg_start = torch.repeat_interleave(table[:, 0], runs, output_size=n * T).view(n, T)
+    seg_uid = torch.repeat_interleave(table[:, 1], runs, output_size=n * T).view(n, T)
+    seg_gid = torch.repeat_interleave(table[:, 2], runs, output_size=n * T).view(n, T) if speaker_ids is not None else None
     for k, cu in upsample_each(eng, mels, ids, cin_pad, hop_size):
         s, off = where[k]
         c_slot[s, off:off + lengths[k]] = cu
     g_rows = None
     if seg_gid is not None:                     # one bias row per speaker of the embedding table (tiny: n_speakers x L x G floats)
         g_rows = torch.arange(int(model.embed_speakers.weight.shape[0]), dtype=torch.int64, device=dev)
-    out, params, _ = eng.generate(B=n, T=T, c_up=c_slot, seed=seed, seg_start=seg_start.to(dev), seg_uid=seg_uid.to(dev),
-                                  seg_gid=None if seg_gid is None else seg_gid.to(dev), g_ids=g_rows, kernel=0, want_params=want_params)
+    out, params, _ = eng.generate(B=n, T=T, c_up=c_slot, seed=seed, seg_start=seg_start, seg_uid=seg_uid, seg_gid=seg_gid, g_ids=g_rows,
+                                  kernel=0, want_params=want_params)
     st = dict(slots=n, slot_steps=T, true_samples=sum(lengths), padded_samples=n * T, utterances_per_slot=[len(b) for b in bins])
     res, par = [], []
     for k in range(len(ids)):
