@@ -1012,23 +1012,28 @@ __device__ __forceinline__ void load_pair8g(const float* img_slot0, int gtid, f2
 }
 // (the addends za, zb are read ahead of the x slice and added behind the reduce: as the init of the accumulators -- variant 12 -- the
 //  first FMAs wait for them, +14 ns; the last DPP level as one hand-written instruction -- variant 11 -- buys nothing)
-__device__ __forceinline__ void group_matvec8r(const f2 (&w)[4][16], const float* xslice, const float* za, const float* zb, float& a, float& g) {
+#ifndef WNV_PHASE2_ZACC
+#define WNV_PHASE2_ZACC 0      // 1: the addends as the init of accumulator pair 0 in the writer lane of each finishing pair (ubench variant 13 form)
+#endif
+__device__ __forceinline__ void group_matvec8r(const f2 (&w)[4][16], const float* xslice, const float* za, const float* zb, float& a, float& g, bool zlane = true) {
     float2 z = make_float2(*za, *zb);
     float x[16];
     lds_read16(xslice, x);
     f2 acc[4];
 #pragma unroll
     for (int pq = 0; pq < 4; ++pq) acc[pq] = f2{0.f, 0.f};
+    if (WNV_PHASE2_ZACC) acc[0] = zlane ? f2{z.x, z.y} : f2{0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 16; ++k)
 #pragma unroll
         for (int pq = 0; pq < 4; ++pq) acc[pq] = __builtin_elementwise_fma(w[pq][k], f2{x[k], x[k]}, acc[pq]);
-    asm volatile("" : "+v"(z.x), "+v"(z.y));                     // the reads were issued up there, not behind the reduce
+    if (!WNV_PHASE2_ZACC) asm volatile("" : "+v"(z.x), "+v"(z.y));   // the reads were issued up there, not behind the reduce
     const float n0 = dpp_fold<0x141>(acc[0].x, acc[2].x), n1 = dpp_fold<0x141>(acc[0].y, acc[2].y);
     const float n2 = dpp_fold<0x141>(acc[1].x, acc[3].x), n3 = dpp_fold<0x141>(acc[1].y, acc[3].y);
     const float m0 = dpp_fold<0x4E>(n0, n2), m1 = dpp_fold<0x4E>(n1, n3);
-    a = dpp_fold<0xB1>(m0, m0) + z.x;
-    g = dpp_fold<0xB1>(m1, m1) + z.y;
+    a = dpp_fold<0xB1>(m0, m0);
+    g = dpp_fold<0xB1>(m1, m1);
+    if (!WNV_PHASE2_ZACC) { a += z.x; g += z.y; }
 }
 
 // One stage = one gated layer on one CU, weights resident in VGPRs.
@@ -1207,7 +1212,7 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
                 __builtin_amdgcn_s_setprio(3);                                  // wave 4 shares its SIMD with the polling wave 0
                 float a, g;
 #if WNV_PHASE2
-                if (!first_stage) group_matvec8r(wmn, s.hb + ES * ks, s.pre + chc, s.pre + RC + chc, a, g);
+                if (!first_stage) group_matvec8r(wmn, s.hb + ES * ks, s.pre + chc, s.pre + RC + chc, a, g, gwriter);
 #else
                 if (!first_stage) group_matvec8(wmn, s.hb + ES * ks, s.pre + chc, s.pre + RC + chc, a, g);
 #endif
@@ -1230,7 +1235,7 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
             if (grp == 0) {
                 float a, g;
 #if WNV_PHASE2
-                group_matvec8r(wmn, s.hx + ES * ks, s.zin + 2 * chc, s.zin + 2 * chc + 1, a, g);
+                group_matvec8r(wmn, s.hx + ES * ks, s.zin + 2 * chc, s.zin + 2 * chc + 1, a, g, gwriter);
 #else
                 group_matvec8(wmn, s.hx + ES * ks, s.zin + 2 * chc, s.zin + 2 * chc + 1, a, g);
 #endif
