@@ -322,6 +322,22 @@ def dry_run(args, world, rank):
     return 0
 
 
+def measured_floor_us(kw, n_head_parts=1):
+    """The serial-chain floor from MEASURED constants only (round 5; profiles/r05_latency_constants.json): per stage on the chain the
+    best same-XCD hop of the own microbenchmarks + the best isolated chain phase of scripts/ubench_phase.hip (barrier, LDS read, mat-vec,
+    reduce, gate, store: what one CU needs for one layer when nothing else is in its way); the head as in latency_floor_us."""
+    try:
+        cj = json.load(open(os.path.join(ROOT, "profiles", "r05_latency_constants.json")))
+        hop, phase = float(cj["hop_us"]), float(cj["phase_us"])
+    except Exception:
+        hop, phase = 0.276, 0.298
+    fma_per_us = 128 * 2400.0
+    K, O = kw["skip_out_channels"], kw["out_channels"]
+    stages = kw["layers"] - (1 if kw.get("scalar_input", False) and K <= 128 and kw["layers"] >= 2 else 0)
+    head = 2 * hop + (K * K / max(n_head_parts, 1) + O * K) / fma_per_us + (hop if n_head_parts > 1 else 0.0)
+    return stages * (hop + phase) + head, hop, phase
+
+
 def latency_floor_us(kw, n_head_parts=1, hop=0.276):
     """Serial-chain floor of the one-layer-per-CU design, from the committed microbenchmarks: per stage on the chain one same-XCD
     CU -> CU hop + the on-chain G x G/2 mat-vec at the CU's fp32 FMA peak (128 FMA/clk at 2.4 GHz: 256 x 128 MACs = 0.107 us); head:
@@ -615,6 +631,7 @@ def main():
             print(f"[bench] LDS peak microbenchmark failed: {e}", file=sys.stderr)
         nparts = max(kw["skip_out_channels"] // 128, 1)
         floor, floor_hop2 = latency_floor_us(kw, nparts), latency_floor_us(kw, nparts, hop=0.444)
+        floor_meas, hop_meas, phase_meas = measured_floor_us(kw, nparts)
         line = {
             "metric": "audio kSamples/sec (24 kHz MoL egs/mol, batch=8 per GPU), whole job",
             "value": round(value, 3), "unit": "kSamples/s", "n_gpus": world, "steps": args.steps,
@@ -637,10 +654,13 @@ def main():
             "roofline_hbm": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(ach / HBM_PEAK_GBS, 5),
                              "note": "for reference only: the sample loop does not stream from HBM (traffic << algorithmic bytes)"},
-            "roofline_latency": {"bound": "serial chain latency", "floor_us_per_step": round(floor, 3), "achieved_us_per_step": round(us_step, 3),
-                                 "frac": round(floor / us_step, 4),
-                                 "model": "stages on the chain x (best same-XCD CU->CU hop 0.276 us [profiles/ubench/hop234_same_box.txt, ubench_hop4] + "
-                                          "on-chain 256x128 mat-vec at the fp32 FMA peak 0.107 us) + head (2 hops + KxK and OxK mat-vecs)",
+            "roofline_latency": {"bound": "serial chain latency", "floor_us_per_step": round(floor_meas, 3), "achieved_us_per_step": round(us_step, 3),
+                                 "frac": round(floor_meas / us_step, 4),
+                                 "model": f"MEASURED constants (profiles/r05_latency_constants.json): stages on the chain x (best same-XCD CU->CU hop {hop_meas} us "
+                                          f"[ubench_hop4] + best isolated chain phase {phase_meas} us [scripts/ubench_phase.hip: barrier, LDS read, 256x128 "
+                                          "mat-vec, reduce, gate, store]) + head (2 hops + KxK and OxK mat-vecs at the FMA peak)",
+                                 "floor_us_per_step_ideal": round(floor, 3), "frac_ideal": round(floor / us_step, 4),
+                                 "model_ideal": "as above with the chain phase priced at the fp32 FMA peak alone (0.107 us): what rounds 3-4 reported",
                                  "floor_us_per_step_hop2_0p444": round(floor_hop2, 3), "frac_hop2_0p444": round(floor_hop2 / us_step, 4)},
             "ranks": ranks,
             "distributed": dist_info(dist, world, args),

@@ -534,6 +534,9 @@ __device__ __forceinline__ float fast_gate(float a, float g) {
 #ifndef WNV_PHASE2
 #define WNV_PHASE2 1
 #endif
+#ifndef WNV_SKIP_DIRECT
+#define WNV_SKIP_DIRECT 1      // K = 512: every stage hands its own skip term to the head parts (head_sum_skip_terms)
+#endif
 constexpr float GATE_SCALE_TANH = -2.8853900817779268f, GATE_SCALE_SIGM = -1.4426950408889634f;
 __device__ __forceinline__ float ring_gate(float a, float g) {
 #if WNV_PHASE2
@@ -1013,7 +1016,8 @@ __device__ __forceinline__ void load_pair8g(const float* img_slot0, int gtid, f2
 // (the addends za, zb are read ahead of the x slice and added behind the reduce: as the init of the accumulators -- variant 12 -- the
 //  first FMAs wait for them, +14 ns; the last DPP level as one hand-written instruction -- variant 11 -- buys nothing)
 #ifndef WNV_PHASE2_ZACC
-#define WNV_PHASE2_ZACC 0      // 1: the addends as the init of accumulator pair 0 in the writer lane of each finishing pair (ubench variant 13 form)
+#define WNV_PHASE2_ZACC 1      // the addends as the init of accumulator pair 0 in the writer lane of each finishing pair (ubench variant 13: 298 against 309 ns;
+                               // same-box A/B of the headline: 511.3 against 507.5 kSamples/s, profiles/r05_phase2_ab.txt); 0: added behind the reduce
 #endif
 __device__ __forceinline__ void group_matvec8r(const f2 (&w)[4][16], const float* xslice, const float* za, const float* zb, float& a, float& g, bool zlane = true) {
     float2 z = make_float2(*za, *zb);
@@ -1110,6 +1114,8 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
     // (the stage before the last: the last stage and, for the skip sum it completes, every head part -- consecutive positions)
     const int rd1 = ring + (sidx + 1) * p.rstride, rd2 = ring + (sidx + 2 <= p.S ? sidx + 2 : sidx + 1) * p.rstride;
     const bool fast = same_xcd_as(p, rd1, last_stage ? p.NH : sidx == p.S - 2 ? 1 + p.NH : 1, rd2, s.flags + 1);
+    // (K = 512: the skip terms are read by the head parts -- positions S .. S + NH - 1 of the ring)
+    const bool fast_head = (NK > 2 && WNV_SKIP_DIRECT) ? same_xcd_as(p, ring + p.S * p.rstride, p.NH, ring + p.S * p.rstride, s.flags + 2) : false;
 
 #ifdef WNV_DBG_MARK
     unsigned miss_pre = 0, miss_g = 0, miss_q = 0;                      // (diagnostic build) what the throughput prologue's first look did not find
@@ -1303,7 +1309,9 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
                     float mine[NK], acc[NK];
 #pragma unroll
                     for (int pp = 0; pp < NK; ++pp) { mine[pp] = skip_term(pp); acc[pp] = 0.f; }
-                    if (sidx > 0 && !last_stage) {
+                    if (WNV_SKIP_DIRECT) {
+                        // the terms go straight to the head parts, which add them up in layer order (head_sum_skip_terms): no wait here
+                    } else if (sidx > 0 && !last_stage) {
                         unsigned spins = 0;
                         for (;;) {
                             bool hit = true;
@@ -1323,7 +1331,7 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
                     }
                     if (writer && ok) {
 #pragma unroll
-                        for (int pp = 0; pp < NK; ++pp) st_granule(sm_out + RC * pp, tag, acc[pp] + mine[pp], fast);
+                        for (int pp = 0; pp < NK; ++pp) st_granule(sm_out + RC * pp, tag, acc[pp] + mine[pp], WNV_SKIP_DIRECT ? fast_head : fast);
                     }
                 }
                 if (!ok) s.flags[0] = 1;
@@ -1660,8 +1668,41 @@ template <int NK, int NW2> struct HeadSlice {
 
 // skip sum of (b, t) -> s.vs (all parts): the sum through stage S - 2 (slot S - 1) + the last stage's own term (slot S), the
 // reference's order of additions (wavenet.py:312);  returns false on abort
+// K = 512 (round 5, WNV_SKIP_DIRECT): the skip sum no longer travels stage to stage.  With four skip passes per stage -- two of them
+// streamed from the L2 -- the accumulated sum ran ~2.5 us behind the gates and the head waited 1.6 us for it after the last gate
+// (profiles/r05_ring_k512_fine_timeline.txt), while every stage spent those microseconds polling its predecessor's sum.  Now every stage
+// hands ITS OWN term to the head parts (slot l + 1 of the same mailbox) and the head parts, idle while the chain runs, add the terms up in
+// layer order -- the reference's order of additions (wavenet.py:312) -- four slots per round trip, as they arrive.
+__device__ __forceinline__ bool head_sum_skip_terms(const RingParams& p, int b, unsigned tag, float* vs, int tid, int lane) {
+    const u64* slot = p.smail + ((size_t)b * (p.S + 1) + 1) * p.Kp + tid;       // stage 0's term; stage l's is Kp granules further per layer
+    float acc = 0.f;
+    for (int l0 = 0; l0 < p.S; l0 += 4) {
+        const int n = min(4, p.S - l0);
+        float v[4];
+        unsigned spins = 0;
+        for (;;) {
+            u64 x[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) x[k] = k < n ? ld_granule(slot + (size_t)(l0 + k) * p.Kp) : ((u64)tag << 32);
+            bool hit = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { v[k] = __uint_as_float((unsigned)x[k]); hit = hit && (unsigned)(x[k] >> 32) == tag; }
+            if (__all(hit)) break;
+            if ((++spins & 255u) == 0u) {
+                if (__hip_atomic_load(p.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return false;
+                if (spins > SPIN_LIMIT) { if (lane == 0) atomicCAS(p.status, 0u, 0x300u); return false; }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < n) acc += v[k];
+    }
+    vs[qidx(tid)] = fmaxf(acc * p.skip_scale, 0.f);                             // wavenet.py:313-316
+    return true;
+}
+
 template <int NK>
 __device__ __forceinline__ bool head_recv_skip(const RingParams& p, int b, unsigned tag, float* vs, int tid, int lane, int wave) {
+    if constexpr (NK == 4 && WNV_SKIP_DIRECT != 0) return head_sum_skip_terms(p, b, tag, vs, tid, lane);
     bool ok = true;
     if (wave < 2 * NK) {
         const u64* own = p.smail + ((size_t)b * (p.S + 1) + p.S) * p.Kp + tid;
