@@ -249,7 +249,7 @@ def test_ring_kernel_keeps_its_poll_registers_out_of_the_compilers_hands(tmp_pat
         lines = [ln.split(";")[0].rstrip() for ln in m.group(1).splitlines()]
         label_pos = {label.match(c).group(1): i for i, c in enumerate(lines) if label.match(c)}
         issues = [i for i, c in enumerate(lines) if issue.match(c)]
-        assert len(issues) > 10
+        assert len(issues) >= 8                                  # (the K = 512 head adds its skip terms up with plain polls since round 5)
         for i0 in issues:
             mi = issue.match(lines[i0])
             slot = set(range(int(mi.group(1)), int(mi.group(2)) + 1))
