@@ -24,12 +24,15 @@ d = json.loads(sys.stdin.readline())
 print("%-26s B = %d  kernel %7.1f  (%.2f x real time at 24 kHz per utterance)" % (sys.argv[1], d["config"]["batch_per_gpu"], d["value"], d["value"] / d["config"]["batch_per_gpu"] / 24.0))' $w
 done
 done
-# K = 512 at two / four utterances per ring: the plain stage prologue (WNV_RING_MODE=0) against the throughput one the host now picks
-for B in 16 32; do
-  WNV_RING_MODE=0 python bench.py --workload cfg4_mol_multispeaker --steps 2 --T 8192 --batch $B --cpu-steps 0 --no-extras 2>/dev/null | tail -1 | python -c '
+# BASELINE configs[3] / configs[4] as jobs on one GPU: 64 utterances of the 30-layer Gaussian, 128 of the speaker-conditioned model (packed slots
+# with a speaker per utterance since round 5)
+for spec in "cfg3b_gaussian30 64" "cfg4_mol_multispeaker 128"; do set -- $spec
+  for M in "" "--packed"; do
+  python bench.py --workload $1 --job $2 --steps 1 --warmup 1 $M 2>/dev/null | tail -1 | python -c '
 import sys, json
-d = json.loads(sys.stdin.readline())
-print("%-26s B = %d  kernel %7.1f  (WNV_RING_MODE=0: the plain prologue)" % (sys.argv[1], d["config"]["batch_per_gpu"], d["value"]))' cfg4_mol_multispeaker
+d = json.loads(sys.stdin.readline()); j = d["job"]
+print("%-22s job of %3d utterances %-7s: %7.1f kSamples/s true (%7.1f incl. padding), padding %4.1f %%, launches %s" % (sys.argv[2], j["utterances"], sys.argv[1] or "padded", d["value"], j["kSamples_per_s_incl_padding"], 100 * j["padding_loss"], j["rank0_launches_B_x_T"][:4]))' "$M" $1
+  done
 done
 for J in 40 100 200; do
   for M in "" "--packed"; do

@@ -566,21 +566,10 @@ __device__ __forceinline__ float dot32p(const f2 (&w)[16], const float (&x)[32])
     a0 += a1;
     return a0.x + a0.y;
 }
-// max(v, v of the DPP partner) as ONE instruction (round 5).  fmaxf(m, dpp_mov(m)) compiles to v_mov_dpp + two canonicalising
-// v_max_f32 x, x, x + the max itself: four dependent instructions per level of the head's Gumbel-max butterfly, on the chain of every
-// step (a dependent level costs a lone wave ~8 ns: scripts/ubench_phase.hip).  The keys are never NaN (finite logits + finite Gumbel
-// noise, -inf in idle lanes).  (s_nop 1: a VALU result needs two wait states before a DPP read; the hazard recogniser is blind in asm)
-#define WNV_DPP_MAX(name, ctrl)                                                                                              \
-    __device__ __forceinline__ float name(float v) {                                                                         \
-        float r;                                                                                                             \
-        asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "=v"(r) : "v"(v)); \
-        return r;                                                                                                            \
-    }
-WNV_DPP_MAX(dpp_max_xor1, "quad_perm:[1,0,3,2]")
-WNV_DPP_MAX(dpp_max_xor2, "quad_perm:[2,3,0,1]")
-WNV_DPP_MAX(dpp_max_half_mirror, "row_half_mirror")
-WNV_DPP_MAX(dpp_max_mirror, "row_mirror")
-#undef WNV_DPP_MAX
+// (Round 5, measured and NOT kept: the head's Gumbel-max butterfly as four hand-written v_max_f32_dpp + a v_cmp straight into a lane
+//  mask -- 4 dependent instructions instead of the 13 the compiler emits for fmaxf(m, dpp_mov(m)) with its canonicalising max pairs --
+//  made the HEADLINE 0.8 % slower on the same box (511.7 -> 507.6 kSamples/s, cfg4 400 -> 390; profiles/r05_phase2_ab.txt): every role
+//  is inlined into one function and a change in the head moves the register allocation of the stage loop, as in round 4.)
 template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
@@ -2033,9 +2022,10 @@ __device__ __attribute__((always_inline)) void run_head(const RingParams& p, int
                     float xc = p.dist == 1 ? mean + __expf(ls) * lr : lr * __expf(ls) + mean;
                     xc = fminf(fmaxf(xc, -1.0f), 1.0f);                           // mixture.py:154 / :269
                     if (nmix > 0) {                                                 // Gumbel-max (mixture.py:138-140), first index wins ties
-                        const float m = dpp_max_mirror(dpp_max_half_mirror(dpp_max_xor2(dpp_max_xor1(key))));   // lanes 0-15 (a DPP row)
-                        // (v_cmp straight into a lane mask; lanes >= nmix hold -inf and can only tie when every key is -inf)
-                        const unsigned long long win = __builtin_amdgcn_fcmpf(key, m, 1 /* FCMP_OEQ */) & ((1ull << nmix) - 1ull);
+                        float m = key;
+                        m = fmaxf(m, dpp_mov<0xB1>(m)); m = fmaxf(m, dpp_mov<0x4E>(m));
+                        m = fmaxf(m, dpp_mov<0x141>(m)); m = fmaxf(m, dpp_mov<0x140>(m));      // row_half_mirror, row_mirror: lanes 0-15
+                        const unsigned long long win = __ballot(lane < nmix && key == m);
                         const int wl = win ? __ffsll((long long)win) - 1 : 0;
                         xo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xc), wl));
                     } else {
