@@ -783,12 +783,18 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
     // registers -- next to 128 weight registers there are none to spare: the register-staged form spilled 27) into the OTHER input
     // buffer; the issuing wave waits for its own DMAs (vmcnt) in [B] of the pass that uses them, in front of the barrier.
     u64 hx0 = 0, hx1 = 0;
-    auto gather_issue = [&](int t_, int b, float* xu, int buf) {
+    // packed slots: seg_start of (utterance b0_ + wave, step t_ + 1) -- a scalar load (no vector register held across the DMA issue),
+    // asked for ONE PASS AHEAD of the gather that needs it (round 5: read at the top of gather_issue, every pass began its mat-vec behind
+    // a scalar-load round trip -- the packed instantiations ran 12-20 % below the padded ones at the same number of rows)
+    auto seg_at = [&](int t_, int b0_) -> int {
+        if (!PACKED || wave >= min(p.tb, p.B - b0_) || t_ + 1 >= p.T) return INT_MIN;
+        return uniform_ld(p.seg_start + (size_t)__builtin_amdgcn_readfirstlane(b0_ + wave) * p.T + t_ + 1);
+    };
+    auto gather_issue = [&](int t_, int b, float* xu, int buf, int st_) {
         const int tp_ = t_ + 1, tf_ = early ? t_ - 1 : t_, kf = fresh_tap(tf_);
         const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
         const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
         // packed slots: the utterance that occupies the slot at step tp_ began at step st_; what lies before reads as zeros (conv.py:34-36)
-        const int st_ = PACKED ? uniform_ld(p.seg_start + (size_t)__builtin_amdgcn_readfirstlane(b) * p.T + tp_) : INT_MIN;   // (scalar: no register held across the DMA issue)
 #pragma unroll
         for (int q = 0; q < GQ; ++q) {
             const int i = 64 * q + lane;
@@ -812,7 +818,14 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
     };
 
     int t = -1, b0 = bfirst, cur = 0;                              // pass (t, b0) consumes h_l[tf], produces pre_l[t + 1]; its inputs: buffer cur
-    if (wave < min(p.tb, p.B - b0)) gather_issue(t, b0 + wave, s.xin + (size_t)wave * kx, 0);
+    int st_cur = seg_at(t, b0);                                      // ... of the pass about to run, of the next one
+    if (wave < min(p.tb, p.B - b0)) gather_issue(t, b0 + wave, s.xin + (size_t)wave * kx, 0, st_cur);
+    int st_next = INT_MIN;
+    {
+        int tn0 = t, bn0 = b0 + pstride;
+        if (bn0 >= p.B) { bn0 = bfirst; tn0 = t + 1; }
+        st_next = seg_at(tn0, bn0);
+    }
     for (;;) {
         const int tp = t + 1;
         const int nb = min(p.tb, p.B - b0);
@@ -846,7 +859,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
                     *reinterpret_cast<float2*>(hist + (size_t)(tf % rows) * RC + 2 * lane) = make_float2(hv[0], hv[1]);
                     if (kfresh >= 0) {
                         // (packed slots: the row is the previous utterance's when the one at step tp began later than tf)
-                        const bool mine = !PACKED || tf >= uniform_ld(p.seg_start + (size_t)__builtin_amdgcn_readfirstlane(b) * p.T + tp);
+                        const bool mine = !PACKED || tf >= st_cur;
                         *reinterpret_cast<float2*>(xu + kfresh * RC + 2 * lane) = mine ? make_float2(hv[0], hv[1]) : make_float2(0.f, 0.f);
                     }
                 }
@@ -860,7 +873,13 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         int tn = t, bn = b0 + pstride;
         if (bn >= p.B) { bn = bfirst; tn = t + 1; }
         const bool more = tn + 1 < p.T;
-        if (more && wave < min(p.tb, p.B - bn)) gather_issue(tn, bn + wave, s.xin + ((size_t)(cur ^ 1) * TB + wave) * kx, cur ^ 1);
+        if (more && wave < min(p.tb, p.B - bn)) gather_issue(tn, bn + wave, s.xin + ((size_t)(cur ^ 1) * TB + wave) * kx, cur ^ 1, st_next);
+        int st_nn = INT_MIN;                                         // the pass after the next: asked for now, used a pass from now
+        if (PACKED && more) {
+            int tnn = tn, bnn = bn + pstride;
+            if (bnn >= p.B) { bnn = bfirst; tnn = tn + 1; }
+            st_nn = seg_at(tnn, bnn);
+        }
         // ---- [D] mat-vec for all utterances of the pass, four at a time (accumulators + weights must fit the register file):
         //      VGPR rows, then LDS rows, then whatever streams; no barrier inside (the inputs are read-only here, the next
         //      pass's land in the other buffer, and its [B] barrier is behind every wave's last read of this one) -----------
@@ -950,6 +969,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
 #undef TAP_STAMP
         if (!more) break;
         t = tn; b0 = bn; cur ^= 1;
+        st_cur = st_next; st_next = st_nn;
     }
 }
 
