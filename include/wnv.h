@@ -157,7 +157,9 @@ typedef struct wnv_generate_args {
     uint64_t seed;
     int32_t softmax;           /* categorical only: apply softmax (wavenet.py:332)                       */
     int32_t quantize;          /* categorical only: sample a one-hot (wavenet.py:333-335)                */
-    float* out;                /* device (B, C, T): C = 1 scalar samples | out_channels one-hot/probs    */
+    float* out;                /* device (B, C, T): C = 1 scalar samples | out_channels one-hot/probs;   */
+                               /*   NULL allowed for a one-hot model with quantize = 1 and index_out     */
+                               /*   given (ABI 5): the sampled classes only                              */
     float* params_out;         /* optional device (B, out_channels, T): head output before sampling      */
     int32_t* index_out;        /* optional device (B, T): sampled class (categorical + quantize)         */
     int32_t kernel;            /* 0 = auto, 1 = generic single-workgroup kernel, 2 = pipelined ring,     */
@@ -263,7 +265,8 @@ wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* args);
  * audio.inv_preemphasis (audio.py:57-58), / global_gain_scale, clip, int16.  inv_mulaw* / inv_preemphasis are
  * nnmnkwii's published definitions (the reference's un-vendored dependency, setup.py:23). */
 typedef struct wnv_post_args {
-    int32_t B, C;              /* y is (B, C, T): C = 1 for scalar input types, quantize_channels for one-hot */
+    int32_t B, C;              /* y is (B, C, T): C = 1 for scalar input types, quantize_channels for one-hot; C = 1 with */
+                               /* "mulaw-quantize" (ABI 5): y holds the sampled CLASSES as floats (index_out), no argmax   */
     int64_t T;
     const float* y;            /* device: wnv_generate's `out`                                            */
     int32_t input_type;        /* 0 "raw", 1 "mulaw", 2 "mulaw-quantize"  (hparams.input_type)             */

@@ -100,3 +100,43 @@ def test_packed_slots_refuse_what_they_do_not_cover():
         eng.generate(B=B, T=T, c_up=c_up, seed=1, seg_start=seg, seg_uid=seg, kernel=1)
     with pytest.raises(ValueError):
         eng.generate(B=B, T=T, c_up=c_up, seed=1, seg_start=seg[:, :100].contiguous(), seg_uid=seg[:, :100].contiguous())
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_classes_only_output_of_one_hot_models(kernel):
+    """``out = NULL`` (ABI 5): a one-hot model that samples classes can return them alone -- 4 bytes per sample instead of 4 out_channels."""
+    name = "cfg0_mulaw256_small"
+    m = build(name).to("cuda")
+    eng = m._get_engine()
+    B, T = 3, 600
+    full, _, idx_full = eng.generate(B=B, T=T, seed=21, kernel=kernel, want_index=True)
+    none, _, idx_only = eng.generate(B=B, T=T, seed=21, kernel=kernel, want_index=True, want_out=False)
+    assert none is None and torch.equal(idx_only, idx_full) and torch.equal(full.argmax(1).int(), idx_full)
+    with pytest.raises(ValueError):
+        eng.generate(B=B, T=T, seed=21, kernel=kernel, want_out=False)                       # classes only means index_out
+    m2 = build("cfg2_mol").to("cuda")
+    with pytest.raises(ValueError):
+        m2._get_engine().generate(B=1, T=256, c_up=torch.zeros(1, 256, 80, device="cuda"), seed=1, want_index=True, want_out=False)
+    m.to("cpu")
+
+
+def test_packed_one_hot_job_as_classes_and_through_the_post_chain():
+    """``as_index``: the packed job of a one-hot model returns classes; they equal the argmax of the one-hot outputs of the same job, and
+    the post-chain (synthesis.postprocess, C = 1 with "mulaw-quantize") decodes them to the waveform the one-hot route gives."""
+    from types import SimpleNamespace
+    from wavenet_vocoder_amd import synthesis
+    name = "cfg1_mulaw256"
+    m = build(name).to("cuda")
+    mels = job(7, 80, 11, lo=2, hi=5)
+    st_a, st_b = {}, {}
+    onehot = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=8, stats=st_a)
+    classes = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=8, stats=st_b, as_index=True)
+    assert st_b["step_bytes"] * 20 < st_a["step_bytes"] * 6                                   # (80 + 1 + 2 against 80 + 256 + 2 floats per slot-step)
+    hp = synthesis.default_hparams()
+    hp.input_type, hp.quantize_channels = "mulaw-quantize", 256
+    for a, b in zip(onehot, classes):
+        assert b.shape == (1, a.shape[-1]) and torch.equal(a.argmax(0).float(), b[0])
+        wa = synthesis.postprocess(a.unsqueeze(0), hp)
+        wb = synthesis.postprocess(b.unsqueeze(0), hp)
+        assert torch.equal(wa, wb)
+    m.to("cpu")

@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(NT) wnv_generate_generic_kernel(const WnvModel
                 const int idx = sample_categorical(m.O, s.obuf, s.nz, a.softmax, a.quantize, lane);
                 if (a.quantize) {
                     if (lane == 0) {
-                        a.out[((size_t)b * O + idx) * T + t] = 1.0f;             // out is pre-zeroed
+                        if (a.out) a.out[((size_t)b * O + idx) * T + t] = 1.0f;  // out is pre-zeroed (NULL: classes only, index_out)
                         if (a.index_out) a.index_out[(size_t)b * T + t] = idx;
                         s.ints[0] = idx;
                     }

@@ -686,7 +686,10 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     const wnv_config& c = h->cfg;
     const WnvModelDev& m = h->m;
     if (a->B <= 0 || a->T <= 0 || a->T > 0x7fffffffLL) return fail(WNV_ERR_INVALID_ARG, "B and T must be positive (T < 2^31)");
-    if (!a->out) return fail(WNV_ERR_INVALID_ARG, "out is NULL");
+    // (out may be NULL for a one-hot model that samples classes: the caller then takes index_out only -- a (B, out_channels, T) one-hot
+    //  output is 1 KB per sample for a 256-way model, index_out 4 bytes)
+    if (!a->out && !(a->index_out && !c.scalar_input && a->quantize))
+        return fail(WNV_ERR_INVALID_ARG, "out is NULL (allowed only for a one-hot model with quantize = 1 and index_out given)");
     if (m.cin > 0 && !a->c_up) return fail(WNV_ERR_INVALID_ARG, "model has local conditioning but c_up is NULL");
     if (m.cin == 0 && a->c_up) return fail(WNV_ERR_INVALID_ARG, "c_up given but the model has no local conditioning");
     if (m.gin > 0 && !a->g && !a->g_ids) return fail(WNV_ERR_INVALID_ARG, "model has global conditioning but neither g nor g_ids is given");
@@ -723,7 +726,7 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     HIP_TRY(wnv_launch_zbias(m, h->d_layers, h->d_W, has_g ? a->g : nullptr, (has_g && !a->g) ? (const long long*)a->g_ids : nullptr,
                              h->embed_off >= 0 ? h->d_W + h->embed_off : nullptr, Bz, (float*)h->zbias.p, s));
     auto zero_onehot_out = [&]() -> hipError_t {                     // the kernels write only the sampled class (wavenet.py:334)
-        if (!c.scalar_input && a->quantize) return hipMemsetAsync(a->out, 0, (size_t)a->B * m.O * (size_t)a->T * sizeof(float), s);
+        if (!c.scalar_input && a->quantize && a->out) return hipMemsetAsync(a->out, 0, (size_t)a->B * m.O * (size_t)a->T * sizeof(float), s);
         return hipSuccess;
     };
 

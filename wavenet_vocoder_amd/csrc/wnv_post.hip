@@ -45,7 +45,9 @@ __global__ void __launch_bounds__(PT) wnv_post_kernel(const float* __restrict__ 
     float acc = 0.f;
     for (long long n = n0; n < n1; ++n) {
         float x;
-        if (input_type == 2) {                       // argmax over the one-hot / probability axis, first maximum wins
+        if (input_type == 2 && C == 1) {             // (ABI 5) y holds the sampled class itself (wnv_generate_args.index_out as floats)
+            x = inv_mulaw(2.0f * yb[n] / mu - 1.0f, mu);
+        } else if (input_type == 2) {                // argmax over the one-hot / probability axis, first maximum wins
             int best = 0;
             float bv = yb[n];
             for (int c = 1; c < C; ++c) {

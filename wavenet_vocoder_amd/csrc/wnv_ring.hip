@@ -2251,7 +2251,7 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
                         WNV_TS(0);
                     }
                     if (tid == 0) {
-                        p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;             // out is pre-zeroed by the host
+                        if (p.out) p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;  // out is pre-zeroed by the host (NULL: classes only, index_out)
                         if (p.index_out) p.index_out[(size_t)b * p.T + t] = idx;
                     }
                 } else if (wave == 0) {
@@ -2776,7 +2776,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
             if (ga.initial) g.initial = ga.initial + (size_t)b0 * cin1;
             if (ga.teacher) g.teacher = ga.teacher + (size_t)b0 * ga.Tt * cin1;
             if (ga.zbias_bstride != 0 && !ga.seg_gid) g.zbias = ga.zbias + (size_t)b0 * ga.zbias_bstride;
-            g.out = ga.out + (size_t)b0 * cin1 * ga.T;
+            if (ga.out) g.out = ga.out + (size_t)b0 * cin1 * ga.T;
             if (ga.params_out) g.params_out = ga.params_out + (size_t)b0 * O * ga.T;
             if (ga.index_out) g.index_out = ga.index_out + (size_t)b0 * ga.T;
             if (ga.seg_start) { g.seg_start = ga.seg_start + (size_t)b0 * ga.T; g.seg_uid = ga.seg_uid + (size_t)b0 * ga.T; }

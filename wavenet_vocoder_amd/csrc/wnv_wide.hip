@@ -948,7 +948,7 @@ __device__ void run_wide_head_b(const WideParams& p, bool fast_first, int part, 
                 const int idx = sample_categorical(O, s.obuf, s.nz, p.softmax, p.quantize, lane);
                 if (p.quantize) {
                     if (lane == 0) {
-                        p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;                               // out is pre-zeroed by the host
+                        if (p.out) p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;                    // out is pre-zeroed by the host (NULL: classes only)
                         if (p.index_out) p.index_out[(size_t)b * p.T + t] = idx;
                         s.ints[1] = idx;
                     }
@@ -1284,7 +1284,7 @@ wnv_status wnv_wide_generate(WnvWideState** pst, int device, const wnv_config& c
             if (ga.initial) g.initial = ga.initial + (size_t)b0 * cin1;
             if (ga.teacher) g.teacher = ga.teacher + (size_t)b0 * ga.Tt * cin1;
             if (ga.zbias_bstride != 0) g.zbias = ga.zbias + (size_t)b0 * ga.zbias_bstride;
-            g.out = ga.out + (size_t)b0 * cin1 * ga.T;
+            if (ga.out) g.out = ga.out + (size_t)b0 * cin1 * ga.T;
             if (ga.params_out) g.params_out = ga.params_out + (size_t)b0 * O * ga.T;
             if (ga.index_out) g.index_out = ga.index_out + (size_t)b0 * ga.T;
             const wnv_status s0 = wnv_wide_generate(pst, device, c, store, g, stream, err);

@@ -253,7 +253,7 @@ class Engine:
     def generate(self, *, B: int, T: int, c_up=None, g=None, g_ids=None, initial=None, teacher=None,
                  noise=None, seed: int = 0, softmax: bool = True, quantize: bool = True,
                  want_params: bool = False, want_index: bool = False, kernel: int = 0, asynchronous: bool = False,
-                 noise_ready=None, seg_start=None, seg_uid=None, seg_gid=None):
+                 noise_ready=None, seg_start=None, seg_uid=None, seg_gid=None, want_out: bool = True):
         """Runs the whole autoregressive loop.  Returns (out (B,C,T), params (B,O,T)|None, index (B,T)|None).
         ``asynchronous`` (ring kernel chosen explicitly, kernel=2): return right after the launch; ``wait()`` or the next
         call reports a bounded-spin timeout (WNV_GEN_ASYNC in include/wnv.h).  ``noise`` / ``noise_ready`` may be device
@@ -263,7 +263,9 @@ class Engine:
         dev = self.device
         cfg = self.cfg
         C_out = 1 if cfg.scalar_input else cfg.out_channels
-        out = torch.empty(B, C_out, T, device=dev, dtype=torch.float32)
+        if not want_out and (cfg.scalar_input or not quantize or not want_index):
+            raise ValueError("want_out=False is for one-hot models that sample classes (quantize) and return them (want_index)")
+        out = torch.empty(B, C_out, T, device=dev, dtype=torch.float32) if want_out else None      # (one-hot output: 4 out_channels bytes per sample)
         params = torch.empty(B, cfg.out_channels, T, device=dev, dtype=torch.float32) if want_params else None
         index = torch.empty(B, T, device=dev, dtype=torch.int32) if want_index else None
         a = GenerateArgs()
@@ -274,7 +276,7 @@ class Engine:
         a.noise = _ptr(noise)
         a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         a.softmax, a.quantize = int(bool(softmax)), int(bool(quantize))
-        a.out, a.params_out, a.index_out = out.data_ptr(), _ptr(params), _ptr(index)
+        a.out, a.params_out, a.index_out = _ptr(out), _ptr(params), _ptr(index)
         a.kernel = int(kernel)
         a.flags = _lib.WNV_GEN_ASYNC if asynchronous else 0
         a.stream = _stream(dev)

@@ -106,7 +106,7 @@ def _packed_local(model, mels, hparams, mine, speaker_ids=None) -> dict:
 
     with torch.no_grad():
         sharding.synthesize_packed(model, mels, hop_size=hparams.hop_size, cin_pad=hparams.cin_pad, indices=mine, sink=sink,
-                                   speaker_ids=speaker_ids)
+                                   speaker_ids=speaker_ids, as_index=True)     # (one-hot models: classes, not 256-wide one-hot vectors)
     return local
 
 

@@ -212,7 +212,7 @@ def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin
                       seed: Optional[int] = None, indices: Optional[Sequence[int]] = None, stats: Optional[dict] = None,
                       max_slot_steps: int = 1 << 20, max_launch_bytes: int = 12 << 30, params_out: Optional[list] = None,
                       speaker_ids: Optional[Sequence[int]] = None,
-                      sink: Optional[Callable[[int, torch.Tensor], None]] = None) -> List[Optional[torch.Tensor]]:
+                      sink: Optional[Callable[[int, torch.Tensor], None]] = None, as_index: bool = False) -> List[Optional[torch.Tensor]]:
     """The waveforms (network outputs ``(C, T_i)`` on the model's device, one per mel of ``mels[i] for i in indices``) of a job run as
     PACKED SLOTS on this process's GPU.  ``model``: an ``EngineHost`` WaveNet on the device that the ring kernel covers (otherwise
     NotImplementedError: the caller falls back to padded groups).  ``slots``: rows of a launch (default ``packed_group_size(model)``);
@@ -222,6 +222,9 @@ def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin
     ``params_out``: a list that receives, per utterance, the head outputs ``(O, T_i)`` the sampler was handed at every step (parity tests).
     ``sink(i, y)``: called with utterance ``i`` (index into ``mels``) and its ``(C, T_i)`` output as soon as its launch is done, INSTEAD
     of keeping the output (the returned list then holds None): a long job keeps only one launch's buffers on the device.
+    ``as_index`` (one-hot models): the outputs are the sampled CLASSES, ``(1, T_i)`` float32, instead of ``(C, T_i)`` one-hot vectors --
+    the launch then carries 4 bytes of output per slot-step instead of 4 C (1 KB for a 256-way model: a job of 100 utterances needed two
+    launches of half-empty slots under the byte bound), and ``synthesis.postprocess`` takes them as they are.
     One launch is bounded by ``max_slot_steps`` steps per slot AND by ``max_launch_bytes`` of resident per-step buffers -- the slots'
     conditioning (``cin`` floats per step), the output (``C`` floats per step: 1 KB for a 256-way one-hot model) and the maps; a longer
     job runs as several launches.  An utterance's waveform does not depend on any of this: its conditioning is upsampled on its own
@@ -248,7 +251,8 @@ def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
     eng = model._get_engine()
     cin = int(mels[idx[0]].shape[0])
-    c_out = 1 if eng.cfg.scalar_input else int(eng.cfg.out_channels)
+    as_index = bool(as_index) and not eng.cfg.scalar_input
+    c_out = 1 if (eng.cfg.scalar_input or as_index) else int(eng.cfg.out_channels)
     step_bytes = 4 * (cin + c_out + 2 + (1 if has_spk else 0) + (int(eng.cfg.out_channels) if params_out is not None else 0))
     steps_cap = max(hop_size, min(int(max_slot_steps), int(max_launch_bytes) // (n_slots * step_bytes)))
     lengths_all = [int(mels[i].shape[-1]) * hop_size for i in idx]
@@ -271,7 +275,7 @@ def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin
     agg = dict(slots=0, slot_steps=0, true_samples=0, padded_samples=0, utterances_per_slot=[], launches=[], step_bytes=step_bytes)
     for members in launches:
         out_m, st_m, par_m = _packed_launch(model, mels, [idx[k] for k in members], hop_size, cin_pad, n_slots, seed,
-                                            want_params=params_out is not None, speaker_ids=speaker_ids)
+                                            want_params=params_out is not None, speaker_ids=speaker_ids, as_index=as_index)
         for j, (k, y) in enumerate(zip(members, out_m)):
             if sink is not None:
                 sink(idx[k], y)
@@ -310,7 +314,7 @@ def upsample_each(eng, mels: Sequence[torch.Tensor], ids: Sequence[int], cin_pad
                 yield k, cu[row]
 
 
-def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, want_params=False, speaker_ids=None):
+def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, want_params=False, speaker_ids=None, as_index=False):
     """One launch of packed slots over the utterances ``ids`` (indices into ``mels``, which are also their ids in the job).
     Returns views into the launch's output buffers (the caller copies or consumes them before the next launch)."""
     eng = model._get_engine()
@@ -345,8 +349,11 @@ def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, want_para
     g_rows = None
     if seg_gid is not None:                     # one bias row per speaker of the embedding table (tiny: n_speakers x L x G floats)
         g_rows = torch.arange(int(model.embed_speakers.weight.shape[0]), dtype=torch.int64, device=dev)
-    out, params, _ = eng.generate(B=n, T=T, c_up=c_slot, seed=seed, seg_start=seg_start, seg_uid=seg_uid, seg_gid=seg_gid, g_ids=g_rows,
-                                  kernel=0, want_params=want_params)
+    out, params, index = eng.generate(B=n, T=T, c_up=c_slot, seed=seed, seg_start=seg_start, seg_uid=seg_uid, seg_gid=seg_gid, g_ids=g_rows,
+                                      kernel=0, want_params=want_params, want_index=as_index, want_out=not as_index)
+    if as_index:                                # the classes as a (n, 1, T) float tensor: what the post-chain takes with C = 1
+        out = index.to(torch.float32).unsqueeze(1)
+        del index
     st = dict(slots=n, slot_steps=T, true_samples=sum(lengths), padded_samples=n * T, utterances_per_slot=[len(b) for b in bins])
     res, par = [], []
     for k in range(len(ids)):
