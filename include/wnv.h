@@ -159,7 +159,8 @@ typedef struct wnv_generate_args {
     int32_t quantize;          /* categorical only: sample a one-hot (wavenet.py:333-335)                */
     float* out;                /* device (B, C, T): C = 1 scalar samples | out_channels one-hot/probs;   */
                                /*   NULL allowed for a one-hot model with quantize = 1 and index_out     */
-                               /*   given (ABI 5): the sampled classes only                              */
+                               /*   given, in a packed-slot launch or with kernel = 1 (ABI 5): the       */
+                               /*   sampled classes only                                                  */
     float* params_out;         /* optional device (B, out_channels, T): head output before sampling      */
     int32_t* index_out;        /* optional device (B, T): sampled class (categorical + quantize)         */
     int32_t kernel;            /* 0 = auto, 1 = generic single-workgroup kernel, 2 = pipelined ring,     */

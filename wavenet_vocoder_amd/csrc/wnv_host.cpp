@@ -688,8 +688,8 @@ extern "C" wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* a) {
     if (a->B <= 0 || a->T <= 0 || a->T > 0x7fffffffLL) return fail(WNV_ERR_INVALID_ARG, "B and T must be positive (T < 2^31)");
     // (out may be NULL for a one-hot model that samples classes: the caller then takes index_out only -- a (B, out_channels, T) one-hot
     //  output is 1 KB per sample for a 256-way model, index_out 4 bytes)
-    if (!a->out && !(a->index_out && !c.scalar_input && a->quantize))
-        return fail(WNV_ERR_INVALID_ARG, "out is NULL (allowed only for a one-hot model with quantize = 1 and index_out given)");
+    if (!a->out && !(a->index_out && !c.scalar_input && a->quantize && (a->seg_start || a->kernel == 1)))
+        return fail(WNV_ERR_INVALID_ARG, "out is NULL (allowed only for a one-hot model with quantize = 1 and index_out given, in a packed-slot launch or on the generic kernel)");
     if (m.cin > 0 && !a->c_up) return fail(WNV_ERR_INVALID_ARG, "model has local conditioning but c_up is NULL");
     if (m.cin == 0 && a->c_up) return fail(WNV_ERR_INVALID_ARG, "c_up given but the model has no local conditioning");
     if (m.gin > 0 && !a->g && !a->g_ids) return fail(WNV_ERR_INVALID_ARG, "model has global conditioning but neither g nor g_ids is given");

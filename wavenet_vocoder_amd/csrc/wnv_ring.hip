@@ -2251,7 +2251,9 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
                         WNV_TS(0);
                     }
                     if (tid == 0) {
-                        if (p.out) p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;  // out is pre-zeroed by the host (NULL: classes only, index_out)
+                        // out is pre-zeroed by the host.  (NULL = classes only, index_out: a PACKED-slot launch may ask for that -- a compile-time
+                        //  condition elsewhere: the run-time test alone moved the one-hot instantiations' code, cfg1 B = 8 444 -> 436 kSamples/s)
+                        if (!PACKED || p.out) p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;
                         if (p.index_out) p.index_out[(size_t)b * p.T + t] = idx;
                     }
                 } else if (wave == 0) {

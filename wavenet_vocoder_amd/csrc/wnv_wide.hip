@@ -948,7 +948,7 @@ __device__ void run_wide_head_b(const WideParams& p, bool fast_first, int part, 
                 const int idx = sample_categorical(O, s.obuf, s.nz, p.softmax, p.quantize, lane);
                 if (p.quantize) {
                     if (lane == 0) {
-                        if (p.out) p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;                    // out is pre-zeroed by the host (NULL: classes only)
+                        p.out[((size_t)b * O + idx) * p.T + t] = 1.0f;                               // out is pre-zeroed by the host
                         if (p.index_out) p.index_out[(size_t)b * p.T + t] = idx;
                         s.ints[1] = idx;
                     }

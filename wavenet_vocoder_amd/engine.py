@@ -263,8 +263,9 @@ class Engine:
         dev = self.device
         cfg = self.cfg
         C_out = 1 if cfg.scalar_input else cfg.out_channels
-        if not want_out and (cfg.scalar_input or not quantize or not want_index):
-            raise ValueError("want_out=False is for one-hot models that sample classes (quantize) and return them (want_index)")
+        if not want_out and (cfg.scalar_input or not quantize or not want_index or not (seg_start is not None or kernel == 1)):
+            raise ValueError("want_out=False is for one-hot models that sample classes (quantize) and return them (want_index), in a "
+                             "packed-slot launch or on the generic kernel (include/wnv.h)")
         out = torch.empty(B, C_out, T, device=dev, dtype=torch.float32) if want_out else None      # (one-hot output: 4 out_channels bytes per sample)
         params = torch.empty(B, cfg.out_channels, T, device=dev, dtype=torch.float32) if want_params else None
         index = torch.empty(B, T, device=dev, dtype=torch.int32) if want_index else None
