@@ -602,6 +602,22 @@ __device__ __forceinline__ float dot16l(const float4* w, const float (&x)[16]) {
     a0 += a1;
     return a0.x + a0.y;
 }
+// dot16l for a row image that STREAMS from the L2 every step (K = 512: the skip passes that fit neither LDS nor registers): non-temporal
+// loads (experiment build -DWNV_STREAM_NT=1: eight rings stream 3 MB each per step through 4-MB L2s that also hold every mailbox)
+#ifndef WNV_STREAM_NT
+#define WNV_STREAM_NT 0
+#endif
+__device__ __forceinline__ float dot16s(const float4* w, const float (&x)[16]) {
+    f2 a0 = f2{0.f, 0.f}, a1 = f2{0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const float4 v = WNV_STREAM_NT ? __builtin_nontemporal_load(w + (size_t)c * RT) : w[(size_t)c * RT];
+        a0 = __builtin_elementwise_fma(f2{v.x, v.y}, f2{x[4 * c], x[4 * c + 1]}, a0);
+        a1 = __builtin_elementwise_fma(f2{v.z, v.w}, f2{x[4 * c + 2], x[4 * c + 3]}, a1);
+    }
+    a0 += a1;
+    return a0.x + a0.y;
+}
 // one matrix row's 16-float K-slice: 4 chunks of 16 B, image layout [chunk][512 threads][4]
 __device__ __forceinline__ void load_image8(const float* img, int tid, f2 (&w)[8]) {
     const float4* src = reinterpret_cast<const float4*>(img);
@@ -1305,7 +1321,7 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
                     const unsigned long long sb = reinterpret_cast<unsigned long long>(wsk_g + (size_t)(8 * pp) * RT);
                     const float4* ub = reinterpret_cast<const float4*>(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(sb >> 32)) << 32) |
                                                                        (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sb));
-                    m0 = dot16l(ub + tid, xu); m1 = dot16l(ub + (size_t)4 * RT + tid, xu);
+                    m0 = dot16s(ub + tid, xu); m1 = dot16s(ub + (size_t)4 * RT + tid, xu);
                 }
                 return quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + (pp == 0 ? bs_r : s.bsk[RC * pp + ch]);
             };
