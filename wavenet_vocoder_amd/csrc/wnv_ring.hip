@@ -611,7 +611,14 @@ __device__ __forceinline__ float dot16s(const float4* w, const float (&x)[16]) {
     f2 a0 = f2{0.f, 0.f}, a1 = f2{0.f, 0.f};
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const float4 v = WNV_STREAM_NT ? __builtin_nontemporal_load(w + (size_t)c * RT) : w[(size_t)c * RT];
+        typedef float f4n __attribute__((ext_vector_type(4)));
+        float4 v;
+        if (WNV_STREAM_NT) {
+            const f4n t = __builtin_nontemporal_load(reinterpret_cast<const f4n*>(w + (size_t)c * RT));
+            v = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            v = w[(size_t)c * RT];
+        }
         a0 = __builtin_elementwise_fma(f2{v.x, v.y}, f2{x[4 * c], x[4 * c + 1]}, a0);
         a1 = __builtin_elementwise_fma(f2{v.z, v.w}, f2{x[4 * c + 2], x[4 * c + 3]}, a1);
     }
