@@ -700,6 +700,10 @@ __device__ __forceinline__ size_t pre_rec(const RingParams& p, int b, int l, int
 // pre_l[t+1] back the same way; both trips have a whole step of slack.  The workgroup also owns the history rings.
 constexpr int KR_MAX = 32;         // K rows per lane slice held in VGPRs (32 float4 = 128 registers)
 constexpr int KL_MAX = 16;         // further K rows per wave held in LDS
+constexpr int KR_PACKED_SPEC = 28; // ... in VGPRs in the packed-slot instantiations that keep the speculative look (run_tap)
+#ifndef WNV_PACKED_SPEC
+#define WNV_PACKED_SPEC 0          // experiment (round 5): the speculative look in the packed tap instantiations, four rows moved to LDS -- still 2-4 spilled registers
+#endif
 constexpr int TB = 8;              // utterances per pass (one polling wave each; their latencies overlap)
 struct TapLds {
     float* xin;      // [2][TB][8 * kper] mat-vec inputs (two buffers: the next pass's gather lands in the other one): tap rows then conditioning row, zero padded
@@ -759,9 +763,12 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         const float4 w = *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + ob);
         return odd ? make_float4(w.z, w.w, w.x, w.y) : w;
     };
-    float4 wreg[KR_MAX];                                            // resident rows (registers), then LDS rows, then whatever streams
+    // (packed slots WITH the speculative look at the next pass's record: four rows less in registers -- they live in LDS --, which is what
+    //  the look's four registers and the packed masks need: with 32 rows that combination spilled 6-8 registers; the host sets kreg_rows)
+    constexpr int KR = (PACKED && SPEC) ? KR_PACKED_SPEC : KR_MAX;
+    float4 wreg[KR];                                                // resident rows (registers), then LDS rows, then whatever streams
 #pragma unroll
-    for (int r = 0; r < KR_MAX; ++r) wreg[r] = r < p.kreg_rows ? wload(k0 + r) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < KR; ++r) wreg[r] = r < p.kreg_rows ? wload(k0 + r) : make_float4(0.f, 0.f, 0.f, 0.f);
     for (int r = 0; r < p.klds_rows; ++r) s.wl[((size_t)wave * p.klds_rows + r) * 64 + lane] = wload(k0 + p.kreg_rows + r);
     const int uq = ks >> 1, uqm = 3 - uq;                            // (7 - ks) >> 1 = 3 - (ks >> 1)
     const int ug[4] = {uq, uq ^ 1, uqm, uqm ^ 1};
@@ -929,7 +936,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
             //  innermost the compiler alternated two and every v_pk_fma_f32 waited for the one before the last: 6.8 clocks per
             //  instruction instead of 4.7, profiles/r04_tap_pass_timeline.txt; all four at once need 16 input registers: spills)
 #pragma unroll
-            for (int r4 = 0; r4 < KR_MAX / 4; ++r4) {
+            for (int r4 = 0; r4 < KR / 4; ++r4) {
 #pragma unroll
                 for (int gp = 0; gp < 4; gp += 2) {                      // two utterances at a time: four independent accumulators in a row
                     const float4 xa = *reinterpret_cast<const float4*>(xg[gp] + 4 * r4), xc = *reinterpret_cast<const float4*>(xg[gp + 1] + 4 * r4);
@@ -2332,14 +2339,14 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
     const int free_slots = (p.rstride - p.n_rings) * P;
     if ((int)blockIdx.x >= p.ring_blocks) {
         const int k = free_slots + (int)blockIdx.x - p.ring_blocks;
-        run_tap<MODE != 2 && NK != 2, MODE == 2>(p, k % p.L, k / p.L, smem);
+        run_tap<(MODE != 2 || WNV_PACKED_SPEC != 0) && NK != 2, MODE == 2>(p, k % p.L, k / p.L, smem);
         return;
     }
     const int ring = blockIdx.x % p.rstride;
     const int pos = blockIdx.x / p.rstride;
     if (ring >= p.n_rings) {
         const int k = pos * (p.rstride - p.n_rings) + (ring - p.n_rings);
-        if (k < p.tap_parts * p.L) run_tap<MODE != 2 && NK != 2, MODE == 2>(p, k % p.L, k / p.L, smem);
+        if (k < p.tap_parts * p.L) run_tap<(MODE != 2 || WNV_PACKED_SPEC != 0) && NK != 2, MODE == 2>(p, k % p.L, k / p.L, smem);
         return;
     }
     if (L0 && pos == 0) return;                   // layer 0 is evaluated by the head (run_head)
@@ -2950,7 +2957,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     // LDS: the stage carve is the larger one
     // tap workgroups: K rows per wave (a multiple of 4), first in VGPRs, then in LDS, the remainder streams from L2
     p.kper = (((st->kpre + RW - 1) / RW) + 3) & ~3;
-    p.kreg_rows = std::min(p.kper, KR_MAX);
+    p.kreg_rows = std::min(p.kper, (ga.seg_start && NK != 2 && WNV_PACKED_SPEC) ? KR_PACKED_SPEC : KR_MAX);      // (= run_tap's KR for the instantiation launched below)
     p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);                      // multiples of 4 (kper is one)
     while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 158 * 1024) p.klds_rows -= 4;
     p.ring_blocks = split ? 8 * max_slots : rstride * P;
