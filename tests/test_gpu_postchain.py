@@ -1,5 +1,7 @@
 """-m gpu: the device post-chain (wnv_postprocess) against the CPU oracle, and batch_wavegen end to
 end against the oracle's incremental_forward + post-chain."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -148,3 +150,43 @@ def test_evaluate_directory_loop_packed_slots(tmp_path, capsys):
     part = [wavfile.read(p)[1] for p in E.synthesize_dir(m, str(tmp_path), str(tmp_path / "out_part"), h, num_utterances=3, packed=True)]
     for i in range(3):
         assert np.array_equal(part[i], outs[0][i]), "an utterance's waveform depends on its own conditioning, id and the seed only"
+
+
+@pytest.mark.parametrize("name", ["cfg1_mulaw256", "cfg4_mol_multispeaker"])
+def test_evaluate_packed_directory_loop_of_one_hot_and_speaker_models(name, tmp_path, capsys):
+    """Round 5: the directory loop as packed slots for a mu-law model (the launch carries the sampled CLASSES, the post-chain decodes them:
+    synthesize_packed(as_index=True) + sink) and for a speaker-conditioned model (speaker ids from train.txt, one bias row per speaker).
+    The files equal what sharding.synthesize_packed + synthesis.postprocess give for the same seed by the plain route."""
+    from scipy.io import wavfile
+    from tests._configs import CONFIGS, build
+    from wavenet_vocoder_amd import evaluate as E, sharding
+    kw = CONFIGS[name]
+    rng = np.random.default_rng(2)
+    frames = [6, 3, 8, 4, 5, 3]
+    spk = [3, 0, 6, 6, 1, 2]
+    multi = kw.get("gin_channels", -1) > 0
+    lines = []
+    for i, f in enumerate(frames):
+        np.save(tmp_path / f"utt{i:02d}-feats.npy", rng.standard_normal((f, 80)).astype(np.float32))
+        lines.append(f"utt{i:02d}-wave.npy|utt{i:02d}-feats.npy|{f}|text" + (f"|{spk[i]}" if multi else ""))
+    (tmp_path / "train.txt").write_text("\n".join(lines) + "\n")
+    m = build(name).to("cuda")
+    onehot = not kw.get("scalar_input", False)
+    h = hp(cin_channels=80, cin_pad=2, hop_size=256, batch_size=None, sample_rate=24000,
+           **({"input_type": "mulaw-quantize", "quantize_channels": 256} if onehot else {}))
+    torch.manual_seed(77)
+    paths = E.synthesize_dir(m, str(tmp_path), str(tmp_path / "out"), h, packed=True)
+    assert "falling back" not in capsys.readouterr().out
+    got = [wavfile.read(p)[1] for p in paths]
+    if multi:
+        assert all(os.path.basename(p).startswith(f"speaker{s}_") for p, s in zip(paths, spk))
+    # the plain route with the same seed: one-hot / scalar network outputs, then the post-chain per utterance
+    torch.manual_seed(77)
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    mels = [torch.from_numpy(np.load(tmp_path / f"utt{i:02d}-feats.npy").T.copy()) for i in range(len(frames))]
+    outs = sharding.synthesize_packed(m, mels, hop_size=256, cin_pad=2, seed=seed, speaker_ids=spk if multi else None)
+    for i, (w, y) in enumerate(zip(got, outs)):
+        want = synthesis.postprocess(y.unsqueeze(0), h, want_int16=True)[1][0].cpu().numpy()
+        assert w.dtype == np.int16 and len(w) == frames[i] * 256 and w.std() > 0
+        assert np.array_equal(w, want), f"utterance {i}"
+    m.to("cpu")
