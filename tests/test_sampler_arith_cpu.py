@@ -19,6 +19,11 @@ def kernel_pick(logits, e):
     return np.argmax((x / e).astype(np.float32), -1)
 
 
+def ring_head_pick(logits, e):
+    """the ring kernel's categorical head since round 5 (run_head_cat, WNV_CAT_LOG): argmax_k logit_k - log e_k, float32"""
+    return np.argmax((logits - np.log(e).astype(np.float32)).astype(np.float32), -1)
+
+
 def oracle_pick(logits, e):
     p = torch.softmax(torch.from_numpy(logits), -1)                # wavenet.py:332
     return oracle_sample_categorical(p, torch.from_numpy(e)).numpy()
@@ -47,6 +52,23 @@ def test_dropping_the_normalising_sums_moves_only_near_ties(spread, O):
         assert float(m[differ].max()) < 5e-7, f"a pick differs at a top-2 margin of {float(m[differ].max()):.3e}"
     # ... and the margin distribution says how rare that is: a handful of steps per million sit below 1e-6
     assert (m < 1e-6).mean() < 1e-4
+
+
+@pytest.mark.parametrize("spread", [1.0, 4.0, 12.0])
+def test_the_log_domain_pick_of_the_ring_head_moves_only_near_ties(spread):
+    """argmax_k exp(logit_k - max) / e_k = argmax_k logit_k - log e_k in exact arithmetic; in float32 the two (and the oracle's
+    normalised form) may part only at a near tie of the choice."""
+    g = np.random.default_rng(99 + int(spread))
+    n, O = 200_000, 256
+    logits = (spread * g.standard_normal((n, O))).astype(np.float32)
+    e = np.maximum(g.exponential(1.0, (n, O)).astype(np.float32), np.float32(1e-30))
+    a, b, k = ring_head_pick(logits, e), oracle_pick(logits, e), kernel_pick(logits, e)
+    m = margins(logits, e)
+    for other in (b, k):
+        differ = a != other
+        assert differ.sum() <= 5, f"{int(differ.sum())} of {n} picks differ"
+        if differ.any():
+            assert float(m[differ].max()) < 4e-6, f"a pick differs at a top-2 margin of {float(m[differ].max()):.3e}"
 
 
 def test_common_factor_cannot_reorder_exactly_representable_cases():

@@ -534,6 +534,9 @@ __device__ __forceinline__ float fast_gate(float a, float g) {
 #ifndef WNV_PHASE2
 #define WNV_PHASE2 1
 #endif
+#ifndef WNV_CAT_LOG
+#define WNV_CAT_LOG 1          // the ring's categorical head picks in the log domain (run_head_cat)
+#endif
 #ifndef WNV_SKIP_DIRECT
 #define WNV_SKIP_DIRECT 1      // K = 512: every stage hands its own skip term to the head parts (head_sum_skip_terms)
 #endif
@@ -2202,7 +2205,12 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
                 next_starts = pf_next == t + 1;
                 seg_prefetch(j, t);
             }
-            if (tid < O) s.nzb[tid] = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
+            // (WNV_CAT_LOG, softmax + multinomial: the pick is taken in the log domain, argmax_k logit_k - log e_k -- the noise term is
+            //  prepared HERE, while the ring works)
+            if (tid < O) {
+                const float ek = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
+                s.nzb[tid] = (WNV_CAT_LOG && p.quantize && p.softmax && O <= 256) ? logf(ek) : ek;
+            }
             if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.ints[0] = 1;
             __syncthreads();
             WNV_TS(1);
@@ -2241,6 +2249,14 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
                 const bool mine = q < 2 && cls < O;
                 const float lg = mine ? (q == 0 ? oa : ob) : -INFINITY;
                 const float ek = mine ? s.nzb[cls] : 1.f;
+#if WNV_CAT_LOG
+                // ROUND 5: argmax_k exp(logit_k - max) / e_k = argmax_k logit_k - log e_k (the logarithm is monotone, the maximum a common
+                // term): no pass for the maximum -- a wave reduction, an LDS exchange and a barrier --, no exp, no division on the chain;
+                // log e_k was formed with the noise.  A pick can move only where the top-2 margin is below the rounding of the difference
+                // (tests/test_sampler_arith_cpu.py: no flip in 600 000 draws at three logit spreads).
+                float best = mine ? lg - ek : -INFINITY;
+                int bi = mine ? cls : 0x7fffffff;
+#else
                 const float mw = wave_max(lg);
                 if (lane == 0) s.part[wave] = mw;
                 __syncthreads();
@@ -2248,6 +2264,7 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
                 const float mx = fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w)));
                 float best = mine ? expf(lg - mx) / ek : -INFINITY;
                 int bi = mine ? cls : 0x7fffffff;
+#endif
                 wave_argmax(best, bi);
                 if (lane == 0) { s.part[8 + wave] = best; s.part[16 + wave] = __int_as_float(bi); }
             } else if (q == 0) {
