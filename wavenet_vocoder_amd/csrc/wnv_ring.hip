@@ -535,7 +535,7 @@ __device__ __forceinline__ float fast_gate(float a, float g) {
 #define WNV_PHASE2 1
 #endif
 #ifndef WNV_CAT_LOG
-#define WNV_CAT_LOG 1          // the ring's categorical head picks in the log domain (run_head_cat)
+#define WNV_CAT_LOG 1          // the ring's categorical head picks in the log domain in the throughput instantiation (run_head_cat, LOGPICK)
 #endif
 #ifndef WNV_SKIP_DIRECT
 #define WNV_SKIP_DIRECT 1      // K = 512: every stage hands its own skip term to the head parts (head_sum_skip_terms)
@@ -2128,7 +2128,12 @@ __device__ __forceinline__ CatLds carve_cat(float* smem, int NK) {
 }
 __host__ __device__ constexpr size_t cat_lds_floats(int NK) { return (size_t)(4 * NK + 4) * QS + 3 * 256 + 4 * RC + 16 + (size_t)256 * RC; }
 
-template <int NK, bool PACKED>
+// (LOGPICK: the softmax + multinomial pick in the log domain -- see the fastcat block.  A compile-time switch, on in the THROUGHPUT
+//  instantiation only (MODE 1: more than four utterances per ring, where the head's occupancy per utterance counts): same-box A/B of the
+//  form everywhere, round 5: cfg1 at 48 utterances 2 381 -> 2 463 kSamples/s, the 30-layer preset at 8 379 -> 386 -- but cfg1 at 1 / 8
+//  utterances 56.2 -> 55.1 / 444.5 -> 436.2: the shorter head moves the register allocation of the NK = 2 stage loop, as every change in a
+//  role of these one-function kernels can; the MODE 0 and packed instantiations keep the code they had.)
+template <int NK, bool PACKED, bool LOGPICK>
 __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p, int ring, float* smem) {
     WNV_TS_DECL;
     const CatLds s = carve_cat(smem, NK);
@@ -2207,9 +2212,13 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
             }
             // (WNV_CAT_LOG, softmax + multinomial: the pick is taken in the log domain, argmax_k logit_k - log e_k -- the noise term is
             //  prepared HERE, while the ring works)
-            if (tid < O) {
-                const float ek = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
-                s.nzb[tid] = (WNV_CAT_LOG && p.quantize && p.softmax && O <= 256) ? logf(ek) : ek;
+            if constexpr (LOGPICK) {
+                if (tid < O) {
+                    const float ek = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
+                    s.nzb[tid] = (p.quantize && p.softmax && O <= 256) ? logf(ek) : ek;
+                }
+            } else {
+                if (tid < O) s.nzb[tid] = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
             }
             if (!head_recv_skip<NK>(p, b, tag, s.vs, tid, lane, wave)) s.ints[0] = 1;
             __syncthreads();
@@ -2249,22 +2258,24 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
                 const bool mine = q < 2 && cls < O;
                 const float lg = mine ? (q == 0 ? oa : ob) : -INFINITY;
                 const float ek = mine ? s.nzb[cls] : 1.f;
-#if WNV_CAT_LOG
-                // ROUND 5: argmax_k exp(logit_k - max) / e_k = argmax_k logit_k - log e_k (the logarithm is monotone, the maximum a common
-                // term): no pass for the maximum -- a wave reduction, an LDS exchange and a barrier --, no exp, no division on the chain;
-                // log e_k was formed with the noise.  A pick can move only where the top-2 margin is below the rounding of the difference
-                // (tests/test_sampler_arith_cpu.py: no flip in 600 000 draws at three logit spreads).
-                float best = mine ? lg - ek : -INFINITY;
-                int bi = mine ? cls : 0x7fffffff;
-#else
-                const float mw = wave_max(lg);
-                if (lane == 0) s.part[wave] = mw;
-                __syncthreads();
-                const float4 ma = *reinterpret_cast<const float4*>(s.part), mb = *reinterpret_cast<const float4*>(s.part + 4);
-                const float mx = fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w)));
-                float best = mine ? expf(lg - mx) / ek : -INFINITY;
-                int bi = mine ? cls : 0x7fffffff;
-#endif
+                float best;
+                int bi;
+                if constexpr (LOGPICK) {
+                    // ROUND 5: argmax_k exp(logit_k - max) / e_k = argmax_k logit_k - log e_k (the logarithm is monotone, the maximum a
+                    // common term): no pass for the maximum -- a wave reduction, an LDS exchange and a barrier --, no exp, no division on
+                    // the chain; log e_k was formed with the noise.  A pick can move only where the top-2 margin is below the rounding of
+                    // the difference (tests/test_sampler_arith_cpu.py: no flip in 600 000 draws at three logit spreads).
+                    best = mine ? lg - ek : -INFINITY;
+                    bi = mine ? cls : 0x7fffffff;
+                } else {
+                    const float mw = wave_max(lg);
+                    if (lane == 0) s.part[wave] = mw;
+                    __syncthreads();
+                    const float4 ma = *reinterpret_cast<const float4*>(s.part), mb = *reinterpret_cast<const float4*>(s.part + 4);
+                    const float mx = fmaxf(fmaxf(fmaxf(ma.x, ma.y), fmaxf(ma.z, ma.w)), fmaxf(fmaxf(mb.x, mb.y), fmaxf(mb.z, mb.w)));
+                    best = mine ? expf(lg - mx) / ek : -INFINITY;
+                    bi = mine ? cls : 0x7fffffff;
+                }
                 wave_argmax(best, bi);
                 if (lane == 0) { s.part[8 + wave] = best; s.part[16 + wave] = __int_as_float(bi); }
             } else if (q == 0) {
@@ -2373,7 +2384,7 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
         // (L0 instantiations serve scalar-input models only -- the categorical head is not compiled into them: every role of a kernel is
         //  inlined into ONE function, and a change in that head moved the register allocation of the stage loop -- 2 % of the headline)
         if constexpr (NK <= 2 && !L0) {         // one-hot models with 512 skip channels stay on the generic kernel (why_not)
-            if (pos == p.S) run_head_cat<NK, MODE == 2>(p, ring, smem);
+            if (pos == p.S) run_head_cat<NK, MODE == 2, MODE == 1 && WNV_CAT_LOG != 0>(p, ring, smem);
             else run_head_part<NK, 2>(p, ring, pos - p.S, smem);
         }
     } else {
