@@ -24,6 +24,9 @@
  *     process the library lets them take turns per device: launches of different handles are ordered on the
  *     device (an event behind the previous one) and their host side runs under a per-device mutex.  Other
  *     processes on the same GPU are what the WNV_ERR_TIMEOUT fallback of kernel = 0 is for.
+ *   - the library reads NO environment variable (ABI 5): what it does is decided by its arguments alone.  The
+ *     measurement knobs of the experiment scripts and the two test / bench hooks live in another build of the
+ *     same sources, libwnv_test.so (include/wnv_test.h).
  */
 #ifndef WNV_H_
 #define WNV_H_
