@@ -537,6 +537,9 @@ __device__ __forceinline__ float fast_gate(float a, float g) {
 #ifndef WNV_CAT_LOG
 #define WNV_CAT_LOG 1          // the ring's categorical head picks in the log domain in the throughput instantiation (run_head_cat, LOGPICK)
 #endif
+#ifndef WNV_CAT_LOG_PACKED
+#define WNV_CAT_LOG_PACKED 0   // experiment: ... and in the packed-slot instantiation
+#endif
 #ifndef WNV_SKIP_DIRECT
 #define WNV_SKIP_DIRECT 1      // K = 512: every stage hands its own skip term to the head parts (head_sum_skip_terms)
 #endif
@@ -2384,7 +2387,7 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
         // (L0 instantiations serve scalar-input models only -- the categorical head is not compiled into them: every role of a kernel is
         //  inlined into ONE function, and a change in that head moved the register allocation of the stage loop -- 2 % of the headline)
         if constexpr (NK <= 2 && !L0) {         // one-hot models with 512 skip channels stay on the generic kernel (why_not)
-            if (pos == p.S) run_head_cat<NK, MODE == 2, MODE == 1 && WNV_CAT_LOG != 0>(p, ring, smem);
+            if (pos == p.S) run_head_cat<NK, MODE == 2, (MODE == 1 || (MODE == 2 && WNV_CAT_LOG_PACKED != 0)) && WNV_CAT_LOG != 0>(p, ring, smem);
             else run_head_part<NK, 2>(p, ring, pos - p.S, smem);
         }
     } else {
