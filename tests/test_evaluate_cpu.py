@@ -92,3 +92,20 @@ def test_directory_loop_lengths_and_padding(tmp_path):
     # groups are packed longest-first in pairs and padded to their longest member + 2*cin_pad replicate frames
     assert all(s[0][0] <= 2 for s in seen) and sorted(i for s in seen for i in s[1]) == [0, 1, 2, 3, 4]
     assert seen[0][0][2] == max(frames) + 4 + 4
+
+
+def test_packed_directory_loop_keeps_the_references_sanity_check(tmp_path):
+    """train.sanity_check (train.py:72-87) guards batch_wavegen (synthesis.py:43-44); the packed path does not go through batch_wavegen, so
+    synthesize_dir applies it itself: a speaker-embedding model without speaker ids (or the other way round) is the reference's RuntimeError,
+    raised before anything touches a device."""
+    import numpy as np
+    from tests._configs import build
+    from wavenet_vocoder_amd import evaluate as E, synthesis
+    for i in range(2):
+        np.save(tmp_path / f"u{i}-feats.npy", np.zeros((3, 80), np.float32))
+    h = synthesis.default_hparams(cin_channels=80, cin_pad=2, hop_size=256, batch_size=None, sample_rate=24000)
+    with pytest.raises(RuntimeError, match="expects speaker embedding"):
+        E.synthesize_dir(build("cfg4_mol_multispeaker"), str(tmp_path), str(tmp_path / "o"), h, packed=True)
+    (tmp_path / "train.txt").write_text("a|u0-feats.npy|3|t|1\nb|u1-feats.npy|3|t|2\n")
+    with pytest.raises(RuntimeError, match="expects no speaker embedding"):
+        E.synthesize_dir(build("cfg2_mol"), str(tmp_path), str(tmp_path / "o"), h, packed=True)

@@ -154,6 +154,10 @@ def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterance
                   and len(mels) > sharding.packed_group_size(model) * world
                   and sharding.packed_unsupported_reason(model) is None)
     local = None
+    if packed and model is not None:
+        # the reference's sanity_check (train.py:72-87, called by batch_wavegen, synthesis.py:43-44), for the path that does not go
+        # through batch_wavegen: a speaker-embedding model needs every utterance's speaker, any other model must not get one
+        synthesis.sanity_check(model, mels[0], spk if has_spk else ([u.speaker_id for u in utts][0] if utts[0].speaker_id is not None else None))
     if packed:
         try:
             local = _packed_local(model, mels, hparams, mine, spk)
