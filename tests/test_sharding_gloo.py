@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from wavenet_vocoder_amd.sharding import (THROUGHPUT_GROUP, auto_group_size, broadcast_weights, lpt_assign, pack_groups,
-                                          pad_group, padding_loss, plan_slots, synthesize_sharded)
+                                          pad_group, padding_loss, plan_launches, plan_slots, synthesize_sharded)
 
 HOP, PAD = 4, 2
 
@@ -90,6 +90,35 @@ def test_slot_plan_of_packed_jobs():
     assert packed_loss < 0.10 < 0.2 < padded_loss, (packed_loss, padded_loss)
     assert [len(b) for b in plan_slots([5, 3, 9], 48)] == [1, 1, 1]                  # never more slots than utterances
     assert plan_slots([7], 4) == [[0]]
+
+
+def test_launch_plan_of_packed_jobs():
+    """sharding.plan_launches: every utterance in exactly one launch; no slot beyond the cap unless one utterance is; as few launches as the
+    total allows (+ the split a tight cap forces); the launches balanced to within the longest utterance; the same plan from the same
+    arguments (every rank of a job plans alone)."""
+    g = torch.Generator().manual_seed(11)
+    lengths = [int(x) * 256 for x in torch.randint(94, 751, (200,), generator=g)]
+    for n_slots, cap in ((48, 1 << 20), (48, 400_000), (48, 200_000), (32, 250_000), (3, 6000 * 40)):
+        plan = plan_launches(lengths, n_slots, cap)
+        assert sorted(sum(plan, [])) == list(range(200))
+        assert plan == plan_launches(list(lengths), n_slots, cap)
+        lower = -(-sum(lengths) // (n_slots * cap))
+        # (few slots under a cap of 1.25 utterances fragment: a fifth more launches than the total alone would need)
+        assert lower <= len(plan) <= lower + 1 + lower // 5, (n_slots, cap, len(plan), lower)
+        totals = [sum(lengths[k] for k in m) for m in plan]
+        assert max(totals) - min(totals) <= max(lengths) * 2, totals
+        for m in plan:
+            slots = plan_slots([lengths[k] for k in m], n_slots)
+            assert max(sum(lengths[m[k]] for k in b) for b in slots) <= cap
+    # the cap bounds packing, it does not refuse work: an utterance longer than the cap runs alone in its slot
+    plan = plan_launches([1000, 10, 10, 10], 2, 100)
+    assert sorted(sum(plan, [])) == [0, 1, 2, 3]
+    for m in plan:
+        for b in plan_slots([[1000, 10, 10, 10][k] for k in m], 2):
+            load = sum([1000, 10, 10, 10][m[k]] for k in b)
+            assert load <= 100 or len(b) == 1
+    assert plan_launches([], 48, 100) == []
+    assert plan_launches([7], 48, 1) == [[0]]
 
 
 def test_single_process_matches():

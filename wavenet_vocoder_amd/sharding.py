@@ -175,6 +175,27 @@ def plan_slots(lengths: Sequence[int], n_slots: int) -> List[List[int]]:
     return [b for b in lpt_assign(lengths, n_slots) if b]
 
 
+def plan_launches(lengths: Sequence[int], n_slots: int, steps_cap: int) -> List[List[int]]:
+    """Positions into ``lengths`` per launch of ``n_slots`` packed slots, no slot longer than ``steps_cap`` steps (an utterance that is
+    longer than the cap on its own still gets its launch: the cap bounds packing, it does not refuse work).  As few launches as the
+    bound allows, and BALANCED: the length-sorted utterances are dealt out to the launches in turn, so every launch gets the same mix of
+    lengths and the same total (round 5: filling the first launch to the cap left a short second one whose slots ran mostly empty -- 200
+    utterances: 2.00 against 2.31 MSamples/s).  A pure function of its arguments: every rank of a job plans the same launches."""
+    lengths = [int(x) for x in lengths]
+    if not lengths:
+        return []
+    n_slots, steps_cap = max(1, int(n_slots)), max(1, int(steps_cap))
+    order = sorted(range(len(lengths)), key=lambda k: (-lengths[k], k))
+    n_launch = max(1, -(-sum(lengths) // (n_slots * steps_cap)))
+    while True:
+        launches = [m for m in (order[i::n_launch] for i in range(n_launch)) if m]
+        # (a slot's sum can exceed the average: check the planned launches against the cap, split further when one does)
+        worst = max(max(sum(lengths[m[k]] for k in b) for b in plan_slots([lengths[k] for k in m], n_slots)) for m in launches)
+        if worst <= steps_cap or n_launch >= len(order):
+            return launches
+        n_launch += 1
+
+
 def packed_group_size(model) -> int:
     """Slots per launch for THIS model: where its throughput curve stops growing (profiles/r04_final_numbers.txt).  128 skip channels
     (egs/mol, egs/gaussian) and the 256-way one-hot models gain up to 48 utterances per GPU; with 512 skip channels (BASELINE
@@ -196,7 +217,9 @@ def packed_unsupported_reason(model) -> Optional[str]:
         return "the model is not on a GPU"
     if int(getattr(model, "gin_channels", -1) or -1) > 0 and getattr(model, "embed_speakers", None) is None:
         return "global conditioning without a speaker embedding (external g vectors per utterance are not packed)"
-    if getattr(model, "upsample_net", None) is None and int(getattr(model, "cin_channels", -1) or -1) > 0:
+    if int(getattr(model, "cin_channels", -1) or -1) <= 0:
+        return "no local conditioning: a packed job is a list of mel spectrograms (an unconditioned model has no utterances to pack)"
+    if getattr(model, "upsample_net", None) is None:
         return "local conditioning without an upsampling network"
     try:
         eng = model._get_engine()
@@ -256,20 +279,7 @@ def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin
     step_bytes = 4 * (cin + c_out + 2 + (1 if has_spk else 0) + (int(eng.cfg.out_channels) if params_out is not None else 0))
     steps_cap = max(hop_size, min(int(max_slot_steps), int(max_launch_bytes) // (n_slots * step_bytes)))
     lengths_all = [int(mels[i].shape[-1]) * hop_size for i in idx]
-    # launches: as few as the bound allows, and BALANCED -- the length-sorted utterances are dealt out to the launches in turn, so every
-    # launch gets the same mix of lengths and the same total (round 5: filling the first launch to the cap left a short second one whose
-    # slots ran mostly empty -- 200 utterances: 2.00 against 2.31 MSamples/s)
-    order = sorted(range(len(idx)), key=lambda k: (-lengths_all[k], k))
-    total = sum(lengths_all)
-    n_launch = max(1, -(-total // (n_slots * steps_cap)))
-    while True:
-        launches = [order[i::n_launch] for i in range(n_launch)]
-        launches = [m for m in launches if m]
-        # (a slot's sum can exceed the average: check the planned launches against the cap, split further when one does)
-        worst = max(max(sum(lengths_all[m[k]] for k in b) for b in plan_slots([lengths_all[k] for k in m], n_slots)) for m in launches)
-        if worst <= steps_cap or n_launch >= len(order):
-            break
-        n_launch += 1
+    launches = plan_launches(lengths_all, n_slots, steps_cap)
     res: List[Optional[torch.Tensor]] = [None] * len(idx)
     par: Optional[list] = None if params_out is None else [None] * len(idx)
     agg = dict(slots=0, slot_steps=0, true_samples=0, padded_samples=0, utterances_per_slot=[], launches=[], step_bytes=step_bytes)
