@@ -188,7 +188,9 @@ typedef struct wnv_generate_args {
     int32_t n_g;               /* wavenet.py:262-269): g / g_ids then have n_g rows -- one per speaker or per utterance of the job,   */
                                /* not per slot -- and seg_gid[b][t] (device (B, T)) is the row of the utterance occupying slot b at   */
                                /* step t: the hoisted bias table conv.bias + conv1x1g(g) (modules.py:146-150) has n_g rows and the    */
-                               /* tap workgroups pick the row per slot and step.  NULL / 0 otherwise.                                 */
+                               /* tap workgroups pick the row per slot and step.  NULL / 0 otherwise.  The maps live in device memory */
+                               /* and are NOT range-checked (no host copy is made): the caller guarantees 0 <= seg_gid < n_g,         */
+                               /* 0 <= seg_start[b][t] <= t, and seg_start / seg_uid constant over a segment.                         */
 } wnv_generate_args;
 
 /* The pipelined ring kernel is a persistent launch whose workgroups wait for each other; every wait is bounded and a
