@@ -538,7 +538,7 @@ __device__ __forceinline__ float fast_gate(float a, float g) {
 #define WNV_CAT_LOG 1          // the ring's categorical head picks in the log domain in the throughput instantiation (run_head_cat, LOGPICK)
 #endif
 #ifndef WNV_CAT_LOG_PACKED
-#define WNV_CAT_LOG_PACKED 0   // experiment: ... and in the packed-slot instantiation
+#define WNV_CAT_LOG_PACKED 1   // ... and in the packed-slot instantiations (there with the quotient form's treatment of e = -0.0: run_head_cat)
 #endif
 #ifndef WNV_SKIP_DIRECT
 #define WNV_SKIP_DIRECT 1      // K = 512: every stage hands its own skip term to the head parts (head_sum_skip_terms)
@@ -2215,7 +2215,16 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
             }
             // (WNV_CAT_LOG, softmax + multinomial: the pick is taken in the log domain, argmax_k logit_k - log e_k -- the noise term is
             //  prepared HERE, while the ring works)
-            if constexpr (LOGPICK) {
+            if constexpr (LOGPICK && PACKED) {
+                // (the in-kernel stream's uniform can round to exactly 1.0 -- wnv_u01, once in 2^24 draws -- and e = -log u is then -0.0: the
+                //  quotient form scores that class x / -0.0 = -inf, it cannot be picked.  The packed instantiation keeps exactly that, so that a
+                //  packed job equals the padded batch sample for sample: log e := +inf there.  Found as the one differing step of
+                //  tests/test_gpu_packed.py when this form was first tried in packed launches: utterance 12, step 24, class 144 of seed 99.)
+                if (tid < O) {
+                    const float ek = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
+                    s.nzb[tid] = (p.quantize && p.softmax && O <= 256) ? (ek > 0.f ? logf(ek) : INFINITY) : ek;
+                }
+            } else if constexpr (LOGPICK) {
                 if (tid < O) {
                     const float ek = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
                     s.nzb[tid] = (p.quantize && p.softmax && O <= 256) ? logf(ek) : ek;
