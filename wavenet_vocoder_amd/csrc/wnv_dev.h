@@ -75,7 +75,11 @@ __device__ __forceinline__ void wnv_philox(uint32_t c0, uint32_t c1, uint32_t c2
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// uniform in (0, 1): never 0, never 1
+// uniform in (0, 1]: never 0; exactly 1.0 once in 2^24 draws -- the sum below is formed in float32, where 16777215.5 rounds to 2^24 (found in
+// round 5, tests/test_philox_cpu.py).  Kind 2 then gives e = -0.0: the quotient form of the categorical pick scores that class x / -0.0 = -inf
+// (it cannot be picked; the packed log-domain pick keeps that, run_head_cat), kind 1 gives 0, kind 0 gives 1 - 1e-5.  Left as it is: the stream
+// is part of what a seed means, every kernel agrees on it, and a class missing one draw in 2^24 is far below anything a listener or a test of
+// the distribution can see.
 __device__ __forceinline__ float wnv_u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // noise value j of (utterance b, step t), same semantics as the tape (wavenet_vocoder_amd/noise.py)
