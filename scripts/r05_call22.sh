@@ -1,0 +1,7 @@
+#!/bin/bash
+# round 5, GPU call 22: the new check of the in-kernel noise mode (what bench.py times) -- every sample of a launch against the oracle's sampler applied
+# to the kernel's own head outputs and the host-restated Philox stream (tests/test_gpu_inkernel_noise.py)
+set -u
+OUT=gpurun_out/r05t
+mkdir -p $OUT
+timeout 150 python -m pytest tests/test_gpu_inkernel_noise.py -m gpu -q -s 2>&1 | tail -25 | tee $OUT/pytest.log

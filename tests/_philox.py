@@ -62,3 +62,38 @@ def categorical_pick_margins(logits, classes, seed, uid, e=None):
         score = np.where(e > 0, logits.T - np.log(np.where(e > 0, e, 1.0)), -np.inf)
     picked = score[np.arange(T), np.asarray(classes, dtype=np.int64)]
     return score.max(-1) - picked
+
+
+def tape(seed, T, B, *, scalar_input, output_distribution="Logistic", out_channels=30, b0=0):
+    """The (T, B, NZ) float32 noise tape the in-kernel stream stands for (wnv_noise_gen: "same semantics as the tape", layout of
+    wavenet_vocoder_amd/noise.py): value j of (utterance b0 + b, step t), kind by position -- Logistic: nr_mix + 1 uniforms of
+    U(1e-5, 1 - 1e-5) (kind 0); Normal: nr_mix uniforms then one N(0, 1) (kind 1: Box-Muller of the first two output words), or the
+    single N(0, 1) for 2 / 3 output channels; one-hot: out_channels draws of Exp(1) (kind 2; -0.0 where the uniform rounded to 1)."""
+    if scalar_input:
+        normal = output_distribution == "Normal"
+        nz = 1 if (normal and out_channels in (2, 3)) else out_channels // 3 + 1
+    else:
+        normal, nz = False, out_channels
+    t = np.arange(T, dtype=np.uint64)[:, None, None]
+    b = (np.arange(B, dtype=np.uint64) + np.uint64(b0))[None, :, None]
+    j = np.arange(nz, dtype=np.uint64)[None, None, :]
+    w = philox4x32_10(t & _MASK, t >> _S32, b, j, int(seed) & 0xFFFFFFFF, (int(seed) >> 32) & 0xFFFFFFFF)
+    f32 = np.float32
+
+    def u01(x):
+        return (((x >> np.uint64(8)).astype(f32) + f32(0.5)).astype(f32) * f32(1.0 / 16777216.0)).astype(f32)
+
+    u = u01(w[0])
+    if not scalar_input:
+        with np.errstate(divide="ignore"):
+            return (-np.log(u.astype(np.float64))).astype(f32)
+    # kind 0: 1e-5f + u * (1.0f - 2e-5f) is ONE fused multiply-add on the device (v_fmac_f32 0x3727c5ac + 0x3f7ffeb0 * u: checked in the
+    # ISA) -- a single rounding, emulated through float64 (the 48-bit product is exact there).  It matters: log(1 - u) near u = 1 - 1e-5
+    # turns one ulp of u into 6e-3 of the logistic's argument.
+    c = np.float64(f32(1.0) - f32(2e-5))
+    out = (u.astype(np.float64) * c + np.float64(f32(1e-5))).astype(f32)
+    if normal:
+        v = u01(w[1])
+        n = np.sqrt(-2.0 * np.log(u.astype(np.float64))) * np.cos(6.28318530717958647692 * v.astype(np.float64))
+        out[:, :, nz - 1] = n[:, :, nz - 1].astype(f32)
+    return out

@@ -72,3 +72,31 @@ def test_pick_margins_of_a_host_made_pick():
     forced = best.copy()
     forced[24] = 144
     assert np.isinf(P.categorical_pick_margins(logits, forced, 99, 12)[24])
+
+
+def test_tape_layouts_of_the_stream():
+    """_philox.tape: the (T, B, NZ) tape the in-kernel stream stands for, per output distribution (layout of wavenet_vocoder_amd/noise.py)"""
+    from wavenet_vocoder_amd.noise import noise_width
+    for kw in (dict(scalar_input=True, output_distribution="Logistic", out_channels=30),
+               dict(scalar_input=True, output_distribution="Normal", out_channels=2),
+               dict(scalar_input=True, output_distribution="Normal", out_channels=9),
+               dict(scalar_input=False, output_distribution="Logistic", out_channels=256)):
+        tp = P.tape(7, 33, 3, **kw)
+        assert tp.dtype == np.float32 and tp.shape == (33, 3, noise_width(kw["scalar_input"], kw["output_distribution"], kw["out_channels"]))
+        # a slice of a larger call: utterance b0 + b
+        assert np.array_equal(P.tape(7, 33, 1, b0=2, **kw)[:, 0], tp[:, 2])
+    mol = P.tape(7, 4096, 2, scalar_input=True, output_distribution="Logistic", out_channels=30)
+    assert 1e-5 <= float(mol.min()) and float(mol.max()) <= 1.0 - 1e-5 + 1e-7 and abs(float(mol.mean()) - 0.5) < 5e-3
+    # kind 0 is one fused multiply-add of the float32 uniform (constants as the ISA holds them: 0x3f7ffeb0, 0x3727c5ac)
+    u = P.uniform01(7, np.arange(4096, dtype=np.uint64)[:, None, None], np.arange(2, dtype=np.uint64)[None, :, None],
+                    np.arange(11, dtype=np.uint64)[None, None, :]).astype(np.float64)
+    c, a = np.float64(np.float32(1.0) - np.float32(2e-5)), np.float64(np.float32(1e-5))
+    assert np.float32(c).view(np.uint32) == 0x3F7FFEB0 and np.float32(a).view(np.uint32) == 0x3727C5AC
+    assert np.array_equal(mol, (u * c + a).astype(np.float32))
+    two_step = (np.float32(1e-5) + (u.astype(np.float32) * np.float32(c)).astype(np.float32)).astype(np.float32)
+    assert 0.05 < float((two_step != mol).mean()) < 0.6          # (the unfused form differs by an ulp in a good part of the draws)
+    gauss = P.tape(7, 8192, 2, scalar_input=True, output_distribution="Normal", out_channels=2)
+    assert abs(float(gauss.mean())) < 0.03 and abs(float(gauss.std()) - 1.0) < 0.03
+    cat = P.tape(99, 32, 13, scalar_input=False, out_channels=256)
+    assert np.array_equal(cat[:, 12], P.exp_grid(99, 12, 32, 256).astype(np.float32))
+    assert cat[24, 12, 144] == 0.0 and np.signbit(cat[24, 12, 144]) and float(np.delete(cat.reshape(-1), (24 * 13 + 12) * 256 + 144).min()) > 0.0
