@@ -4,4 +4,4 @@
 set -u
 OUT=gpurun_out/r05t
 mkdir -p $OUT
-timeout 150 python -m pytest tests/test_gpu_inkernel_noise.py -m gpu -q -s 2>&1 | tail -25 | tee $OUT/pytest.log
+timeout 120 python -m pytest tests/test_gpu_inkernel_noise.py -m gpu -q -s ${WNV_K:+-k "$WNV_K"} 2>&1 | tail -25 | tee $OUT/pytest.log
