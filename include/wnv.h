@@ -157,7 +157,15 @@ typedef struct wnv_generate_args {
     const float* teacher;      /* device (B, Tt, Cin) teacher-forcing inputs (test_inputs), or NULL      */
     int64_t Tt;
     const float* noise;        /* device (T, B, wnv_noise_width) tape, or NULL = in-kernel Philox(seed)  */
-    uint64_t seed;
+    uint64_t seed;             /* THE IN-KERNEL STREAM (noise == NULL): value j of (utterance b, step t) is the first output word x of */
+                               /*   Philox4x32-10(counter = (t lo, t hi, b, j), key = (seed lo, seed hi)) mapped to the float32         */
+                               /*   u = ((x >> 8) + 0.5) / 2^24, and by the tape's position j (wnv_noise_width's layout) to             */
+                               /*   U(1e-5, 1 - 1e-5) = fma(u, 1 - 2e-5, 1e-5) | N(0, 1) = sqrt(-2 ln u) cos(2 pi v), v from the second */
+                               /*   word | Exp(1) = -ln u.  Packed slots: b = seg_uid, t = the step within the utterance.  u is exactly  */
+                               /*   1.0 once in 2^24 draws (float32 rounding): Exp(1) is then -0.0 and that class cannot be picked       */
+                               /*   (in launches of more than four one-hot utterances per ring it is picked instead: log-domain pick).   */
+                               /*   A launch is a deterministic function of (weights, inputs, seed): tests/_philox.py restates the      */
+                               /*   stream in numpy and tests/test_gpu_inkernel_noise.py checks every sample against it.                */
     int32_t softmax;           /* categorical only: apply softmax (wavenet.py:332)                       */
     int32_t quantize;          /* categorical only: sample a one-hot (wavenet.py:333-335)                */
     float* out;                /* device (B, C, T): C = 1 scalar samples | out_channels one-hot/probs;   */
