@@ -8,7 +8,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from wavenet_vocoder_amd.sharding import (THROUGHPUT_GROUP, auto_group_size, broadcast_weights, lpt_assign, pack_groups,
-                                          pad_group, padding_loss, plan_launches, plan_slots, synthesize_sharded)
+                                          pad_group, padding_loss, plan_launches, plan_slots, segment_maps, synthesize_sharded)
 
 HOP, PAD = 4, 2
 
@@ -119,6 +119,37 @@ def test_launch_plan_of_packed_jobs():
             assert load <= 100 or len(b) == 1
     assert plan_launches([], 48, 100) == []
     assert plan_launches([7], 48, 1) == [[0]]
+
+
+def test_segment_maps_of_a_packed_launch():
+    """sharding.segment_maps (the (slots, T) int32 maps the ring kernel's roles read, built with torch ops from one small table) against
+    the literal per-step loop: at slot-step (s, t) the start step, the job id and the speaker of the utterance that runs there; a slot
+    that ends early keeps its last utterance to T."""
+    g = torch.Generator().manual_seed(3)
+    lengths = [int(x) * 8 for x in torch.randint(1, 12, (23,), generator=g)]
+    ids = [100 + 3 * k for k in range(23)]                              # ids in the job (positions into the job's mel list)
+    speakers = {i: int(torch.randint(0, 7, (1,), generator=g)) for i in ids}
+    spk_list = [speakers.get(i, -1) for i in range(max(ids) + 1)]
+    for n_slots in (1, 4, 23, 48):
+        bins = plan_slots(lengths, n_slots)
+        T = max(sum(lengths[k] for k in b) for b in bins)
+        for with_spk in (False, True):
+            where, start, uid, gid = segment_maps(bins, lengths, ids, spk_list if with_spk else None, T, "cpu")
+            assert start.dtype == uid.dtype == torch.int32 and start.shape == uid.shape == (len(bins), T) and start.is_contiguous()
+            assert (gid is None) == (not with_spk)
+            assert sorted(where) == list(range(23))
+            for s, b in enumerate(bins):
+                off = 0
+                for j, k in enumerate(b):
+                    assert where[k] == (s, off)
+                    end = off + lengths[k] if j + 1 < len(b) else T
+                    assert torch.all(start[s, off:end] == off) and torch.all(uid[s, off:end] == ids[k])
+                    if with_spk:
+                        assert torch.all(gid[s, off:end] == speakers[ids[k]])
+                    off += lengths[k]
+            # the kernel's reading of the maps: the step within the utterance is t - start, a new utterance begins where start == t
+            t = torch.arange(T).unsqueeze(0)
+            assert torch.all(start <= t) and int((start == t).sum()) == 23
 
 
 def test_single_process_matches():

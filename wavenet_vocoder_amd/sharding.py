@@ -324,6 +324,33 @@ def upsample_each(eng, mels: Sequence[torch.Tensor], ids: Sequence[int], cin_pad
                 yield k, cu[row]
 
 
+def segment_maps(bins: Sequence[Sequence[int]], lengths: Sequence[int], ids: Sequence[int], speaker_ids: Optional[Sequence[int]], T: int, device):
+    """The per-slot-step maps of a packed launch (``wnv_generate_args.seg_start / seg_uid / seg_gid``, each ``(len(bins), T)`` int32 on
+    ``device``) and ``where``: position in ``ids`` -> (slot, first step).  ``bins[s]``: positions into ``ids`` / ``lengths`` in running
+    order.  At slot-step (s, t) the maps name the utterance that runs there: the step it started at, its id in the job (``ids[k]``: its
+    noise stream), its speaker (``speaker_ids[ids[k]]``: its bias row; None without a speaker embedding).  A slot that ends before T
+    keeps its last utterance running to T (ignored by the caller).
+    8-12 bytes per slot-step next to 4 cin of conditioning: the kernel's roles look a step up without carrying a cursor per slot in
+    registers they do not have.  Built ON THE DEVICE from one small segment table (start, id, speaker, run length per segment) -- as host
+    arrays they were 8-12 T n bytes of fills and of pageable upload per launch."""
+    where = {}
+    seg_rows = []                               # (start, uid, gid, run length) per segment, slot after slot
+    for s, b in enumerate(bins):
+        off = 0
+        for j, k in enumerate(b):
+            where[k] = (s, off)
+            run = lengths[k] if j + 1 < len(b) else T - off
+            seg_rows.append((off, ids[k], int(speaker_ids[ids[k]]) if speaker_ids is not None else 0, run))
+            off += lengths[k]
+    n = len(bins)
+    table = torch.tensor(seg_rows, dtype=torch.int32).to(device)
+    runs = table[:, 3].to(torch.int64)
+    seg_start = torch.repeat_interleave(table[:, 0], runs, output_size=n * T).view(n, T)
+    seg_uid = torch.repeat_interleave(table[:, 1], runs, output_size=n * T).view(n, T)
+    seg_gid = torch.repeat_interleave(table[:, 2], runs, output_size=n * T).view(n, T) if speaker_ids is not None else None
+    return where, seg_start, seg_uid, seg_gid
+
+
 def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, want_params=False, speaker_ids=None, as_index=False):
     """One launch of packed slots over the utterances ``ids`` (indices into ``mels``, which are also their ids in the job).
     Returns views into the launch's output buffers (the caller copies or consumes them before the next launch)."""
@@ -335,24 +362,7 @@ def _packed_launch(model, mels, ids, hop_size, cin_pad, n_slots, seed, want_para
     bins = plan_slots(lengths, n_slots)                                               # positions into ids
     n, T = len(bins), max(sum(lengths[k] for k in b) for b in bins)
     c_slot = torch.zeros(n, T, cin, device=dev, dtype=torch.float32)
-    # per-slot-step maps (int32 each: 8-12 bytes per slot-step next to 4 cin of conditioning; the kernel's roles look a step up without
-    # carrying a cursor per slot in registers they do not have).  Built ON THE DEVICE from one small segment table (start, id, speaker,
-    # length per segment; a slot that ends early keeps its last utterance running to T: ignored) -- as host arrays they were 8-12 T n
-    # bytes of fills and of pageable upload per launch
-    where = {}
-    seg_rows = []                               # (start, uid, gid, run length) per segment, slot after slot
-    for s, b in enumerate(bins):
-        off = 0
-        for j, k in enumerate(b):
-            where[k] = (s, off)
-            run = lengths[k] if j + 1 < len(b) else T - off
-            seg_rows.append((off, ids[k], int(speaker_ids[ids[k]]) if speaker_ids is not None else 0, run))
-            off += lengths[k]
-    table = torch.tensor(seg_rows, dtype=torch.int32).to(dev)
-    runs = table[:, 3].to(torch.int64)
-    seg_start = torch.repeat_interleave(table[:, 0], runs, output_size=n * T).view(n, T)
-    seg_uid = torch.repeat_interleave(table[:, 1], runs, output_size=n * T).view(n, T)
-    seg_gid = torch.repeat_interleave(table[:, 2], runs, output_size=n * T).view(n, T) if speaker_ids is not None else None
+    where, seg_start, seg_uid, seg_gid = segment_maps(bins, lengths, ids, speaker_ids, T, dev)
     for k, cu in upsample_each(eng, mels, ids, cin_pad, hop_size):
         s, off = where[k]
         c_slot[s, off:off + lengths[k]] = cu
