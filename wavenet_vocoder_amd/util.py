@@ -14,18 +14,19 @@ def _scalar(input_type):
     return _SCALAR[input_type]
 
 
-def is_scalar_input(input_type):
+# (the parameter is called ``s`` as in the reference, util.py:9-25: a keyword call ``is_mulaw(s=...)`` keeps working)
+def is_scalar_input(s):
     """True for the two scalar-sample types ("raw", "mulaw")."""
-    return _scalar(input_type)
+    return _scalar(s)
 
 
-def is_mulaw_quantize(input_type):
-    return not _scalar(input_type)
+def is_mulaw_quantize(s):
+    return not _scalar(s)
 
 
-def is_mulaw(input_type):
-    return _scalar(input_type) and input_type == "mulaw"
+def is_mulaw(s):
+    return _scalar(s) and s == "mulaw"
 
 
-def is_raw(input_type):
-    return _scalar(input_type) and input_type == "raw"
+def is_raw(s):
+    return _scalar(s) and s == "raw"
