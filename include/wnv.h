@@ -38,7 +38,14 @@
 extern "C" {
 #endif
 
-#define WNV_ABI_VERSION 5
+#define WNV_ABI_VERSION 6
+/* The library is built with -fvisibility=hidden: the entry points declared with WNV_API below are its ONLY dynamic symbols
+ * (tests/test_host_cpu.py checks `nm -D`: no mangled C++ internals, nothing else defined). */
+#if defined(__GNUC__) || defined(__clang__)
+#define WNV_API __attribute__((visibility("default")))
+#else
+#define WNV_API
+#endif
 #define WNV_MAX_UPSAMPLE_STAGES 8
 
 typedef enum wnv_status {
@@ -116,22 +123,22 @@ typedef struct wnv_engine* wnv_handle;
 /* Replaces WaveNet.__init__ (wavenet.py:98-156).  Synchronous.  device = -1 creates a HOST-ONLY handle: wnv_load_weights
  * validates, folds and packs a checkpoint without touching a device (wnv_bytes_per_step / wnv_macs_per_sample work);
  * wnv_upsample / wnv_generate / wnv_forward refuse it -- there is no CPU path. */
-wnv_status wnv_create(const wnv_config* cfg, int32_t device, wnv_handle* out);
-wnv_status wnv_destroy(wnv_handle h);
+WNV_API wnv_status wnv_create(const wnv_config* cfg, int32_t device, wnv_handle* out);
+WNV_API wnv_status wnv_destroy(wnv_handle h);
 
 /* Replaces load_state_dict + make_generation_fast_ (evaluate.py:145-153, wavenet.py:355-361) and
  * conv.Conv1d._get_linearized_weight (conv.py:51-62): takes the tensors of a reference state_dict,
  * folds weight norm, re-lays the weights out for the kernels and uploads them.  Synchronous.
  * Unknown names -> WNV_ERR_INVALID_ARG; a missing required tensor -> WNV_ERR_NOT_LOADED. */
-wnv_status wnv_load_weights(wnv_handle h, const wnv_tensor* tensors, int32_t n);
+WNV_API wnv_status wnv_load_weights(wnv_handle h, const wnv_tensor* tensors, int32_t n);
 
 /* receptive_field_size (wavenet.py:42-60). */
-int64_t wnv_receptive_field(int32_t layers, int32_t stacks, int32_t kernel_size);
+WNV_API int64_t wnv_receptive_field(int32_t layers, int32_t stacks, int32_t kernel_size);
 /* Number of float32 noise values consumed per utterance per step for this configuration
  * (tape layout: wavenet_vocoder_amd/noise.py; draw order of the reference: SURVEY.md A.3). */
-int32_t wnv_noise_width(const wnv_config* cfg);
+WNV_API int32_t wnv_noise_width(const wnv_config* cfg);
 /* Number of output samples the upsampling network produces for Tc_in input frames, or -1. */
-int64_t wnv_upsampled_length(const wnv_config* cfg, int64_t Tc_in);
+WNV_API int64_t wnv_upsampled_length(const wnv_config* cfg, int64_t Tc_in);
 
 /* ---- prologue: local-conditioning upsampling ----------------------------------------------------
  * Replaces ConvInUpsampleNetwork.forward / UpsampleNetwork.forward (upsample.py:83-85, :51-66) and the
@@ -139,7 +146,7 @@ int64_t wnv_upsampled_length(const wnv_config* cfg, int64_t Tc_in);
  *   c      device (B, cin, Tc_in)                       [Tc_in includes the 2*cin_pad context frames]
  *   c_up   device (B, T, cin)   TIME-MAJOR              [T = wnv_upsampled_length(cfg, Tc_in)]
  * Returns WNV_ERR_SHAPE when T != T_expected (T_expected < 0 skips the check). */
-wnv_status wnv_upsample(wnv_handle h, const float* c, int32_t B, int64_t Tc_in,
+WNV_API wnv_status wnv_upsample(wnv_handle h, const float* c, int32_t B, int64_t Tc_in,
                         float* c_up, int64_t T_expected, void* stream);
 
 /* ---- the hot loop --------------------------------------------------------------------------------
@@ -159,13 +166,15 @@ typedef struct wnv_generate_args {
     const float* noise;        /* device (T, B, wnv_noise_width) tape, or NULL = in-kernel Philox(seed)  */
     uint64_t seed;             /* THE IN-KERNEL STREAM (noise == NULL): value j of (utterance b, step t) is the first output word x of */
                                /*   Philox4x32-10(counter = (t lo, t hi, b, j), key = (seed lo, seed hi)) mapped to the float32         */
-                               /*   u = ((x >> 8) + 0.5) / 2^24, and by the tape's position j (wnv_noise_width's layout) to             */
-                               /*   U(1e-5, 1 - 1e-5) = fma(u, 1 - 2e-5, 1e-5) | N(0, 1) = sqrt(-2 ln u) cos(2 pi v), v from the second */
-                               /*   word | Exp(1) = -ln u.  Packed slots: b = seg_uid, t = the step within the utterance.  u is exactly  */
-                               /*   1.0 once in 2^24 draws (float32 rounding): Exp(1) is then -0.0 and that class cannot be picked       */
-                               /*   (in launches of more than four one-hot utterances per ring it is picked instead: log-domain pick).   */
-                               /*   A launch is a deterministic function of (weights, inputs, seed): tests/_philox.py restates the      */
-                               /*   stream in numpy and tests/test_gpu_inkernel_noise.py checks every sample against it.                */
+                               /*   u = ((x >> 9) + 0.5) / 2^23 -- exact, 0 < u < 1 -- and by the tape's position j (wnv_noise_width's   */
+                               /*   layout) to U(1e-5, 1 - 1e-5) = fma(u, 1 - 2e-5, 1e-5) | N(0, 1) = sqrt(-2 ln u) cos(2 pi v), v from   */
+                               /*   the second word | Exp(1) = -ln u > 0.  Packed slots: b = seg_uid, t = the step within the utterance. */
+                               /*   A launch is a deterministic function of (weights, inputs, seed), and an utterance's waveform does   */
+                               /*   not depend on the batch it ran in or on how a job was packed (one-hot models: one pick form,        */
+                               /*   argmax logit_k - log e_k, in every instantiation of the ring kernel; ABI 6 changed the map from     */
+                               /*   ((x >> 8) + 0.5) / 2^24, which rounded to 1.0 once in 2^24 draws).  tests/_philox.py restates the   */
+                               /*   stream in numpy; tests/test_gpu_inkernel_noise.py checks every sample against it,                   */
+                               /*   tests/test_gpu_seed_determinism.py the independence of the batch size.                              */
     int32_t softmax;           /* categorical only: apply softmax (wavenet.py:332)                       */
     int32_t quantize;          /* categorical only: sample a one-hot (wavenet.py:333-335)                */
     float* out;                /* device (B, C, T): C = 1 scalar samples | out_channels one-hot/probs;   */
@@ -217,28 +226,28 @@ typedef struct wnv_generate_args {
  * once 2 further calls have been served by the generic kernel (4, 8, ... 32 after consecutive time-outs; wnv_reset() makes
  * the next call try at once).  An explicit kernel == 2 reports the error instead.  WNV_GEN_ASYNC needs kernel == 2 and at
  * most 64 utterances (larger batches are run as several launches of 64). */
-wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* args);
+WNV_API wnv_status wnv_generate(wnv_handle h, const wnv_generate_args* args);
 /* Waits for the handle's last WNV_GEN_ASYNC launch and returns its status (WNV_OK when nothing is pending).  Synchronous. */
-wnv_status wnv_wait(wnv_handle h);
+WNV_API wnv_status wnv_wait(wnv_handle h);
 /* Which kernel served the last wnv_generate of this handle: 1 generic, 2 ring, 3 group ring (wide models), 0 none yet. */
-int32_t wnv_last_kernel(wnv_handle h);
+WNV_API int32_t wnv_last_kernel(wnv_handle h);
 
 /* WaveNet.clear_buffer (wavenet.py:345-353): the engine re-zeroes its history at the start of every
  * wnv_generate (as incremental_forward does at :241), so this only releases scratch. */
-wnv_status wnv_reset(wnv_handle h);
+WNV_API wnv_status wnv_reset(wnv_handle h);
 
 /* ---- layer-level drop-ins ------------------------------------------------------------------------
  * conv.Conv1d.incremental_forward (conv.py:17-46): one step of a queue-cached dilated convolution. */
 typedef struct wnv_qconv* wnv_qconv_handle;
-wnv_status wnv_qconv_create(int32_t cin, int32_t cout, int32_t kernel_size, int32_t dilation,
+WNV_API wnv_status wnv_qconv_create(int32_t cin, int32_t cout, int32_t kernel_size, int32_t dilation,
                             int32_t device, wnv_qconv_handle* out);
 /* weight host (cout, cin, kernel_size) [nn.Conv1d layout]; bias host (cout) or NULL. */
-wnv_status wnv_qconv_set_weights(wnv_qconv_handle q, const float* weight, const float* bias);
+WNV_API wnv_status wnv_qconv_set_weights(wnv_qconv_handle q, const float* weight, const float* bias);
 /* x device (B, cin) -> y device (B, cout).  History is created zeroed on the first step after a reset
  * (conv.py:34-36) for that B. */
-wnv_status wnv_qconv_step(wnv_qconv_handle q, const float* x, float* y, int32_t B, void* stream);
-wnv_status wnv_qconv_reset(wnv_qconv_handle q);          /* conv.py:48-49 clear_buffer */
-wnv_status wnv_qconv_destroy(wnv_qconv_handle q);
+WNV_API wnv_status wnv_qconv_step(wnv_qconv_handle q, const float* x, float* y, int32_t B, void* stream);
+WNV_API wnv_status wnv_qconv_reset(wnv_qconv_handle q);          /* conv.py:48-49 clear_buffer */
+WNV_API wnv_status wnv_qconv_destroy(wnv_qconv_handle q);
 
 /* ResidualConv1dGLU.incremental_forward (modules.py:112-163): one gated residual layer step. */
 typedef struct wnv_glu* wnv_glu_handle;
@@ -246,15 +255,15 @@ typedef struct wnv_glu_config {
     int32_t residual_channels, gate_channels, kernel_size, skip_out_channels;
     int32_t cin_channels, gin_channels, dilation, bias;
 } wnv_glu_config;
-wnv_status wnv_glu_create(const wnv_glu_config* cfg, int32_t device, wnv_glu_handle* out);
+WNV_API wnv_status wnv_glu_create(const wnv_glu_config* cfg, int32_t device, wnv_glu_handle* out);
 /* names as in ResidualConv1dGLU.state_dict(): "conv.weight[_g|_v]", "conv.bias", "conv1x1c.weight..",
  * "conv1x1g.weight..", "conv1x1_out.*", "conv1x1_skip.*". */
-wnv_status wnv_glu_load_weights(wnv_glu_handle g, const wnv_tensor* tensors, int32_t n);
+WNV_API wnv_status wnv_glu_load_weights(wnv_glu_handle g, const wnv_tensor* tensors, int32_t n);
 /* x (B,R), c (B,cin)|NULL, gcond (B,gin)|NULL  ->  x_out (B,R), s_out (B,K); all device. */
-wnv_status wnv_glu_step(wnv_glu_handle g, const float* x, const float* c, const float* gcond,
+WNV_API wnv_status wnv_glu_step(wnv_glu_handle g, const float* x, const float* c, const float* gcond,
                         float* x_out, float* s_out, int32_t B, void* stream);
-wnv_status wnv_glu_reset(wnv_glu_handle g);              /* modules.py:165-169 clear_buffer */
-wnv_status wnv_glu_destroy(wnv_glu_handle g);
+WNV_API wnv_status wnv_glu_reset(wnv_glu_handle g);              /* modules.py:165-169 clear_buffer */
+WNV_API wnv_status wnv_glu_destroy(wnv_glu_handle g);
 
 /* ---- teacher-forced batch evaluation ------------------------------------------
  * Replaces WaveNet.forward (wavenet.py:164-213) after the upsampling step: first_conv, the L gated layers over all T at
@@ -271,7 +280,7 @@ typedef struct wnv_forward_args {
     int32_t softmax;           /* F.softmax(x, dim=1) at the end (wavenet.py:211)                           */
     void* stream;
 } wnv_forward_args;
-wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* args);
+WNV_API wnv_status wnv_forward(wnv_handle h, const wnv_forward_args* args);
 
 /* ---- post-chain ------------------------------------------------------------
  * Replaces the tail of synthesis.batch_wavegen (synthesis.py:66-84) and the clip / int16 conversion of
@@ -292,7 +301,7 @@ typedef struct wnv_post_args {
     int16_t* pcm;              /* optional device (B, T): to_int16 (evaluate.py:43-48), needs clip        */
     void* stream;
 } wnv_post_args;
-wnv_status wnv_postprocess(int32_t device, const wnv_post_args* args);
+WNV_API wnv_status wnv_postprocess(int32_t device, const wnv_post_args* args);
 
 /* ---- mel front end ------------------------------------------------------------
  * Replaces audio.logmelspectrogram (audio.py:101-109: librosa.stft -> |D| -> librosa.filters.mel -> log10(max(., 1e-10)))
@@ -314,14 +323,14 @@ typedef struct wnv_mel_config {
 } wnv_mel_config;
 typedef struct wnv_mel* wnv_mel_handle;
 /* device < 0 creates a host-only handle (filterbank introspection via wnv_mel_basis; wnv_logmel refuses it). */
-wnv_status wnv_mel_create(const wnv_mel_config* cfg, int32_t device, wnv_mel_handle* out);   /* synchronous */
-wnv_status wnv_mel_destroy(wnv_mel_handle h);
+WNV_API wnv_status wnv_mel_create(const wnv_mel_config* cfg, int32_t device, wnv_mel_handle* out);   /* synchronous */
+WNV_API wnv_status wnv_mel_destroy(wnv_mel_handle h);
 /* StandardScaler.mean_ / scale_ (host, num_mels each): out = (logmel - mean) / scale.  Synchronous. */
-wnv_status wnv_mel_set_scaler(wnv_mel_handle h, const float* mean, const float* scale);
+WNV_API wnv_status wnv_mel_set_scaler(wnv_mel_handle h, const float* mean, const float* scale);
 /* Number of frames librosa.stft(center=True) yields for n samples: 1 + n / hop_size; -1 on bad arguments. */
-int64_t wnv_mel_frames(const wnv_mel_config* cfg, int64_t n);
+WNV_API int64_t wnv_mel_frames(const wnv_mel_config* cfg, int64_t n);
 /* The filterbank the engine uses, host (num_mels, fft_size / 2 + 1) float32 = librosa.filters.mel(...). */
-wnv_status wnv_mel_basis(wnv_mel_handle h, float* host_out);
+WNV_API wnv_status wnv_mel_basis(wnv_mel_handle h, float* host_out);
 typedef struct wnv_logmel_args {
     int32_t B;
     int64_t n;                 /* samples per utterance                                                     */
@@ -332,7 +341,7 @@ typedef struct wnv_logmel_args {
     int32_t normalize;         /* 1: apply the scaler (needs wnv_mel_set_scaler)                            */
     void* stream;
 } wnv_logmel_args;
-wnv_status wnv_logmel(wnv_mel_handle h, const wnv_logmel_args* args);
+WNV_API wnv_status wnv_logmel(wnv_mel_handle h, const wnv_logmel_args* args);
 
 /* ---- host helpers for a streamed replay tape (ABI 3) -------------------------------------------------
  * The reference draws its sampling noise from torch's CPU generator inside the loop (wavenet.py:334-335: OneHotCategorical ->
@@ -340,13 +349,13 @@ wnv_status wnv_logmel(wnv_mel_handle h, const wnv_logmel_args* args);
  * of a mu-law model -- longer to draw than the kernel takes to run.  These helpers let the host draw it WHILE the kernel runs. */
 /* Coherent, device-mapped host memory (hipHostMalloc, coherent + mapped + portable: valid on every device of the process, whichever
  * is current on the calling thread): *host_ptr for the CPU, *device_ptr for wnv_generate_args. */
-wnv_status wnv_pinned_alloc(size_t bytes, void** host_ptr, void** device_ptr);
-wnv_status wnv_pinned_free(void* host_ptr);
+WNV_API wnv_status wnv_pinned_alloc(size_t bytes, void** host_ptr, void** device_ptr);
+WNV_API wnv_status wnv_pinned_free(void* host_ptr);
 /* out[i] = (float)(-log1p(-u[i])), u in [0, 1) double: the transform ATen's CPU exponential_ applies to its uniform draw
  * (TransformationHelper.h: -1 / lambda * log1p(-u), lambda = 1, computed in double, libm's log1p), on `threads` host threads.
  * With u = torch.empty(n, dtype=float64).uniform_(0, 1) this reproduces torch.empty(n).exponential_(1) bit for bit and leaves the
  * generator in the same state (tests/test_host_cpu.py).  Pure host code. */
-wnv_status wnv_exponential_from_uniform(const double* u, float* out, int64_t n, int32_t threads);
+WNV_API wnv_status wnv_exponential_from_uniform(const double* u, float* out, int64_t n, int32_t threads);
 /* n draws of torch's CPU generator as `torch.empty(n, dtype=float64).uniform_(0, 1, generator=g)` makes them, natively: `state` is the
  * blob g.get_state() returns (CPUGeneratorImpl's legacy layout: seed u64 @0, left i32 @8, seeded i32 @12, next u64 @16, the 624 words of
  * at::mt19937 as u64 @24) and is ADVANCED in place -- g.set_state(state) afterwards leaves g where the torch call would have.  Two
@@ -354,19 +363,19 @@ wnv_status wnv_exponential_from_uniform(const double* u, float* out, int64_t n, 
  * wnv_exponential_from_uniform this is the reference's exponential race (wavenet.py:334-335) at ~1.5 ns per value instead of the 5-10 ns
  * torch's element-by-element walk costs inside a busy process; the Python host checks it against torch once per process and falls back
  * to uniform_ when the numbers or the state differ (added within ABI 4, round 4; pure host code). */
-wnv_status wnv_mt19937_uniform53(void* state, int64_t state_bytes, double* out, int64_t n);
+WNV_API wnv_status wnv_mt19937_uniform53(void* state, int64_t state_bytes, double* out, int64_t n);
 
 /* ---- misc --------------------------------------------------------------------------------------- */
-const char* wnv_last_error(void);
-int32_t wnv_abi_version(void);
+WNV_API const char* wnv_last_error(void);
+WNV_API int32_t wnv_abi_version(void);
 /* Introspection used by bench.py's roofline: algorithmic bytes moved per time step of a B-utterance
  * group (weights once + ring taps + conditioning row + output) and MACs per sample. */
-int64_t wnv_bytes_per_step(wnv_handle h, int32_t B);
-int64_t wnv_macs_per_sample(wnv_handle h);
+WNV_API int64_t wnv_bytes_per_step(wnv_handle h, int32_t B);
+WNV_API int64_t wnv_macs_per_sample(wnv_handle h);
 /* Which configurations a sample-loop kernel covers, from the configuration alone (pure host code): "supported", or the reason
  * wnv_generate would report with WNV_ERR_UNSUPPORTED.  kernel: 1 generic (everything the reference can express), 2 pipelined ring,
  * 3 group ring (wide models).  ABI 5. */
-const char* wnv_kernel_coverage(const wnv_config* cfg, int32_t kernel, int32_t B);
+WNV_API const char* wnv_kernel_coverage(const wnv_config* cfg, int32_t kernel, int32_t B);
 /* (ABI 5: the LDS-peak microbenchmark and the time-out injection hook left the product ABI: include/wnv_test.h, libwnv_test.so.) */
 
 #ifdef __cplusplus

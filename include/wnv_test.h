@@ -12,12 +12,12 @@ extern "C" {
 
 /* The next n persistent (ring) launches this handle would make in auto mode (kernel = 0) report WNV_ERR_TIMEOUT without being
  * launched -- drives the retry policy described at wnv_reset without a device that loses its CUs.  n = 0 clears. */
-wnv_status wnv_debug_inject_timeouts(wnv_handle h, int32_t n);
+WNV_API wnv_status wnv_debug_inject_timeouts(wnv_handle h, int32_t n);
 
 /* The MEASURED on-chip peak the sample loop's roofline is priced against: LDS read bandwidth of the whole device in
  * GB/s from a microbenchmark launch (every CU: 16 waves of conflict-free ds_read_b128; csrc/wnv_ubench.hip), ~5 ms.  *n_cu (optional)
  * receives the CU count the figure covers.  Synchronous; needs a GPU. */
-wnv_status wnv_measure_lds_read_peak(int32_t device, double* gb_per_s, int32_t* n_cu);
+WNV_API wnv_status wnv_measure_lds_read_peak(int32_t device, double* gb_per_s, int32_t* n_cu);
 
 #ifdef __cplusplus
 }

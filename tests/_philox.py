@@ -4,10 +4,9 @@ csrc/wnv_dev.h: wnv_philox (Philox4x32-10, Salmon et al. 2011 -- the Random123 k
 wnv_u01 and wnv_noise_gen: value j of (utterance b, step t) under ``seed`` = Philox(counter = (t lo, t hi, b, j), key = (seed lo, seed hi));
 the first output word gives the uniform, kind 0: U(1e-5, 1 - 1e-5), kind 2: Exp(1) = -log u.
 
-The uniform is ((x >> 8) + 0.5) / 2^24 EVALUATED IN FLOAT32, as the device does: for x >> 8 = 2^24 - 1 the sum 16777215.5 is not a float32
-and rounds to 2^24 -- u = 1.0 and e = -log u = -0.0, once in 2^24 draws.  The quotient form of the categorical pick (argmax x_k / e_k) then
-scores that class -inf: it cannot be picked; the packed-slot log-domain pick keeps that treatment (run_head_cat), the throughput
-instantiation's scores it +inf.  The margin helpers below treat e <= 0 as "cannot be picked"."""
+The uniform is ((x >> 9) + 0.5) / 2^23: exact in float32 (the sum needs 24 bits, the scale is a power of two), never 0 and never 1, so
+e = -log u > 0 for every draw and every form of the categorical pick is defined everywhere (round 6; until round 5 the map was
+((x >> 8) + 0.5) / 2^24, which rounds to 1.0 once in 2^24 draws).  The margin helpers below still treat e <= 0 as "cannot be picked"."""
 import numpy as np
 
 _M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
@@ -36,8 +35,8 @@ def first_word(seed, t, b, j):
 
 def uniform01(seed, t, b, j):
     """wnv_u01 of the first word: float32 arithmetic, round to nearest even"""
-    x = (first_word(seed, t, b, j) >> np.uint64(8)).astype(np.float32)           # (< 2^24: exact)
-    return ((x + np.float32(0.5)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+    x = (first_word(seed, t, b, j) >> np.uint64(9)).astype(np.float32)           # (< 2^23: exact, and so is the sum)
+    return ((x + np.float32(0.5)).astype(np.float32) * np.float32(1.0 / 8388608.0)).astype(np.float32)
 
 
 def exp_noise(seed, t, b, j):
@@ -68,7 +67,7 @@ def tape(seed, T, B, *, scalar_input, output_distribution="Logistic", out_channe
     """The (T, B, NZ) float32 noise tape the in-kernel stream stands for (wnv_noise_gen: "same semantics as the tape", layout of
     wavenet_vocoder_amd/noise.py): value j of (utterance b0 + b, step t), kind by position -- Logistic: nr_mix + 1 uniforms of
     U(1e-5, 1 - 1e-5) (kind 0); Normal: nr_mix uniforms then one N(0, 1) (kind 1: Box-Muller of the first two output words), or the
-    single N(0, 1) for 2 / 3 output channels; one-hot: out_channels draws of Exp(1) (kind 2; -0.0 where the uniform rounded to 1)."""
+    single N(0, 1) for 2 / 3 output channels; one-hot: out_channels draws of Exp(1) (kind 2; strictly positive)."""
     if scalar_input:
         normal = output_distribution == "Normal"
         nz = 1 if (normal and out_channels in (2, 3)) else out_channels // 3 + 1
@@ -81,7 +80,7 @@ def tape(seed, T, B, *, scalar_input, output_distribution="Logistic", out_channe
     f32 = np.float32
 
     def u01(x):
-        return (((x >> np.uint64(8)).astype(f32) + f32(0.5)).astype(f32) * f32(1.0 / 16777216.0)).astype(f32)
+        return (((x >> np.uint64(9)).astype(f32) + f32(0.5)).astype(f32) * f32(1.0 / 8388608.0)).astype(f32)
 
     u = u01(w[0])
     if not scalar_input:

@@ -78,15 +78,10 @@ def test_packed_slots_draw_the_stream_of_the_utterance():
 
 @pytest.mark.parametrize("name", ["cfg1_mulaw256", "cfg1b_mulaw256_intree"])
 def test_one_hot_picks_of_the_throughput_instantiation(name):
-    """40 utterances of a mu-law model: more than four per ring, the instantiation whose head picks in the log domain (LOGPICK, round 5) --
-    under in-kernel noise every class it picks must be the argmax of logit_k - log e_k over its own head outputs and the host-restated
-    stream (or within 1e-5 of it).  The seed is one without a uniform that rounds to 1.0 among these draws (tests/_philox.py: this
-    instantiation would let such a class win, the others exclude it -- both are treatments of an e that rounded to zero)."""
+    """40 utterances of a mu-law model: more than four per ring (the throughput instantiation) -- under in-kernel noise every class it picks
+    must be the argmax of logit_k - log e_k over its own head outputs and the host-restated stream (or within 1e-5 of it)."""
     kw = CONFIGS[name]
     B, T, seed = 40, 512, 20260923
-    w = _philox.first_word(seed, np.arange(T, dtype=np.uint64)[:, None, None], np.arange(B, dtype=np.uint64)[None, :, None],
-                           np.arange(kw["out_channels"], dtype=np.uint64)[None, None, :]) >> np.uint64(8)
-    assert int((w == 0xFFFFFF).sum()) == 0
     m = build(name).to("cuda")
     eng = m._get_engine()
     c, _ = inputs(name, B, T)

@@ -3,6 +3,7 @@ fixtures, that libwnv_hip.so loads and exports everything include/wnv.h declares
 points, and that the product never touches the oracle."""
 import ctypes
 import os
+import subprocess
 import re
 
 import numpy as np
@@ -119,6 +120,12 @@ def test_product_library_reads_no_environment_and_has_no_test_hooks():
     texp = {s[-1] for s in tsyms if len(s) == 3 and s[1] == "T" and s[2].startswith("wnv_")}
     assert pexp == set(_lib.EXPORTED_SYMBOLS), pexp ^ set(_lib.EXPORTED_SYMBOLS)
     assert texp == set(_lib.EXPORTED_SYMBOLS) | set(_lib.TEST_HOOK_SYMBOLS), texp ^ (set(_lib.EXPORTED_SYMBOLS) | set(_lib.TEST_HOOK_SYMBOLS))
+    # ... and NOTHING else is defined in the dynamic symbol table (round 6: -fvisibility=hidden + csrc/wnv_exports.map): no mangled C++
+    # internals (_Z17wnv_ring_generate... used to be there), no libstdc++ instantiations, no toolchain markers
+    for path, want in ((prod, set(_lib.EXPORTED_SYMBOLS)), (test, set(_lib.EXPORTED_SYMBOLS) | set(_lib.TEST_HOOK_SYMBOLS))):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        defined = {ln.split()[-1].split("@")[0] for ln in out.splitlines() if ln.strip()}
+        assert defined == want, sorted(defined ^ want)[:10]
     # no getenv() call in the sources outside the knob header either
     csrc = os.path.join(ROOT, "wavenet_vocoder_amd", "csrc")
     for fn in os.listdir(csrc):

@@ -13,7 +13,7 @@ from typing import Optional
 __all__ = ["lib", "WnvError", "check", "Config", "Tensor", "GenerateArgs", "GluConfig", "PostArgs", "ForwardArgs", "MelConfig", "LogmelArgs", "LIB_PATH",
            "WNV_ABI_VERSION", "DIST", "UPSAMPLE"]
 
-WNV_ABI_VERSION = 5
+WNV_ABI_VERSION = 6
 WNV_MAX_UPSAMPLE_STAGES = 8
 WNV_GEN_ASYNC = 1
 # WNV_LIB selects another build of the same sources: the TEST library (libwnv_test.so: knobs + the hooks of include/wnv_test.h) or a

@@ -54,7 +54,7 @@ def _compile(src: str, tag: str, flags, verbose: bool) -> str:
     obj = os.path.join(OBJ, tag, src + ".o")
     if not _stale(obj):
         return obj
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", *flags,
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden", *flags,
            "-c", "-x", "hip", os.path.join(CSRC, src), "-o", obj + ".tmp"]
     if verbose:
         print("[wnv build]", " ".join(cmd), flush=True)
@@ -64,7 +64,8 @@ def _compile(src: str, tag: str, flags, verbose: bool) -> str:
 
 
 def _link(objs, out: str, verbose: bool) -> str:
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", out + ".tmp", *objs]
+    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={os.path.join(CSRC, 'wnv_exports.map')}",
+           "-o", out + ".tmp", *objs]
     if verbose:
         print("[wnv build]", " ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)

@@ -75,12 +75,11 @@ __device__ __forceinline__ void wnv_philox(uint32_t c0, uint32_t c1, uint32_t c2
     }
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
-// uniform in (0, 1]: never 0; exactly 1.0 once in 2^24 draws -- the sum below is formed in float32, where 16777215.5 rounds to 2^24 (found in
-// round 5, tests/test_philox_cpu.py).  Kind 2 then gives e = -0.0: the quotient form of the categorical pick scores that class x / -0.0 = -inf
-// (it cannot be picked; the packed log-domain pick keeps that, run_head_cat), kind 1 gives 0, kind 0 gives 1 - 1e-5.  Left as it is: the stream
-// is part of what a seed means, every kernel agrees on it, and a class missing one draw in 2^24 is far below anything a listener or a test of
-// the distribution can see.
-__device__ __forceinline__ float wnv_u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+// uniform in (0, 1), EXACT in float32 (round 6): (x >> 9) + 0.5 <= 2^23 - 0.5 needs 24 bits, the scale is a power of two -- no rounding
+// anywhere, never 0, never 1 (largest value 1 - 2^-24).  Exp(1) = -log u is therefore strictly positive and every form of the categorical
+// pick (argmax x_k / e_k, argmax logit_k - log e_k) is defined for every draw.  (Until round 5 the map was ((x >> 8) + 0.5) / 2^24, whose sum
+// rounds to 2^24 once in 2^24 draws: u = 1.0, e = -0.0, and the two pick forms parted there -- a one-hot waveform depended on the batch size.)
+__device__ __forceinline__ float wnv_u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f); }
 
 // noise value j of (utterance b, step t), same semantics as the tape (wavenet_vocoder_amd/noise.py)
 // kind: 0 = U(1e-5, 1-1e-5), 1 = N(0,1), 2 = Exp(1)

@@ -535,10 +535,7 @@ __device__ __forceinline__ float fast_gate(float a, float g) {
 #define WNV_PHASE2 1
 #endif
 #ifndef WNV_CAT_LOG
-#define WNV_CAT_LOG 1          // the ring's categorical head picks in the log domain in the throughput instantiation (run_head_cat, LOGPICK)
-#endif
-#ifndef WNV_CAT_LOG_PACKED
-#define WNV_CAT_LOG_PACKED 1   // ... and in the packed-slot instantiations (there with the quotient form's treatment of e = -0.0: run_head_cat)
+#define WNV_CAT_LOG 1          // the ring's categorical head picks in the log domain (run_head_cat, LOGPICK) -- in EVERY instantiation since round 6
 #endif
 #ifndef WNV_SKIP_DIRECT
 #define WNV_SKIP_DIRECT 1      // K = 512: every stage hands its own skip term to the head parts (head_sum_skip_terms)
@@ -2131,11 +2128,10 @@ __device__ __forceinline__ CatLds carve_cat(float* smem, int NK) {
 }
 __host__ __device__ constexpr size_t cat_lds_floats(int NK) { return (size_t)(4 * NK + 4) * QS + 3 * 256 + 4 * RC + 16 + (size_t)256 * RC; }
 
-// (LOGPICK: the softmax + multinomial pick in the log domain -- see the fastcat block.  A compile-time switch, on in the THROUGHPUT
-//  instantiation only (MODE 1: more than four utterances per ring, where the head's occupancy per utterance counts): same-box A/B of the
-//  form everywhere, round 5: cfg1 at 48 utterances 2 381 -> 2 463 kSamples/s, the 30-layer preset at 8 379 -> 386 -- but cfg1 at 1 / 8
-//  utterances 56.2 -> 55.1 / 444.5 -> 436.2: the shorter head moves the register allocation of the NK = 2 stage loop, as every change in a
-//  role of these one-function kernels can; the MODE 0 and packed instantiations keep the code they had.)
+// (LOGPICK: the softmax + multinomial pick in the log domain -- see the fastcat block.  Round 5 had it in the throughput and packed
+//  instantiations only (cfg1 at 48 utterances 2 381 -> 2 463 kSamples/s; at 1 / 8 utterances 56.2 -> 55.1 / 444.5 -> 436.2 through the
+//  register allocation of the NK = 2 stage loop) -- which made a one-hot waveform a function of the batch size: the two forms can part at a
+//  near tie.  Round 6: ONE form in every instantiation; -DWNV_CAT_LOG=0 builds the quotient form everywhere, for A/B runs.)
 template <int NK, bool PACKED, bool LOGPICK>
 __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p, int ring, float* smem) {
     WNV_TS_DECL;
@@ -2214,17 +2210,9 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
                 seg_prefetch(j, t);
             }
             // (WNV_CAT_LOG, softmax + multinomial: the pick is taken in the log domain, argmax_k logit_k - log e_k -- the noise term is
-            //  prepared HERE, while the ring works)
-            if constexpr (LOGPICK && PACKED) {
-                // (the in-kernel stream's uniform can round to exactly 1.0 -- wnv_u01, once in 2^24 draws -- and e = -log u is then -0.0: the
-                //  quotient form scores that class x / -0.0 = -inf, it cannot be picked.  The packed instantiation keeps exactly that, so that a
-                //  packed job equals the padded batch sample for sample: log e := +inf there.  Found as the one differing step of
-                //  tests/test_gpu_packed.py when this form was first tried in packed launches: utterance 12, step 24, class 144 of seed 99.)
-                if (tid < O) {
-                    const float ek = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
-                    s.nzb[tid] = (p.quantize && p.softmax && O <= 256) ? (ek > 0.f ? logf(ek) : INFINITY) : ek;
-                }
-            } else if constexpr (LOGPICK) {
+            //  prepared HERE, while the ring works.  The in-kernel stream's e is strictly positive -- wnv_u01 is exact and never 1, round 6 --,
+            //  a tape's e = +0.0 scores +inf in this form as in the quotient form.)
+            if constexpr (LOGPICK) {
                 if (tid < O) {
                     const float ek = nz_ok ? head_noise(p, t, b, tid, 2, tl, ub) : 1.0f;
                     s.nzb[tid] = (p.quantize && p.softmax && O <= 256) ? logf(ek) : ek;
@@ -2396,7 +2384,9 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
         // (L0 instantiations serve scalar-input models only -- the categorical head is not compiled into them: every role of a kernel is
         //  inlined into ONE function, and a change in that head moved the register allocation of the stage loop -- 2 % of the headline)
         if constexpr (NK <= 2 && !L0) {         // one-hot models with 512 skip channels stay on the generic kernel (why_not)
-            if (pos == p.S) run_head_cat<NK, MODE == 2, (MODE == 1 || (MODE == 2 && WNV_CAT_LOG_PACKED != 0)) && WNV_CAT_LOG != 0>(p, ring, smem);
+            // (round 6: ONE pick form in every instantiation -- with bit-identical logits a seed gives the same classes whatever the batch size
+            //  or the packing: tests/test_gpu_seed_determinism.py)
+            if (pos == p.S) run_head_cat<NK, MODE == 2, WNV_CAT_LOG != 0>(p, ring, smem);
             else run_head_part<NK, 2>(p, ring, pos - p.S, smem);
         }
     } else {

@@ -11,6 +11,7 @@
 #include <cstdio>
 
 #include "wnv_hostutil.h"
+#include "../../include/wnv_test.h"      // (the declaration carries WNV_API: the library is built with -fvisibility=hidden)
 
 namespace {
 
