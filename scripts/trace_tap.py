@@ -25,6 +25,6 @@ for r in rows[2:7]:
         w = v[5 * k:5 * k + 5]
         if w[0] < 0:
             continue
-        out.append(f"pass {k}: start {w[0] - base} | inputs +{w[1] - w[0]} | h filed, barrier +{w[2] - w[1]} | round 0 +{w[3] - w[2]}" + (f" | round 1 +{w[4] - w[3]}" if w[4] >= 0 else ""))
+        out.append(f"pass {k}: start {w[0] - base} | wave 0: h filed, DMAs landed +{w[1] - w[0]} | barrier +{w[2] - w[1]} | round 0 +{w[3] - w[2]}" + (f" | round 1 +{w[4] - w[3]}" if w[4] >= 0 else ""))
     print(f" step {step}" + (f" (period {base - prev})" if prev is not None else "") + ": " + " || ".join(out))
     prev = base

@@ -537,8 +537,8 @@ __device__ __forceinline__ float fast_gate(float a, float g) {
 #ifndef WNV_CAT_LOG
 #define WNV_CAT_LOG 1          // the ring's categorical head picks in the log domain (run_head_cat, LOGPICK) -- in EVERY instantiation since round 6
 #endif
-#ifndef WNV_PAIR
-#define WNV_PAIR 1             // (round 6) MODE 1 / 2 with up to 256 skip channels: the stages take a ring's utterances two at a time (run_stage_pair)
+#ifndef WNV_TAP_DEFER
+#define WNV_TAP_DEFER 1        // (round 6) tap workgroups: the last publish of a pass is held back behind the next pass's [B] and barrier (run_tap)
 #endif
 #ifndef WNV_SKIP_DIRECT
 #define WNV_SKIP_DIRECT 1      // K = 512: every stage hands its own skip term to the head parts (head_sum_skip_terms)
@@ -715,16 +715,18 @@ struct TapLds {
     float* xin;      // [2][TB][8 * kper] mat-vec inputs (two buffers: the next pass's gather lands in the other one): tap rows then conditioning row, zero padded
     int* flags;      // [32]: 0 = give-up flag; 8 + buf * TB + u = packed slots: bias row (seg_gid) of utterance u of the pass whose inputs are in buffer buf
     float4* wl;      // [8 waves][klds_rows][64 lanes] LDS-resident rows
+    float2* dv;      // [512] the held-back publish of a pass's last round (round 6: parked here, not in registers -- the tap role has none to spare)
 };
 __device__ __forceinline__ TapLds carve_tap(float* smem, const RingParams& p) {
     TapLds s;
     s.xin = smem;
     s.flags = reinterpret_cast<int*>(smem + (size_t)2 * TB * RW * p.kper);
-    s.wl = reinterpret_cast<float4*>(s.flags + 32);
+    s.dv = reinterpret_cast<float2*>(s.flags + 32);
+    s.wl = reinterpret_cast<float4*>(s.dv + RT);
     return s;
 }
 __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
-    return (size_t)2 * TB * RW * kper + 32 + (size_t)RW * klds_rows * 64 * 4;
+    return (size_t)2 * TB * RW * kper + 32 + 2 * RT + (size_t)RW * klds_rows * 64 * 4;
 }
 
 // EXPERIMENT BUILDS ONLY (-DWNV_EXP_NOPRE=1|2; results are WRONG on purpose, timing only): 1 = stages and head do not wait for the tap
@@ -737,7 +739,10 @@ __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
 //  with SPEC = false since the packed-slot masks took the last registers of the capped kernels: it saved one poll round trip per pass
 //  while the tap passes bound the step; now the stages' occupancy does.)
 // (PACKED: the launch runs packed slots -- RingParams::seg_start; a compile-time switch like SPEC: together they spill)
-template <bool SPEC, bool PACKED>
+// (DEFER: the throughput and packed instantiations hold a pass's last publish back -- see the pass loop; a compile-time switch: the
+//  single-utterance-per-ring kernels never run two passes per workgroup and step at their batch sizes that matter, and the code alone moved
+//  the headline kernel's tap role by 1.4 %)
+template <bool SPEC, bool PACKED, bool DEFER>
 __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int l, int part, float* smem) {
     if (WNV_EXP_NOPRE >= 2) return;
     const TapLds s = carve_tap(smem, p);
@@ -798,6 +803,10 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
     // wait for h[t] -- the row is waited for and filed by the NEXT pass of the utterance (tf = t - 1), a whole step later --, so the rings
     // never wait for this layer's taps (pre_rec: why the records come in two slots).  With d = 2 the youngest tap of step t + 1 is h[t-1],
     // the row that pass files: taken from the record, as a dilation-1 layer takes h[t].
+    // slot of a step in the history ring: rows = (kw - 1) d is a power of two for every kernel size 3 model (d = 2^i): a mask, not the
+    // ~40-instruction integer division the general case costs every lane of every gather (uniform: one compare)
+    const int rmask = rows > 0 && (rows & (rows - 1)) == 0 ? rows - 1 : -1;
+    auto ring_slot = [&](int step) -> int { return rmask >= 0 ? (step & rmask) : step % rows; };
     const bool early = d >= 2 && rows > 0;
     const int ntap4 = hoff / 4, ncin4 = (p.cin & 3) == 0 ? p.cin / 4 : 0;      // float4s of a mat-vec input: tap rows, conditioning row
     constexpr int GQ = 2;                                          // ... per lane ((kw - 1) 128 + cin <= 512 floats: why_not)
@@ -831,15 +840,20 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
         const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
         // packed slots: the utterance that occupies the slot at step tp_ began at step st_; what lies before reads as zeros (conv.py:34-36)
+        // (the lane-constant pieces of the addresses are formed HERE, from a copy of the lane id the compiler cannot see through: kept live
+        //  across the pass they were the registers that spilled once the deferred publish joined the loop -- a reload per pass against
+        //  three VALU instructions)
+        int lane_l = lane;
+        if constexpr (DEFER) asm volatile("" : "+v"(lane_l));
 #pragma unroll
         for (int q = 0; q < GQ; ++q) {
-            const int i = 64 * q + lane;
+            const int i = 64 * q + lane_l;
             const float* src = nullptr;
             if (i < ntap4) {
                 const int k = i >> 5, r4 = i & 31;                   // RC / 4 = 32 float4s per row
                 // (a row from before the utterance's start comes from a row of zeros: a select on the address, no branch -- the tap role has
                 //  no register to spare)
-                if (k != kf) src = tp_ - (p.kw - 1 - k) * d >= st_ ? hb + (size_t)((tp_ + k * d) % rows) * RC + 4 * r4 : p.zero_row + 4 * r4;
+                if (k != kf) src = tp_ - (p.kw - 1 - k) * d >= st_ ? hb + (size_t)ring_slot(tp_ + k * d) * RC + 4 * r4 : p.zero_row + 4 * r4;
             } else if (i < ntap4 + ncin4) {
                 src = cb + 4 * (i - ntap4);
             }
@@ -862,11 +876,6 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         if (bn0 >= p.B) { bn0 = bfirst; tn0 = t + 1; }
         st_next = seg_at(tn0, bn0);
     }
-    for (;;) {
-        const int tp = t + 1;
-        const int nb = min(p.tb, p.B - b0);
-        const int tf = early ? t - 1 : t;                           // the step whose h this pass waits for and files
-        const int kfresh = fresh_tap(tf);
 #ifdef WNV_FINE_TRACE
 #define TAP_STAMP(k) do { const int pk_ = (b0 - bfirst) / pstride; \
                           if (p.trace_tap && l == WNV_TRACE_TAP_LAYER && part == 0 && pk_ < 3 && (k) < 5 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
@@ -874,37 +883,72 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
 #else
 #define TAP_STAMP(k) ((void)0)
 #endif
-        TAP_STAMP(0);
-        // ---- [B] wave w finishes the mat-vec input of utterance b0 + w ------------------------------------------------------------
-        if (wave < nb) {
-            const int b = b0 + wave;
-            float* xu = s.xin + ((size_t)cur * TB + wave) * kx;
+    // ---- [B] wave w finishes the mat-vec input of utterance b0_ + w of pass (t_, b0_) in buffer cur_: the h record it waits for (looked at
+    //      speculatively with the gather: hx0, hx1) -> history ring and LDS; then its own DMAs (issued with the gather) have landed -------------
+    auto do_B = [&](int t_, int b0_, int cur_, int st_) {
+        const int tp_ = t_ + 1, nb_ = min(p.tb, p.B - b0_);
+        const int tf_ = early ? t_ - 1 : t_;                        // the step whose h this pass waits for and files
+        const int kfresh = fresh_tap(tf_);
+        if (wave < nb_) {
+            const int b = b0_ + wave;
+            float* xu = s.xin + ((size_t)cur_ * TB + wave) * kx;
             if (ncin4 == 0) {                                        // cin not a multiple of 4: scalar conditioning row
-                const float* cb = p.c_up + ((size_t)b * p.T + tp) * p.cin;
+                const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
                 for (int e = lane; e < p.cin; e += 64) xu[hoff + e] = cb[e];
             }
-            TAP_STAMP(1);
-            if (tf >= 0) {
-                const unsigned htag = p.tag_base + (unsigned)tf + 1u;
+            if (tf_ >= 0) {
+                const unsigned htag = p.tag_base + (unsigned)tf_ + 1u;
                 float hv[2] = {__uint_as_float((unsigned)hx0), __uint_as_float((unsigned)hx1)};         // channels 2 lane, 2 lane + 1
                 if (!__all((unsigned)(hx0 >> 32) == htag && (unsigned)(hx1 >> 32) == htag)) {
-                    if (!rec_recv<1>(p.fmail + h_rec(p, b, l, tf), htag, hv, p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
+                    // (round 6) ONE direct look at the whole record first: while the stages pace the passes the record lands during the pass
+                    // before -- behind the speculative look, ahead of this one -- and the patient receive (first granule at a relaxed cadence,
+                    // then the record: two round trips and a sleep at best) made every pass wait ~1.4 us at its barrier for the one wave
+                    // whose speculative look had missed (profiles/r06_tap_pass_timeline.txt)
+                    const u64* rec = p.fmail + h_rec(p, b, l, tf_);
+                    const u4v x = ld16_sc1(rec + 2 * lane);
+                    hv[0] = __uint_as_float(x.x); hv[1] = __uint_as_float(x.z);
+                    if (!__all(x.y == htag && x.w == htag)) {
+                        if (!rec_recv<1>(rec, htag, hv, p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
+                    }
                 }
                 if (rows > 0) {
                     float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
-                    *reinterpret_cast<float2*>(hist + (size_t)(tf % rows) * RC + 2 * lane) = make_float2(hv[0], hv[1]);
+                    *reinterpret_cast<float2*>(hist + (size_t)ring_slot(tf_) * RC + 2 * lane) = make_float2(hv[0], hv[1]);
                     if (kfresh >= 0) {
                         // (packed slots: the row is the previous utterance's when the one at step tp began later than tf)
-                        const bool mine = !PACKED || tf >= st_cur;
+                        const bool mine = !PACKED || tf_ >= st_;
                         *reinterpret_cast<float2*>(xu + kfresh * RC + 2 * lane) = mine ? make_float2(hv[0], hv[1]) : make_float2(0.f, 0.f);
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs into buffer cur (issued a pass ago) have landed
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs into buffer cur_ (issued with the gather) have landed
         }
-        __syncthreads();
+    };
+    // (round 6) THE LAST PUBLISH OF A PASS IS HELD BACK until the next pass's [B] and barrier are through (dv0, dv1 -> "deferred publish"
+    // below).  A publish is a write-through store (the stage may sit on any XCD), its acknowledgement takes 1.5-2 us, and every wait of
+    // this wave for a LOAD -- the h record's poll, the DMA wait -- waits for it too (vmcnt counts stores): with the last publish right in
+    // front of [B] that drain was paid in the open once per pass -- the "wait for h" of profiles/r04_throughput_bound_final_stages.txt,
+    // 1.6-2.6 us of a 5.9-us pass whatever the stages did (at 40+ utterances per GPU the step was 3 or 4 such passes: 17.6 / 23.5 us).
+    // Now every publish is followed by a round of FMAs before this wave waits for anything.
+    // ONLY where this workgroup runs at least two passes per step: with a single one the next pass is the same utterances' next step, whose
+    // h (a dilation-1 layer's pass waits for it) cannot exist before the publish it would be holding back -- the ring would stop.
+    // With two or more, pass N + 1 waits for h of ANOTHER group, which depends on publishes of pass N - 1 and earlier, all released.
+    const bool defer = DEFER && WNV_TAP_DEFER != 0 && bfirst + pstride < p.B;
+    int dbase = -1, du0 = 0, dnb = 0, dtp = 0;                       // the held publish: its pass's first utterance (-1: nothing held), round, utterances, step
+    for (;;) {
+        const int tp = t + 1;
+        const int nb = min(p.tb, p.B - b0);
+        TAP_STAMP(0);
+        do_B(t, b0, cur, st_cur);
+        TAP_STAMP(1);                                                // (this wave's h record filed, its DMAs landed)
+        __syncthreads();                                             // the inputs of pass (t, b0) are complete in buffer cur
         if (s.flags[0]) return;
         TAP_STAMP(2);
+        if (dbase >= 0 && du0 + pu < dnb) {                             // the deferred publish of the pass before (see above the loop)
+            const float2 dvv = s.dv[tid];
+            st_granule2(p.pmail + pre_rec(p, dbase + du0 + pu, l, dtp) + po, p.tag_base + (unsigned)dtp + 1u, dvv.x, dvv.y, false);
+        }
+        dbase = -1;
         // ---- [C] the next pass of this workgroup: its gather is issued now and lands under the mat-vec below -------------------------
         int tn = t, bn = b0 + pstride;
         if (bn >= p.B) { bn = bfirst; tn = t + 1; }
@@ -999,6 +1043,10 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
             const float v0 = dpp_fold<0xB1>(acc[0][0].x, acc[0][1].x) + fmaf(zb0, zsc, cvl.x);
             const float v1 = dpp_fold<0xB1>(acc[0][0].y, acc[0][1].y) + fmaf(zb1, zsc, cvl.y);
             // pre_l[tp] of utterance rb leaves as tagged granules (write-through: the stage may sit on any XCD): no drain
+            if (defer && more && u0 + 4 >= nb) {                          // the last round of the pass: held back (see above the loop)
+                s.dv[tid] = make_float2(v0, v1);                         // (read back by this very thread)
+                dbase = b0; du0 = u0; dnb = nb; dtp = tp;
+            } else
             if (pub) st_granule2(p.pmail + pre_rec(p, rb, l, tp) + po, p.tag_base + (unsigned)tp + 1u, v0, v1, false);
             TAP_STAMP(min(3 + u0 / 4, 4));
         }
@@ -1433,320 +1481,6 @@ __device__ __attribute__((always_inline)) void run_stage(const RingParams& p, in
             else if (wave < 4) WNV_TS_FLUSH(b, t, sidx, 0x002u, 7 + wave);
             else if (wave == 4) WNV_TS_FLUSH(b, t, sidx, 0x10C1u, 0);            // 12: N waves released
             else if (wave == 5) WNV_TS_FLUSH(b, t, sidx, 0x0040u, 7);          // 13: zin ready as wave 5 saw it
-        }
-    }
-}
-
-// ---- ROUND 6: TWO UTTERANCES PER STAGE PASS (throughput and packed instantiations) -----------------------------------------------------
-// Beyond four utterances per ring a stage's OCCUPANCY per utterance bounds the step, and that occupancy is latency, not work: of the
-// ~3.1 us a stage spends per utterance at 64 per GPU (profiles/r04_throughput_bound_final_stages.txt) 0.32 us are FMAs; the rest is four
-// barriers, the LDS hand-overs, three poll round trips (everything ahead of the chain input; the chain input; the skip sum so far) and two
-// 14-level dependent reduce / gate tails issued by one wave per SIMD.  The utterances of a ring are independent, so the stage takes them
-// TWO AT A TIME through the same phases: one round trip asks for both utterances' inputs, one barrier releases both mat-vecs (the
-// second utterance's FMAs fill the first one's dependent tail), one barrier fences both sends.  Arithmetic per utterance is run_stage's,
-// instruction for instruction (group_matvec8r, ring_gate, dot16p / dot16l, the same association order): an utterance's samples do not
-// depend on whether it travelled alone or in a pair (tests/test_gpu_seed_determinism.py).  scripts/ubench_phase.hip variant 16 is the
-// chain phase of a pair on its own (profiles/r06_ubench_phase.txt).
-struct StageLds2 {
-    float* hx[2]; float* hb[2]; float* us[2]; float* hh; float* pre[2]; float* zin[2];
-    int* flags; float* bsk; float4* wsk;
-};
-__device__ __forceinline__ StageLds2 carve_stage2(float* smem) {
-    StageLds2 s;
-    s.hx[0] = smem;            s.hx[1] = smem + 8 * ES;
-    s.hb[0] = smem + 16 * ES;  s.hb[1] = smem + 24 * ES;
-    s.us[0] = smem + 32 * ES;  s.us[1] = smem + 40 * ES;
-    s.hh = smem + 48 * ES;                                // (two vectors: one per serving wave)
-    s.pre[0] = smem + 64 * ES; s.pre[1] = s.pre[0] + GC;
-    s.zin[0] = s.pre[1] + GC;  s.zin[1] = s.zin[0] + GC;
-    s.flags = reinterpret_cast<int*>(s.zin[1] + GC);
-    s.bsk = reinterpret_cast<float*>(s.flags + 16);
-    s.wsk = reinterpret_cast<float4*>(s.bsk + 512);
-    return s;
-}
-__host__ __device__ constexpr size_t stage2_lds_floats(int NK) { return (size_t)64 * ES + 4 * GC + 16 + 512 + (size_t)lds_passes(NK) * 8 * RT * 4; }
-
-// group_matvec8r for TWO input vectors against the same register-resident rows: per utterance the same FMAs in the same order (k ascending
-// per accumulator) and the same reduce as group_matvec8r -- bit-identical results --, the x slices read in 16-byte chunks so that only a
-// chunk per utterance is live next to the 160 weight registers (both slices at once, as two calls of group_matvec8r would hold them,
-// spilled 35-87 registers in the capped kernels), and the second utterance's FMAs fill the first one's dependent reduce tail.
-__device__ __forceinline__ void group_matvec8r_pair(const f2 (&w)[4][16], const float* xa, const float* xb, const float* zaa, const float* zba,
-                                                    const float* zab, const float* zbb, float (&a)[2], float (&g)[2], bool zlane) {
-    const float2 za = make_float2(*zaa, *zba), zb = make_float2(*zab, *zbb);
-    f2 acc[2][4];
-#pragma unroll
-    for (int pq = 0; pq < 4; ++pq) acc[0][pq] = acc[1][pq] = f2{0.f, 0.f};
-    if (WNV_PHASE2_ZACC) { acc[0][0] = zlane ? f2{za.x, za.y} : f2{0.f, 0.f}; acc[1][0] = zlane ? f2{zb.x, zb.y} : f2{0.f, 0.f}; }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const float4 va = reinterpret_cast<const float4*>(xa)[c], vb = reinterpret_cast<const float4*>(xb)[c];
-        const float xs[2][4] = {{va.x, va.y, va.z, va.w}, {vb.x, vb.y, vb.z, vb.w}};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int pq = 0; pq < 4; ++pq) {
-                acc[0][pq] = __builtin_elementwise_fma(w[pq][4 * c + e], f2{xs[0][e], xs[0][e]}, acc[0][pq]);
-                acc[1][pq] = __builtin_elementwise_fma(w[pq][4 * c + e], f2{xs[1][e], xs[1][e]}, acc[1][pq]);
-            }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const float n0 = dpp_fold<0x141>(acc[u][0].x, acc[u][2].x), n1 = dpp_fold<0x141>(acc[u][0].y, acc[u][2].y);
-        const float n2 = dpp_fold<0x141>(acc[u][1].x, acc[u][3].x), n3 = dpp_fold<0x141>(acc[u][1].y, acc[u][3].y);
-        const float m0 = dpp_fold<0x4E>(n0, n2), m1 = dpp_fold<0x4E>(n1, n3);
-        a[u] = dpp_fold<0xB1>(m0, m0);
-        g[u] = dpp_fold<0xB1>(m1, m1);
-    }
-    if (!WNV_PHASE2_ZACC) { a[0] += za.x; g[0] += za.y; a[1] += zb.x; g[1] += zb.y; }
-}
-
-// Roles inside a pair pass: wave 0 serves utterance 0, wave 1 utterance 1 for everything a single wave does per utterance in run_stage
-// (the prologue's round trip, the chain-input poll, the hand-on of the layer input, the record for the tap workgroup) -- the two waves run
-// side by side, each with run_stage's single-utterance register footprint; the mat-vecs take both utterances through the same
-// register-resident rows (group_matvec8r_pair); the work behind the sends runs utterance after utterance between ONE pair of barriers.
-template <int NK, bool L0, bool ZMSG>
-__device__ __attribute__((always_inline)) void run_stage_pair(const RingParams& p, int ring, int sidx, float* smem) {
-    static_assert(NK <= 2, "K = 512 keeps run_stage (its skip passes stream)");
-    constexpr int NLDS = lds_passes(NK);
-    const StageLds2 s = carve_stage2(smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ks = tid & 7, og = tid >> 3;
-    const bool hi = ks >= 4;
-    const int ch = 2 * og + (hi ? 1 : 0);
-    const bool writer = (ks & 3) == 0;
-    const int grp = tid >> 8, gtid = tid & (GT - 1);
-    const int chc = 4 * (gtid >> 3) + (ks >> 1);
-    const bool gwriter = (ks & 1) == 0;
-    const int l = sidx;
-    const bool first_stage = sidx == 0, last_stage = sidx == p.S - 1;
-    const int S1 = p.S + 1;
-    constexpr float RS = 0.70710678118654752440f;
-    WNV_TS_DECL;
-    constexpr int VS = 8 * ES;                                                   // stride between the two utterances' hx / hb / us vectors
-
-    // ---- resident weights: exactly run_stage's -----------------------------------------------------------------------------
-    f2 wmn[4][16], wo[2][8];
-    load_pair8g((grp == 0 ? p.w2img : p.wnimg) + ((size_t)l * 8) * 4 * GT * 4, gtid, wmn);
-    const float4* wsk_g = reinterpret_cast<const float4*>(p.wsimg) + (size_t)l * NK * 8 * RT;
-#pragma unroll
-    for (int row = 0; row < 2; ++row) {
-        if (last_stage) load_image8(reinterpret_cast<const float*>(wsk_g + ((size_t)0 * 2 + row) * 4 * RT), tid, wo[row]);
-        else load_image8(p.woimg + ((size_t)l * 2 + row) * 4 * RT * 4, tid, wo[row]);
-    }
-    for (int c = 0; c < NLDS * 8; ++c) s.wsk[(size_t)c * RT + tid] = wsk_g[(size_t)c * RT + tid];
-    const float bo_r = p.bo[(size_t)l * RC + ch];
-    const float bs_r = p.bskip[(size_t)l * p.Kp + ch];
-    for (int k = tid; k < RC * NK; k += RT) s.bsk[k] = p.bskip[(size_t)l * p.Kp + k];
-    if (tid == 0) s.flags[0] = 0;
-    const int rd1 = ring + (sidx + 1) * p.rstride, rd2 = ring + (sidx + 2 <= p.S ? sidx + 2 : sidx + 1) * p.rstride;
-    const bool fast = same_xcd_as(p, rd1, last_stage ? p.NH : sidx == p.S - 2 ? 1 + p.NH : 1, rd2, s.flags + 1);
-
-    const int nlive = min(p.upr, (p.B - ring + p.n_rings - 1) / p.n_rings);       // utterances of this ring
-    const int uw = wave & 1;                                                     // the utterance of the pair this wave serves as a single wave
-    for (int t = 0; t < p.T; ++t) {
-        const unsigned tag = p.tag_base + (unsigned)t + 1u;
-        const int par = t & 1;
-        for (int j = 0; j < nlive; j += 2) {
-            const bool two = j + 1 < nlive;                                       // uniform over the ring: every stage pairs the same way
-            const int b0 = ring + j * p.n_rings;
-            const int bstep = two ? p.n_rings : 0;                                // utterance 1 of the pair = b0 + bstep
-            const bool serve = wave == 0 || (wave == 1 && two);                   // this wave runs a single-wave role in this pass
-            const size_t bw = (size_t)(b0 + uw * bstep);                          // ... for this utterance
-            float hv0 = 0.f, hv1 = 0.f;                                           // serving waves: h_{l-1}[t], channels 2 lane, 2 lane + 1
-            bool hand_on = false;
-            auto recv128 = [&](const u64* g2, unsigned code, float& v0, float& v1) { return rpoll_recv2<false>(g2, tag, v0, v1, p.status, code, lane); };
-            if (serve) {
-                // ---- everything ahead of the chain input in one round trip (run_stage's throughput prologue), one wave per utterance ----
-                const u64* x_in = p.xmail + (bw * S1 + sidx) * RC + 2 * lane;
-                float* pre_w = s.pre[0] + uw * GC;
-                float pvv[4] = {0.f, 0.f, 0.f, 0.f};
-                const u64* prec = p.pmail + pre_rec(p, (int)bw, l, t);
-                bool pre_ok = WNV_EXP_NOPRE != 0, g_ok = false, q_ok = false;
-                float g0 = 0.f, g1 = 0.f, q0 = 0.f, q1 = 0.f;
-                const size_t slot = ((bw * 2 + par) * S1 + sidx - 1) * RC + 2 * lane;
-                const u64* gsrc = (L0 && sidx == 2) || sidx == 1 ? p.xmail + (bw * S1) * RC + 2 * lane : p.gmail + slot;
-                const u64* qsrc = p.hmail + slot;
-                if (!ZMSG && !first_stage && !WNV_EXP_NOPRE) {
-                    u4v ra, rb2, rc, rd;
-                    ld16x4_sc1(prec + rec4_a(lane), prec + rec4_b(lane), gsrc, sidx == 1 ? gsrc : qsrc, ra, rb2, rc, rd);
-                    pre_ok = __all(ra.y == tag && ra.w == tag && rb2.y == tag && rb2.w == tag);
-                    g_ok = __all(rc.y == tag && rc.w == tag);
-                    q_ok = sidx != 1 && __all(rd.y == tag && rd.w == tag);
-                    pvv[0] = __uint_as_float(ra.x); pvv[1] = __uint_as_float(ra.z); pvv[2] = __uint_as_float(rb2.x); pvv[3] = __uint_as_float(rb2.z);
-                    g0 = __uint_as_float(rc.x); g1 = __uint_as_float(rc.z); q0 = __uint_as_float(rd.x); q1 = __uint_as_float(rd.z);
-                } else if (!WNV_EXP_NOPRE) {
-                    u4v ra, rb2;
-                    ld16x2_sc1(prec + rec4_a(lane), prec + rec4_b(lane), ra, rb2);
-                    pre_ok = __all(ra.y == tag && ra.w == tag && rb2.y == tag && rb2.w == tag);
-                    pvv[0] = __uint_as_float(ra.x); pvv[1] = __uint_as_float(ra.z); pvv[2] = __uint_as_float(rb2.x); pvv[3] = __uint_as_float(rb2.z);
-                }
-                if (!pre_ok && !rec_recv<2>(prec, tag, pvv, p.status, 0x700u + (unsigned)sidx, lane)) s.flags[0] = 1;
-                const float4 pv = make_float4(pvv[0], pvv[1], pvv[2], pvv[3]);
-                *reinterpret_cast<float4*>(pre_w + 4 * lane) = pv;
-                if constexpr (ZMSG) {
-                    float v[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                    if (!rpoll_recv3(p.zmail + bw * GC + 4 * lane, p.zmail + bw * GC + 4 * lane + 2, x_in, tag, v, p.status,
-                                     0x100u + (unsigned)sidx, lane)) s.flags[0] = 1;
-                    float* zin_w = s.zin[0] + uw * GC;
-                    WNV_TS(5); WNV_TS(8);
-                    const int rr = 4 * lane, half = rr >> 7, c0 = rr & (RC - 1);
-                    zin_w[2 * c0 + half] = v[0] + pv.x; zin_w[2 * (c0 + 1) + half] = v[1] + pv.y;
-                    zin_w[2 * (c0 + 2) + half] = v[2] + pv.z; zin_w[2 * (c0 + 3) + half] = v[3] + pv.w;
-                    *reinterpret_cast<float2*>(s.hx[0] + uw * VS + eidx(2 * lane)) = make_float2(v[4], v[5]);
-                } else if (!first_stage) {
-                    bool ok;
-                    if (sidx == 1) {
-                        ok = g_ok || recv128(gsrc, 0x400u + (unsigned)sidx, g0, g1);
-                        hv0 = g0; hv1 = g1;
-                    } else {
-                        ok = (g_ok || recv128(gsrc, 0x480u + (unsigned)sidx, g0, g1)) &&
-                             (q_ok || recv128(qsrc, 0x400u + (unsigned)sidx, q0, q1));
-                        hv0 = (q0 + g0) * RS;
-                        hv1 = (q1 + g1) * RS;
-                    }
-                    if (!ok) s.flags[0] = 1;
-                    WNV_TS(5);
-                    *reinterpret_cast<float2*>(s.hb[0] + uw * VS + eidx(2 * lane)) = make_float2(hv0, hv1);
-                    hand_on = !last_stage && ok;
-                }
-            }
-            __syncthreads();                                                    // pre_l and h_{l-1} of both utterances in LDS
-            if (serve && hand_on) st_granule2(p.gmail + ((bw * 2 + par) * S1 + sidx) * RC + 2 * lane, tag, hv0, hv1, fast);
-            if (grp == 1 && !ZMSG) {                                            // the N waves: zin of both utterances
-                WNV_TSX(12);
-                __builtin_amdgcn_s_setprio(3);
-                float a[2], g[2];
-                if (first_stage) {
-                    a[0] = s.pre[0][chc]; g[0] = s.pre[0][RC + chc]; a[1] = s.pre[1][chc]; g[1] = s.pre[1][RC + chc];
-                } else if (two) {
-                    group_matvec8r_pair(wmn, s.hb[0] + ES * ks, s.hb[1] + ES * ks, s.pre[0] + chc, s.pre[0] + RC + chc, s.pre[1] + chc, s.pre[1] + RC + chc, a, g, gwriter);
-                } else {
-                    group_matvec8r(wmn, s.hb[0] + ES * ks, s.pre[0] + chc, s.pre[0] + RC + chc, a[0], g[0], gwriter);
-                    a[1] = g[1] = 0.f;
-                }
-                if (gwriter) {
-                    *reinterpret_cast<float2*>(s.zin[0] + 2 * chc) = make_float2(a[0], g[0]);
-                    if (two) *reinterpret_cast<float2*>(s.zin[1] + 2 * chc) = make_float2(a[1], g[1]);
-                }
-                __builtin_amdgcn_s_setprio(0);
-                WNV_TS(6);
-            } else if (serve && !ZMSG) {
-                // ---- the chain input X[l][t]: wave 0 polls utterance 0's, wave 1 utterance 1's (sent right behind it) ----
-                float v0 = 0.f, v1 = 0.f;
-                if (!rpoll_recv2<false>(p.xmail + (bw * S1 + sidx) * RC + 2 * lane, tag, v0, v1, p.status, 0x100u + (unsigned)sidx, lane)) s.flags[0] = 1;
-                WNV_TS(8);
-                *reinterpret_cast<float2*>(s.hx[0] + uw * VS + eidx(2 * lane)) = make_float2(v0, v1);
-            }
-            __syncthreads();                                                    // X[l][t] and zin of both in LDS
-            if (grp == 1) WNV_TS(0);
-            if (grp == 0) {
-                float a[2], g[2];
-                if (two) {
-                    group_matvec8r_pair(wmn, s.hx[0] + ES * ks, s.hx[1] + ES * ks, s.zin[0] + 2 * chc, s.zin[0] + 2 * chc + 1, s.zin[1] + 2 * chc, s.zin[1] + 2 * chc + 1, a, g, gwriter);
-                } else {
-                    group_matvec8r(wmn, s.hx[0] + ES * ks, s.zin[0] + 2 * chc, s.zin[0] + 2 * chc + 1, a[0], g[0], gwriter);
-                    a[1] = g[1] = 0.f;
-                }
-                const float u0 = ring_gate(a[0], g[0]);                         // modules.py:154
-                const float u1 = ring_gate(a[1], g[1]);
-                if (gwriter) {
-                    u64* x_out = p.xmail + ((size_t)b0 * S1 + sidx + 1) * RC + chc;
-                    if (!last_stage) { st_granule(x_out, tag, u0, fast); if (two) st_granule(x_out + (size_t)bstep * S1 * RC, tag, u1, fast); }
-                    s.us[0][eidx(chc)] = u0;
-                    if (two) s.us[1][eidx(chc)] = u1;
-                }
-                WNV_TS(1);
-            }
-            // ---- behind the sends: utterance after utterance ------------------------------------------------------------------
-            __syncthreads();                                                    // u_l of both complete in LDS
-            if (grp == 1) WNV_TSX(7);
-            float mine[2][NK];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u == 1 && !two) { for (int pp = 0; pp < NK; ++pp) mine[1][pp] = 0.f; break; }
-                const size_t b = (size_t)(b0 + u * bstep);
-                float xu[16];
-                lds_read16(s.us[u] + ES * ks, xu);
-                auto h_out = [&]() {
-                    if (last_stage) return;                                     // wavenet.py:310-313
-                    const float o0 = dot16p(wo[0], xu), o1 = dot16p(wo[1], xu);
-                    const float o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1)) + bo_r;
-                    if (writer) st_granule(p.hmail + ((b * 2 + par) * S1 + sidx + 1) * RC + ch, tag, o, fast);
-                };
-                if (!(last_stage || sidx == p.S - 2)) h_out();
-                if (u == uw) WNV_TS(2);
-#pragma unroll
-                for (int pp = 0; pp < NK; ++pp) {
-                    float m0, m1;
-                    if (last_stage && pp == 0) { m0 = dot16p(wo[0], xu); m1 = dot16p(wo[1], xu); }
-                    else { m0 = dot16l(s.wsk + (size_t)(8 * pp) * RT + tid, xu); m1 = dot16l(s.wsk + (size_t)(8 * pp + 4) * RT + tid, xu); }
-                    mine[u][pp] = quad_allreduce((hi ? m1 : m0) + dpp_mov<0x141>(hi ? m0 : m1)) + (pp == 0 ? bs_r : s.bsk[RC * pp + ch]);
-                }
-                if (last_stage) {                                               // the head waits for the last stage's own term: out at once
-#pragma unroll
-                    for (int pp = 0; pp < NK; ++pp)
-                        if (writer) st_granule(p.smail + (b * S1 + sidx + 1) * p.Kp + ch + RC * pp, tag, 0.f + mine[u][pp], fast);   // (0 + term: run_stage's arithmetic)
-                }
-            }
-            if (!last_stage) {
-                // the skip sum so far (stage l - 1's, a chain of its own) + this stage's term, per utterance and pass
-                bool ok = true;
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (u == 1 && !two) break;
-                    const size_t b = (size_t)(b0 + u * bstep);
-                    const u64* sm_in = p.smail + (b * S1 + sidx) * p.Kp + ch;
-                    u64* sm_out = p.smail + (b * S1 + sidx + 1) * p.Kp + ch;
-#pragma unroll
-                    for (int pp = 0; pp < NK; ++pp) {
-                        float acc = 0.f;
-                        if (sidx > 0 && ok) ok = wave_recv<false>(sm_in + RC * pp, writer, tag, acc, p.status, 0x200u + (unsigned)sidx, lane);
-                        if (writer && ok) st_granule(sm_out + RC * pp, tag, acc + mine[u][pp], fast);
-                    }
-                }
-                if (!ok) s.flags[0] = 1;
-                if (sidx == p.S - 2) {                                          // (its q only feeds the last stage's history push: behind the skip sums)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        if (u == 1 && !two) break;
-                        const size_t b = (size_t)(b0 + u * bstep);
-                        float xu[16];
-                        lds_read16(s.us[u] + ES * ks, xu);
-                        const float o0 = dot16p(wo[0], xu), o1 = dot16p(wo[1], xu);
-                        const float o = quad_allreduce((hi ? o1 : o0) + dpp_mov<0x141>(hi ? o0 : o1)) + bo_r;
-                        if (writer) st_granule(p.hmail + ((b * 2 + par) * S1 + sidx + 1) * RC + ch, tag, o, fast);
-                    }
-                }
-            }
-            WNV_TSX(3);
-            __syncthreads();                        // fences the LDS vectors against the next pair; makes flags[0] uniform
-            if (s.flags[0]) return;
-            if (serve) {
-                auto file = [&](int layer, const float* vec) {
-                    const float2 v = *reinterpret_cast<const float2*>(vec + eidx(2 * lane));
-                    st_granule2(p.fmail + h_rec(p, (int)bw, layer, t) + 2 * lane, tag, v.x, v.y, false);
-                };
-                if (!first_stage && !ZMSG) file(l - 1, s.hb[0] + uw * VS);       // (ZMSG: the head files h_0 itself)
-                if (last_stage) {
-                    if (first_stage) {
-                        file(l, s.hx[0] + uw * VS);
-                    } else {
-                        float q0 = 0.f, q1 = 0.f;
-                        if constexpr (ZMSG) {
-                            if (!recv128(p.xmail + (bw * S1) * RC + 2 * lane, 0x500u + (unsigned)sidx, hv0, hv1)) return;
-                        }
-                        if (!recv128(p.hmail + ((bw * 2 + par) * S1 + sidx) * RC + 2 * lane, 0x500u + (unsigned)sidx, q0, q1)) return;
-                        float* hh_w = s.hh + uw * VS;
-                        *reinterpret_cast<float2*>(hh_w + eidx(2 * lane)) = make_float2((q0 + hv0) * RS, (q1 + hv1) * RS);
-                        file(l, hh_w);
-                    }
-                }
-            }
-            WNV_TSX(4);
-            // timeline slots as run_stage's; waves 0 / 1 stamp the utterance they serve, wave 4 both (the N phase and the barriers are shared)
-            if (wave == 0) WNV_TS_FLUSH(b0, t, sidx, 0x013Eu, 0);
-            else if (wave == 1 && two) WNV_TS_FLUSH(b0 + bstep, t, sidx, 0x013Eu, 0);
-            else if (wave == 4) { WNV_TS_FLUSH(b0, t, sidx, 0x10C1u, 0); if (two) WNV_TS_FLUSH(b0 + bstep, t, sidx, 0x10C1u, 0); }
         }
     }
 }
@@ -2659,7 +2393,7 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
         // split rings (see run_stage_split): block b on XCD b % 8, slot b / 8; ring r = XCDs 2r (head, stages 1 .. sA) and 2r + 1
         if ((int)blockIdx.x >= p.ring_blocks) {
             const int k = (int)blockIdx.x - p.ring_blocks;
-            if (k < p.tap_parts * p.L) run_tap<true, false>(p, k % p.L, k / p.L, smem);
+            if (k < p.tap_parts * p.L) run_tap<true, false, false>(p, k % p.L, k / p.L, smem);
             return;
         }
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, ring = xcd >> 1;
@@ -2684,28 +2418,19 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
     const int free_slots = (p.rstride - p.n_rings) * P;
     if ((int)blockIdx.x >= p.ring_blocks) {
         const int k = free_slots + (int)blockIdx.x - p.ring_blocks;
-        run_tap<(MODE != 2 || WNV_PACKED_SPEC != 0) && NK != 2, MODE == 2>(p, k % p.L, k / p.L, smem);
+        run_tap<(MODE != 2 || WNV_PACKED_SPEC != 0) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
         return;
     }
     const int ring = blockIdx.x % p.rstride;
     const int pos = blockIdx.x / p.rstride;
     if (ring >= p.n_rings) {
         const int k = pos * (p.rstride - p.n_rings) + (ring - p.n_rings);
-        if (k < p.tap_parts * p.L) run_tap<(MODE != 2 || WNV_PACKED_SPEC != 0) && NK != 2, MODE == 2>(p, k % p.L, k / p.L, smem);
+        if (k < p.tap_parts * p.L) run_tap<(MODE != 2 || WNV_PACKED_SPEC != 0) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
         return;
     }
     if (L0 && pos == 0) return;                   // layer 0 is evaluated by the head (run_head)
-    // (round 6) the throughput and packed instantiations take the utterances of a ring two at a time (run_stage_pair)
-    constexpr bool PAIR = MULTI && NK <= 2 && WNV_PAIR != 0;
-    if (pos < p.S) {
-        if constexpr (PAIR) {
-            if (L0 && pos == 1) run_stage_pair<(NK <= 2 ? NK : 1), L0, L0>(p, ring, pos, smem);
-            else run_stage_pair<(NK <= 2 ? NK : 1), L0, false>(p, ring, pos, smem);
-        } else {
-            if (L0 && pos == 1) run_stage<NK, L0, L0, MULTI>(p, ring, pos, smem);
-            else run_stage<NK, L0, false, MULTI>(p, ring, pos, smem);
-        }
-    }
+    if (L0 && pos == 1) run_stage<NK, L0, L0, MULTI>(p, ring, pos, smem);
+    else if (pos < p.S) run_stage<NK, L0, false, MULTI>(p, ring, pos, smem);
     else if (!L0 && p.cin1 > 1) {
         // (L0 instantiations serve scalar-input models only -- the categorical head is not compiled into them: every role of a kernel is
         //  inlined into ONE function, and a change in that head moved the register allocation of the stage loop -- 2 % of the headline)
@@ -3317,8 +3042,7 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);                      // multiples of 4 (kper is one)
     while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 158 * 1024) p.klds_rows -= 4;
     p.ring_blocks = split ? 8 * max_slots : rstride * P;
-    const size_t lds = std::max(std::max(std::max(std::max(stage_lds_floats(NK), NK <= 2 ? stage2_lds_floats(NK) : (size_t)0), head_lds_floats(NK)),
-                                         tap_lds_floats(p.kper, p.klds_rows)),
+    const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
                                 st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
     // more than four utterances per ring (40+ per GPU): the stages' occupancy per utterance bounds the step -> their throughput
