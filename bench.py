@@ -354,12 +354,98 @@ def latency_floor_us(kw, n_head_parts=1, hop=0.276):
     return stages * layer + head
 
 
-def dist_info(dist, world, args):
-    """Which collective library carried the barriers / reduces of this line (None: a single process without --force-dist)."""
+def dist_info(dist, world, args, dev=None):
+    """Which collective library carried the barriers / reduces of this line (None: a single process without --force-dist).
+    ``ranks_seen``: an all_reduce(SUM) of one 1 per rank over that library -- the line ASSERTS it equals --gpus, so a launch whose ranks
+    did not all join the RCCL communicator cannot post a number (VERDICT r05 next #6c)."""
     if dist is None:
         return None
-    return {"backend": str(dist.get_backend()), "world_size": world, "forced_single_rank": bool(getattr(args, "force_dist", False) and world == 1),
-            "collectives": "barrier x2, all_reduce(MAX), all_gather (rank report)" + (", gather_object (waveforms)" if getattr(args, "job", 0) > 0 else "")}
+    info = {"backend": str(dist.get_backend()), "world_size": world, "forced_single_rank": bool(getattr(args, "force_dist", False) and world == 1),
+            "collectives": "barrier x2, all_reduce(MAX), all_reduce(SUM: ranks_seen), all_gather (rank report)"
+                           + (", gather_object (waveforms)" if getattr(args, "job", 0) > 0 else "")}
+    if dev is not None:
+        one = torch.ones(1, device=dev, dtype=torch.float64)
+        dist.all_reduce(one, op=dist.ReduceOp.SUM)
+        info["ranks_seen"] = int(round(float(one.item())))
+        assert info["ranks_seen"] == world == dist.get_world_size(), (info["ranks_seen"], world)
+    return info
+
+
+def strong_job(name, n_utts, dev, dist, world, rank):
+    """One STRONG-SCALED job of BASELINE.json -- configs[3]: 64 utterances of the 30-layer Gaussian model, configs[4]: 128 of the
+    speaker-conditioned K = 512 model -- the same job whatever the number of ranks: seeded lengths 1-8 s, longest-first assignment to
+    the ranks (sharding.lpt_assign), packed slots on every rank, ONE gather of the waveforms to rank 0 (sharding.gather_results).
+    With a process group the weights are REPLICATED FROM RANK 0 by sharding.broadcast_weights (one RCCL broadcast of the flat parameter
+    buffer) -- every other rank first perturbs its own copy, so the check that all ranks ended with the same waveform statistics is a
+    check of the broadcast.  Every rank runs this (it holds collectives); returns the report on rank 0, None elsewhere.
+    Reported per rank: true samples, slot-steps incl. padding, seconds of synthesis; the gather's seconds; the imbalance of both."""
+    from tests._configs import CONFIGS, build
+    from wavenet_vocoder_amd import sharding
+    kw = CONFIGS[name]
+    hop, pad = 256, int(kw.get("cin_pad", 0))
+    gen = torch.Generator().manual_seed(2024)
+    frames = torch.randint(94, 751, (n_utts,), generator=gen).tolist()
+    mels = [torch.randn(kw["cin_channels"], f, generator=gen) for f in frames]
+    spk = torch.randint(0, kw["n_speakers"], (n_utts,), generator=gen).tolist() if kw.get("gin_channels", -1) > 0 else None
+    lengths = [f * hop for f in frames]
+    model = build(name, seed=0).to(dev)
+    t_bcast = None
+    if dist is not None:
+        if rank != 0:                                       # (what the broadcast has to undo)
+            with torch.no_grad():
+                for prm in model.parameters():
+                    prm.add_(0.01)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sharding.broadcast_weights(model, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t1
+    model.rng = "philox"
+    mine = sharding.lpt_assign(lengths, world)[rank]
+    warm = sorted(mine, key=lambda i: lengths[i])[:2]       # engine, scratch and mailboxes exist before the clock starts
+    if warm:
+        sharding.synthesize_packed(model, mels, hop_size=hop, cin_pad=pad, indices=warm, seed=1, speaker_ids=spk)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    st = {}
+    outs = sharding.synthesize_packed(model, mels, hop_size=hop, cin_pad=pad, indices=mine, stats=st, seed=4321, speaker_ids=spk) if mine else []
+    torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0
+    local = {i: o[0].detach().to("cpu") for i, o in zip(mine, outs)}
+    t1 = time.perf_counter()
+    wavs = sharding.gather_results(local, n_utts, gather_to=0) if dist is not None else [local[i] for i in range(n_utts)]
+    t_gather = time.perf_counter() - t1
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    mine_row = [float(sum(lengths[i] for i in mine)), float(st.get("padded_samples", 0)), t_local, t_gather, elapsed, float(len(mine))]
+    if dist is not None:
+        rows = [torch.zeros(len(mine_row), dtype=torch.float64, device=dev) for _ in range(world)]
+        dist.all_gather(rows, torch.tensor(mine_row, dtype=torch.float64, device=dev))
+        rows = [r.tolist() for r in rows]
+    else:
+        rows = [mine_row]
+    if rank != 0:
+        return None
+    assert wavs is not None and len(wavs) == n_utts and all(w.numel() == n for w, n in zip(wavs, lengths))
+    assert all(torch.isfinite(w).all() and float(w.std()) > 1e-3 for w in wavs), "dead or non-finite waveform in the job"
+    true_total = sum(lengths)
+    wall = max(r[4] for r in rows)
+    t_loc = [r[2] for r in rows]
+    return {"workload": f"{name}: {describe(kw)}", "utterances": n_utts, "audio_s_24k": round(true_total / 24000.0, 1),
+            "scheduler": f"lpt_assign over {world} rank(s) + packed slots ({sharding.packed_group_size(model)} per GPU)", "scaling": "strong",
+            "kSamples_per_s": round(true_total / wall / 1e3, 1), "wall_s": round(wall, 3),
+            "x_real_time_24k_whole_job": round(true_total / 24000.0 / wall, 2),
+            "per_rank": {"utterances": [int(r[5]) for r in rows], "true_samples": [int(r[0]) for r in rows], "slot_steps_incl_padding": [int(r[1]) for r in rows],
+                         "synthesis_s": [round(x, 3) for x in t_loc], "gather_s": [round(r[3], 4) for r in rows]},
+            "imbalance_true_samples": round(max(r[0] for r in rows) / (true_total / world), 4),
+            "imbalance_synthesis_time": round(max(t_loc) / (sum(t_loc) / world), 4),
+            "padding_loss": round(1.0 - true_total / max(sum(r[1] for r in rows), 1.0), 4),
+            "broadcast_weights_s": None if t_bcast is None else round(t_bcast, 4),
+            "collectives": None if dist is None else "broadcast (weights, rank 0 -> all), barrier x2, gather_object (waveforms -> rank 0), all_gather (report)"}
 
 
 def rank_report(dist, dev, kernel_ms, last_kernel):
@@ -526,6 +612,10 @@ def main():
                     help="run the distributed leg even with ONE rank: init_process_group('nccl') = RCCL with world size 1, both barriers, "
                          "the MAX all_reduce, the all_gather of the rank report and (job mode) the gather_object -- what a multi-GPU "
                          "launch executes, on one GPU (tests/test_gpu_zz_boundary.py)")
+    ap.add_argument("--no-strong-jobs", dest="strong_jobs", action="store_false",
+                    help="skip the two strong-scaled BASELINE jobs (configs[3] / configs[4]) that follow the timed batch")
+    ap.add_argument("--strong-utts", default="64,128",
+                    help="utterances of the two strong-scaled jobs (BASELINE: 64,128); another value also runs them under --no-extras (tests)")
     ap.add_argument("--no-extras", action="store_true",
                     help="only the timed steps (no throughput_mode, no cpu_baseline): what the rocprofv3 summaries are taken with")
     args = ap.parse_args()
@@ -601,6 +691,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ranks = rank_report(dist, dev, sum(kern_ms) / len(kern_ms), eng.last_kernel())
+    dinfo = dist_info(dist, world, args, dev)             # (every rank: it holds an all_reduce)
+    # THE STRONG-SCALED JOBS of BASELINE.json (configs[3]: 64 utterances, configs[4]: 128) behind the weak-scaled batch: the weak line grows
+    # ~N-fold by construction, these say what N GPUs do to ONE job (VERDICT r05 next #6a).  Every rank takes part; skipped with --no-extras.
+    strong = None
+    n3, n4 = (int(x) for x in args.strong_utts.split(","))
+    if args.strong_jobs and args.batch == B_PER_GPU and args.workload == WORKLOAD and (not args.no_extras or args.strong_utts != "64,128"):
+        strong = []
+        for jname, jn in (("cfg3b_gaussian30", n3), ("cfg4_mol_multispeaker", n4)):
+            try:
+                strong.append(strong_job(jname, jn, dev, dist, world, rank))
+            except Exception as e:                        # (a single process only: with a process group a rank must not leave the others waiting)
+                if dist is not None:
+                    raise
+                strong.append({"workload": jname, "error": str(e)[:160]})
 
     if rank == 0:
         total_samples = world * B * T * args.steps
@@ -663,7 +767,8 @@ def main():
                                  "model_ideal": "as above with the chain phase priced at the fp32 FMA peak alone (0.107 us): what rounds 3-4 reported",
                                  "floor_us_per_step_hop2_0p444": round(floor_hop2, 3), "frac_hop2_0p444": round(floor_hop2 / us_step, 4)},
             "ranks": ranks,
-            "distributed": dist_info(dist, world, args),
+            "distributed": dinfo,
+            "strong_scaled_jobs": strong,
         }
         if world == 1 and args.batch == B_PER_GPU and args.workload == WORKLOAD and not args.no_extras:
             # informative only (not `value`): the same kernel with 48 utterances per GPU -- the rings pipeline six

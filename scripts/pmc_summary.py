@@ -28,6 +28,28 @@ if "FETCH_SIZE" in res:
 if "TCC_HIT_sum" in res and "TCC_MISS_sum" in res:
     h, m = res["TCC_HIT_sum"]["mean_per_launch"], res["TCC_MISS_sum"]["mean_per_launch"]
     summary["l2_hit_rate"] = h / (h + m) if h + m else None
+# ---- the issue side (round 6): shares of WAVE time.  SQ_WAVE_CYCLES = cycles summed over resident waves (a persistent workgroup holds 8
+#      waves for the whole launch); SQ_WAIT_INST_ANY = of those, cycles a wave spent waiting for an instruction to issue or complete
+#      (s_waitcnt, s_barrier, s_sleep and the polls' round trips all land here); SQ_ACTIVE_INST_VALU = cycles the VALU worked for a wave.
+def m(n):
+    return res[n]["mean_per_launch"] if n in res else None
+wc = m("SQ_WAVE_CYCLES")
+if wc:
+    issue = {}
+    if m("SQ_WAIT_INST_ANY") is not None:
+        issue["wave_time_waiting_share"] = m("SQ_WAIT_INST_ANY") / wc
+    if m("SQ_ACTIVE_INST_ANY") is not None:
+        issue["wave_time_issuing_share"] = m("SQ_ACTIVE_INST_ANY") / wc
+    if m("SQ_ACTIVE_INST_VALU") is not None:
+        issue["wave_time_valu_busy_share"] = m("SQ_ACTIVE_INST_VALU") / wc
+    if m("SQ_INSTS_VALU") and m("SQ_INSTS_VMEM_RD") is not None:
+        issue["valu_insts_per_vmem_read"] = m("SQ_INSTS_VALU") / max(m("SQ_INSTS_VMEM_RD"), 1.0)
+    for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM", "SQ_INSTS_LDS", "SQ_WAVES"):
+        if m(k) is not None:
+            issue[k.lower() + "_per_launch"] = m(k)
+    if m("SQ_LDS_IDX_ACTIVE") is not None and m("SQ_BUSY_CYCLES"):
+        issue["lds_active_over_sq_busy"] = m("SQ_LDS_IDX_ACTIVE") / m("SQ_BUSY_CYCLES")
+    summary["issue_side"] = issue
 print(json.dumps(summary, indent=1))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 json.dump(summary, open(os.path.join(out, "traffic.json"), "w"), indent=1)

@@ -300,3 +300,26 @@ def test_bench_distributed_leg_runs_on_rccl_with_one_rank(extra):
     assert j["ranks"]["last_kernel_by_rank"] == ["ring"], j["ranks"]
     if extra:
         assert j["job"]["utterances"] == 6 and "gather_object" in j["distributed"]["collectives"]
+
+
+def test_bench_strong_scaled_jobs_broadcast_and_gather_on_rccl_with_one_rank():
+    """behind the weak-scaled batch `bench.py --gpus N` runs BASELINE configs[3] / configs[4] as STRONG-scaled jobs
+    (here scaled down to 6 and 8 utterances): sharding.broadcast_weights and sharding.gather_results execute on RCCL (a process group of one
+    rank), the line carries per-rank true samples, slot-steps, synthesis and gather seconds and the imbalance of both, and it asserts that
+    the all_reduce over the communicator saw exactly --gpus ranks."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "1", "--no-extras",
+           "--T", "2048", "--strong-utts", "6,8"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, f"rc {r.returncode}\n{r.stdout[-1500:]}\n{r.stderr[-3000:]}"
+    j = json.loads(lines[0])
+    assert j["distributed"]["backend"] == "nccl" and j["distributed"]["ranks_seen"] == 1 == j["n_gpus"]
+    jobs = j["strong_scaled_jobs"]
+    assert [x["utterances"] for x in jobs] == [6, 8] and all(x["scaling"] == "strong" for x in jobs)
+    for x in jobs:
+        assert x["kSamples_per_s"] > 0 and x["broadcast_weights_s"] is not None and "broadcast" in x["collectives"] and "gather_object" in x["collectives"]
+        pr = x["per_rank"]
+        assert len(pr["true_samples"]) == 1 and pr["utterances"] == [x["utterances"]] and pr["synthesis_s"][0] > 0 and pr["gather_s"][0] >= 0
+        assert x["imbalance_true_samples"] == 1.0 and x["imbalance_synthesis_time"] == 1.0 and 0.0 <= x["padding_loss"] < 0.6
+
