@@ -758,13 +758,16 @@ def main():
             "roofline_hbm": {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(ach / HBM_PEAK_GBS, 5),
                              "note": "for reference only: the sample loop does not stream from HBM (traffic << algorithmic bytes)"},
-            "roofline_latency": {"bound": "serial chain latency", "floor_us_per_step": round(floor_meas, 3), "achieved_us_per_step": round(us_step, 3),
-                                 "frac": round(floor_meas / us_step, 4),
-                                 "model": f"MEASURED constants (profiles/r05_latency_constants.json): stages on the chain x (best same-XCD CU->CU hop {hop_meas} us "
-                                          f"[ubench_hop4] + best isolated chain phase {phase_meas} us [scripts/ubench_phase.hip: barrier, LDS read, 256x128 "
-                                          "mat-vec, reduce, gate, store]) + head (2 hops + KxK and OxK mat-vecs at the FMA peak)",
-                                 "floor_us_per_step_ideal": round(floor, 3), "frac_ideal": round(floor / us_step, 4),
-                                 "model_ideal": "as above with the chain phase priced at the fp32 FMA peak alone (0.107 us): what rounds 3-4 reported",
+            "roofline_latency": {"bound": "serial chain latency", "floor_us_per_step": round(floor, 3), "achieved_us_per_step": round(us_step, 3),
+                                 "frac": round(floor / us_step, 4),
+                                 "model": "HARDWARE constants (what rounds 3-4 reported; comparable across rounds): stages on the chain x (best same-XCD CU->CU hop "
+                                          "0.276 us [ubench_hop4] + the chain phase's 256x128 mat-vec at the CU's fp32 FMA peak, 0.107 us) + head (2 hops + KxK and "
+                                          "OxK mat-vecs at the FMA peak)",
+                                 "floor_us_per_step_measured_phase": round(floor_meas, 3), "frac_vs_measured_phase": round(floor_meas / us_step, 4),
+                                 "model_measured_phase": f"the same with the chain phase priced at this implementation's own best isolated phase, {phase_meas} us "
+                                          f"[scripts/ubench_phase.hip: barrier, LDS read, 256x128 mat-vec, reduce, gate, store; hop {hop_meas} us; "
+                                          "profiles/r05_latency_constants.json] -- NOT a roofline (circular: built from the implementation's own phase), "
+                                          "it says how much of the step is outside hop + phase",
                                  "floor_us_per_step_hop2_0p444": round(floor_hop2, 3), "frac_hop2_0p444": round(floor_hop2 / us_step, 4)},
             "ranks": ranks,
             "distributed": dinfo,

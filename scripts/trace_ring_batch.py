@@ -9,10 +9,11 @@ if not os.path.exists(raw) or os.environ.get("RUN", "1") == "1":
     import torch
     from tests._configs import build, inputs
     B, T = int(os.environ.get("B", 64)), 4096
-    m = build("cfg2_mol").to("cuda")
+    NAME = os.environ.get("NAME", "cfg2_mol")
+    m = build(NAME).to("cuda")
     eng = m._get_engine()
-    c, _ = inputs("cfg2_mol", B, T)
-    eng.generate(B=B, T=T, c_up=eng.upsample(c.cuda(), T_expected=T), seed=1, kernel=2)
+    c, gid = inputs(NAME, B, T)
+    eng.generate(B=B, T=T, c_up=eng.upsample(c.cuda(), T_expected=T), g_ids=None if gid is None else gid[:, 0].cuda(), seed=1, kernel=2)
     torch.cuda.synchronize()
 rows = {}
 for l in open(raw):
@@ -38,3 +39,11 @@ h = [rows[(j, t, S)] for j in range(upr)]
 print("head (ns after its first send of the step):", [[x - h[0][0] if x >= 0 else None for x in hv[:5]] for hv in h])
 per = [rows[(0, b, S)][0] - rows[(0, a, S)][0] for a, b in zip(steps, steps[1:])]
 print("step period:", per)
+# head of ring 0, per utterance of the traced step: 1 skip sum in LDS | 3 hidden layer in LDS | 4 head outputs in LDS | 2 step done | 0 input of the next step sent
+hn = {1: "skip sum", 3: "hidden", 4: "outputs", 2: "done", 0: "sent"}
+print(f"head, step {t}: per utterance (ns after utterance 0's skip sum)")
+hb = rows[(0, t, S)][1]
+for j in range(upr):
+    v = rows[(j, t, S)]
+    v1 = rows.get((j, t + 1, S))
+    print(f"  utt {j}: " + " | ".join(f"{hn[k]} {v[k] - hb if v[k] >= 0 else None}" for k in (1, 3, 4, 2)) + (f" | next input sent {v1[0] - hb}" if v1 and v1[0] >= 0 else ""))

@@ -175,7 +175,7 @@ def test_packed_one_hot_job_as_classes_and_through_the_post_chain():
     st_a, st_b = {}, {}
     onehot = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=8, stats=st_a)
     classes = sharding.synthesize_packed(m, mels, hop_size=HOP, cin_pad=2, slots=3, seed=8, stats=st_b, as_index=True)
-    assert st_b["step_bytes"] * 20 < st_a["step_bytes"] * 6                                   # (80 + 1 + 2 against 80 + 256 + 2 floats per slot-step)
+    assert st_b["step_bytes"] * 5 < st_a["step_bytes"] * 2                                    # (2 x 80 + 2 + 2 against 2 x 80 + 256 + 2 floats per slot-step)
     hp = synthesis.default_hparams()
     hp.input_type, hp.quantize_channels = "mulaw-quantize", 256
     for a, b in zip(onehot, classes):

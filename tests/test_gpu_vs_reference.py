@@ -99,10 +99,11 @@ def test_free_run_from_the_default_first_input_vs_reference(name):
 
 
 @pytest.mark.parametrize("name,B,Tt,T", [("cfg2_mol", 48, 96, 256), ("cfg1_mulaw256", 40, 40, 256), ("cfg4_mol_multispeaker", 16, 160, 256),
-                                         ("cfg3b_gaussian30", 14, 96, 256)])
+                                         ("cfg3b_gaussian30", 14, 96, 256), ("cfg4_mol_multispeaker", 40, 40, 256)])
 def test_ring_throughput_instantiation_vs_reference(name, B, Tt, T):
     """MODE 1 of wnv_ring_kernel (csrc/wnv_ring.hip: more than four utterances per ring -- six at 48 utterances, five at 40 --, K = 512
-    from two per ring; the 30-layer wording runs 7 rings, two utterances each at 14) against the reference itself."""
+    from two per ring; the 30-layer wording runs 7 rings, two utterances each at 14; K = 512 at 40: five per ring) against the
+    reference itself."""
     d = case(name, B, Tt, T, seed=13)
     out, params, idx, ran = run_hip(d, 2)
     assert ran == 2

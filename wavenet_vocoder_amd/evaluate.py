@@ -161,9 +161,11 @@ def synthesize_dir(model, data_dir: str, dst_dir: str, hparams, *, num_utterance
     if packed:
         try:
             local = _packed_local(model, mels, hparams, mine, spk)
-        except (NotImplementedError, TimeoutError, RuntimeError) as e:   # not a ring configuration / the ring does not fit / out of
-            # memory (torch.cuda.OutOfMemoryError is a RuntimeError): THIS rank runs its share as padded groups -- neither path holds a
-            # collective, the one gather below is reached by every rank whichever path it took
+        except (NotImplementedError, TimeoutError, torch.cuda.OutOfMemoryError) as e:   # not a ring configuration (WNV_ERR_UNSUPPORTED) /
+            # the ring does not fit or gave up waiting (WNV_ERR_TIMEOUT) / out of memory: THIS rank runs its share as padded groups --
+            # neither path holds a collective, the one gather below is reached by every rank whichever path it took.  Anything else (an
+            # invalid argument, a HIP fault, a bug in the segment maps) propagates: it would be masked by a silent re-run, and a job
+            # must not mix packed and padded waveforms for one seed without the caller hearing about it.
             print(f"[wnv] rank {rank}: packed slots not used ({type(e).__name__}: {str(e)[:160]}); falling back to padded groups", flush=True)
             local = None
             if torch.cuda.is_available():

@@ -276,7 +276,10 @@ def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin
     cin = int(mels[idx[0]].shape[0])
     as_index = bool(as_index) and not eng.cfg.scalar_input
     c_out = 1 if (eng.cfg.scalar_input or as_index) else int(eng.cfg.out_channels)
-    step_bytes = 4 * (cin + c_out + 2 + (1 if has_spk else 0) + (int(eng.cfg.out_channels) if params_out is not None else 0))
+    # resident bytes per slot-step of a launch: conditioning row, output (as_index: the int32 classes AND their float32 copy for the
+    # post-chain, both alive at once), the two segment maps (+ the speaker map), the head outputs when asked for; the per-utterance
+    # upsampler output is one utterance at a time (<= a slot's worth of conditioning: one more cin per step covers it)
+    step_bytes = 4 * (2 * cin + (2 if as_index else c_out) + 2 + (1 if has_spk else 0) + (int(eng.cfg.out_channels) if params_out is not None else 0))
     steps_cap = max(hop_size, min(int(max_slot_steps), int(max_launch_bytes) // (n_slots * step_bytes)))
     lengths_all = [int(mels[i].shape[-1]) * hop_size for i in idx]
     launches = plan_launches(lengths_all, n_slots, steps_cap)
