@@ -109,3 +109,29 @@ def test_packed_directory_loop_keeps_the_references_sanity_check(tmp_path):
     (tmp_path / "train.txt").write_text("a|u0-feats.npy|3|t|1\nb|u1-feats.npy|3|t|2\n")
     with pytest.raises(RuntimeError, match="expects no speaker embedding"):
         E.synthesize_dir(build("cfg2_mol"), str(tmp_path), str(tmp_path / "o"), h, packed=True)
+
+
+def test_packed_fallback_is_for_unsupported_timeout_and_oom_only(tmp_path, monkeypatch, capsys):
+    """A rank whose packed run cannot proceed re-runs its share as padded groups -- but only for what "cannot proceed" means: the ring does
+    not take the configuration (NotImplementedError = WNV_ERR_UNSUPPORTED), it gave up waiting (TimeoutError = WNV_ERR_TIMEOUT), or the
+    launch's buffers did not fit (OutOfMemoryError).  Anything else -- an invalid argument, a HIP fault, a bug in the segment maps -- reaches
+    the caller (the blanket RuntimeError catch masked real faults and could mix packed and padded waveforms under one seed)."""
+    make_dump(tmp_path)
+    hp = SimpleNamespace(cin_channels=80, hop_size=256, cin_pad=2, batch_size=2, sample_rate=24000)
+
+    def fake_synth(c, idx):
+        B, _, F = c.shape
+        return torch.zeros(B, (F - 2 * hp.cin_pad) * hp.hop_size)
+
+    def fault(*a, **k):
+        raise RuntimeError("HIP fault in the packed launch")
+    monkeypatch.setattr(E, "_packed_local", fault)
+    with pytest.raises(RuntimeError, match="HIP fault"):
+        E.synthesize_dir(None, str(tmp_path), str(tmp_path / "o1"), hp, synth_group=fake_synth, packed=True)
+    for exc in (NotImplementedError("packed slots: not a ring configuration"), TimeoutError("ring kernel gave up waiting"),
+                torch.cuda.OutOfMemoryError("out of memory")):
+        def refuse(*a, _e=exc, **k):
+            raise _e
+        monkeypatch.setattr(E, "_packed_local", refuse)
+        paths = E.synthesize_dir(None, str(tmp_path), str(tmp_path / "o2"), hp, synth_group=fake_synth, packed=True)
+        assert len(paths) == 5 and "falling back to padded groups" in capsys.readouterr().out

@@ -233,7 +233,7 @@ def packed_unsupported_reason(model) -> Optional[str]:
 
 def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin_pad: int, slots: Optional[int] = None,
                       seed: Optional[int] = None, indices: Optional[Sequence[int]] = None, stats: Optional[dict] = None,
-                      max_slot_steps: int = 1 << 20, max_launch_bytes: int = 12 << 30, params_out: Optional[list] = None,
+                      max_slot_steps: int = 1 << 20, max_launch_bytes: int = 32 << 30, params_out: Optional[list] = None,
                       speaker_ids: Optional[Sequence[int]] = None,
                       sink: Optional[Callable[[int, torch.Tensor], None]] = None, as_index: bool = False) -> List[Optional[torch.Tensor]]:
     """The waveforms (network outputs ``(C, T_i)`` on the model's device, one per mel of ``mels[i] for i in indices``) of a job run as
@@ -249,8 +249,10 @@ def synthesize_packed(model, mels: Sequence[torch.Tensor], *, hop_size: int, cin
     the launch then carries 4 bytes of output per slot-step instead of 4 C (1 KB for a 256-way model: a job of 100 utterances needed two
     launches of half-empty slots under the byte bound), and ``synthesis.postprocess`` takes them as they are.
     One launch is bounded by ``max_slot_steps`` steps per slot AND by ``max_launch_bytes`` of resident per-step buffers -- the slots'
-    conditioning (``cin`` floats per step), the output (``C`` floats per step: 1 KB for a 256-way one-hot model) and the maps; a longer
-    job runs as several launches.  An utterance's waveform does not depend on any of this: its conditioning is upsampled on its own
+    conditioning (``cin`` floats per step, and as much again for the upsampler's output of the utterance being placed), the output (``C``
+    floats per step: 1 KB for a 256-way one-hot model; ``as_index``: the int32 classes and their float copy) and the maps; a longer job runs
+    as several launches.  The default byte bound is 32 GiB of the GPU's 288 GB: 48 slots of egs/mol may run 2^20 steps (43 s of audio) each --
+    with 12 GiB (round 5) and the honest byte count of round 6 a job of 200 utterances split into two launches and lost 5 % to padding.  An utterance's waveform does not depend on any of this: its conditioning is upsampled on its own
     (what ``incremental_forward`` gives for the utterance alone, its edges replicate-padded as evaluate.py:163-164 does for a batch of
     one), its noise stream is (utterance id, step within the utterance)."""
     why = packed_unsupported_reason(model)
