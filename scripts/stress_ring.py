@@ -8,12 +8,12 @@ eng = m._get_engine()
 def cond(B, T, seed=0):
     return torch.randn(B, T, 80, generator=torch.Generator().manual_seed(seed)).cuda()
 t0 = time.time()
-for B in list(range(1, 18)) + [24, 32]:
+for B in list(range(1, 18)) + [24, 32, 40, 47, 48, 56, 64, 72]:      # (round 6: the throughput instantiation's batch sizes too; 72 = two launches)
     T = 1500 + 13 * B
     out, _, _ = eng.generate(B=B, T=T, c_up=cond(B, T, B), seed=B, kernel=2)
     ref, _, _ = eng.generate(B=B, T=T, c_up=cond(B, T, B), seed=B, kernel=2)
     assert torch.equal(out, ref) and torch.isfinite(out).all(), B
-print(f"batch sizes 1..17, 24, 32: deterministic, finite ({time.time()-t0:.1f} s)")
+print(f"batch sizes 1..17, 24, 32, 40, 47, 48, 56, 64, 72: deterministic, finite ({time.time()-t0:.1f} s)")
 t0 = time.time()
 c = cond(8, 256)
 first = None
