@@ -15,7 +15,12 @@ librosa.filters.mel with htk=False / norm="slaney", librosa.core.convert.hz_to_m
 PARITY UNPINNED against librosa itself (it cannot be run here and the reference's tests hold no vector for this path).
 What pins the restatement (tests/test_mel_cpu.py): the known answers printed in librosa's own docstrings (hz_to_mel(60) = 0.9,
 mel_to_hz(3) = 200, mel_frequencies(n_mels=40) table, filters.mel(sr=22050, n_fft=2048)[0, 1] = 0.016), an independent
-STFT (scipy.signal.stft on the same padded signal), unit filter areas, and scikit-learn's StandardScaler (installed).
+STFT (scipy.signal.stft on the same padded signal), unit filter areas, and scikit-learn's StandardScaler (installed) -- and, since
+round 6 (tests/test_mel_second_source_cpu.py), a SECOND INDEPENDENT SOURCE: Hugging Face transformers.audio_utils (in the image; its
+authors validate it against librosa for the Whisper / SpeechT5 feature extractors): the Slaney mel scale to 1e-12, the Slaney-normalised
+filterbank at four geometries to 2e-9, the whole log-mel at the reference's hparams to 1e-7 (their FFT buffer is complex64), and
+torch.stft as a third STFT to 1e-9.  Not librosa's own output -- the row stays "parity unpinned" -- but two restatements written by
+different people from the same definitions agree.
 """
 import numpy as np
 
