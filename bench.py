@@ -721,6 +721,16 @@ def main():
                 traffic = tj.get("hbm_bytes_per_launch")
                 traffic_src = {k: tj.get(k) for k in ("source", "commit", "kernel_version", "collected_with") if tj.get(k) is not None}
                 traffic_src["note"] = "quoted from a separate rocprofv3 --pmc run (counters cannot be read from inside this process)"
+                # (round 6) where the waves' time goes, from the issue-side counters of the same passes: shares of
+                # SQ_WAVE_CYCLES over the whole launch (all roles together -- the counters are per kernel, not per role; per-role
+                # timelines come from the trace builds' in-kernel stamps, profiles/r0*_timeline.txt)
+                iss = tj.get("issue_side") or {}
+                if iss:
+                    traffic_src["issue_side"] = {"valu_busy_share_of_wave_time": round(iss.get("wave_time_valu_busy_share", 0.0), 4),
+                                                 "issuing_any_instruction_share": round(iss.get("wave_time_issuing_share", 0.0), 4),
+                                                 "valu_insts_per_vmem_read_poll": round(iss.get("valu_insts_per_vmem_read", 0.0), 1),
+                                                 "lds_active_over_sq_busy": round(iss.get("lds_active_over_sq_busy", 0.0), 4),
+                                                 "l2_hit_rate": round(tj.get("l2_hit_rate", 0.0), 4)}
             except Exception:
                 traffic, traffic_src = None, None
         us_step = kdur / T * 1e6
