@@ -540,6 +540,9 @@ __device__ __forceinline__ float fast_gate(float a, float g) {
 #ifndef WNV_TAP_DEFER
 #define WNV_TAP_DEFER 1        // (round 6) tap workgroups: the last publish of a pass is held back behind the next pass's [B] and barrier (run_tap)
 #endif
+#ifndef WNV_TAP_ZLDS
+#define WNV_TAP_ZLDS 1         // (round 6) tap workgroups of the packed instantiations: the bias rows of a pass come through LDS (run_tap)
+#endif
 #ifndef WNV_SKIP_DIRECT
 #define WNV_SKIP_DIRECT 1      // K = 512: every stage hands its own skip term to the head parts (head_sum_skip_terms)
 #endif
@@ -716,17 +719,19 @@ struct TapLds {
     int* flags;      // [32]: 0 = give-up flag; 8 + buf * TB + u = packed slots: bias row (seg_gid) of utterance u of the pass whose inputs are in buffer buf
     float4* wl;      // [8 waves][klds_rows][64 lanes] LDS-resident rows
     float2* dv;      // [512] the held-back publish of a pass's last round (round 6: parked here, not in registers -- the tap role has none to spare)
+    float* zl;       // [2][TB][256] (round 6, WNV_TAP_ZLDS) the effective conv bias row of every utterance of a pass, fetched with the pass's inputs
 };
 __device__ __forceinline__ TapLds carve_tap(float* smem, const RingParams& p) {
     TapLds s;
     s.xin = smem;
     s.flags = reinterpret_cast<int*>(smem + (size_t)2 * TB * RW * p.kper);
     s.dv = reinterpret_cast<float2*>(s.flags + 32);
-    s.wl = reinterpret_cast<float4*>(s.dv + RT);
+    s.zl = reinterpret_cast<float*>(s.dv + RT);
+    s.wl = reinterpret_cast<float4*>(s.zl + 2 * TB * GC);
     return s;
 }
 __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
-    return (size_t)2 * TB * RW * kper + 32 + 2 * RT + (size_t)RW * klds_rows * 64 * 4;
+    return (size_t)2 * TB * RW * kper + 32 + 2 * RT + (size_t)2 * TB * GC + (size_t)RW * klds_rows * 64 * 4;
 }
 
 // EXPERIMENT BUILDS ONLY (-DWNV_EXP_NOPRE=1|2; results are WRONG on purpose, timing only): 1 = stages and head do not wait for the tap
@@ -892,6 +897,20 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         if (wave < nb_) {
             const int b = b0_ + wave;
             float* xu = s.xin + ((size_t)cur_ * TB + wave) * kx;
+            // (round 6, WNV_TAP_ZLDS) the utterance's effective conv bias row -- b_l + W_g g: per utterance when the model has a speaker
+            // embedding -- is fetched HERE, with the inputs, and handed to the rounds through LDS.  It used to be two global loads per lane at
+            // the top of every round: in round 0 they were issued right behind the next pass's gather DMAs, loads return in order, and the
+            // round's publish waited for the whole gather (history rows from the L2, the conditioning row from HBM).  PACKED instantiations
+            // only: there [B] has a record round trip for the fetch to hide under (no speculative look) and a packed job gains 3.6-4.4 %
+            // (egs/mol 100 utterances 2 292 -> 2 375, cfg4 128 utterances 1 166 -> 1 217 kSamples/s, same box); in the throughput
+            // instantiation, whose speculative look usually hits, the fetch sits in the open in front of the pass's barrier: egs/mol
+            // +0.4 %, mu-law -1.9 %, cfg4 -4 % (profiles/r06_tap_zlds_ab.txt) -- so not there.
+            float4 zrow4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PACKED && WNV_TAP_ZLDS != 0) {
+                size_t zr = (size_t)b;
+                if (PACKED && p.seg_gid) zr = (size_t)uniform_ld(p.seg_gid + (size_t)__builtin_amdgcn_readfirstlane(b) * p.T + tp_);
+                if (4 * lane < p.zb_ld) zrow4 = *reinterpret_cast<const float4*>(p.zbias + (size_t)l * p.zb_ld + zr * p.zbias_bstride + 4 * lane);
+            }
             if (ncin4 == 0) {                                        // cin not a multiple of 4: scalar conditioning row
                 const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
                 for (int e = lane; e < p.cin; e += 64) xu[hoff + e] = cb[e];
@@ -921,6 +940,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
                     }
                 }
             }
+            if constexpr (PACKED && WNV_TAP_ZLDS != 0) *reinterpret_cast<float4*>(s.zl + ((size_t)cur_ * TB + wave) * GC + 4 * lane) = zrow4;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs into buffer cur_ (issued with the gather) have landed
         }
     };
@@ -970,6 +990,13 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
             const bool pub = u0 + pu < nb;                                   // this lane has something to publish in this round
             const int rb = b0 + u0 + pu;
             float zb0 = 0.f, zb1 = 0.f;                                      // the utterance's effective conv bias: requested ahead of the FMAs
+            if constexpr (PACKED && WNV_TAP_ZLDS != 0) {
+                if (pub) {
+                    const float* zq = s.zl + ((size_t)cur * TB + u0 + pu) * GC + zhalf * p.gh + zch;
+                    if (z0) zb0 = zq[0];
+                    if (z1) zb1 = zq[1];
+                }
+            } else
             if (pub) {
                 // (packed slots: the bias row of the utterance that occupies the slot at step tp -- its speaker.  Read here, ahead of the
                 //  FMAs; parked in LDS a pass ahead it cost the packed instantiations 2-4 spilled registers and 3 % -- round 5, measured)
