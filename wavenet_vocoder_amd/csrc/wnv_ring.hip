@@ -710,6 +710,9 @@ __device__ __forceinline__ size_t pre_rec(const RingParams& p, int b, int l, int
 constexpr int KR_MAX = 32;         // K rows per lane slice held in VGPRs (32 float4 = 128 registers)
 constexpr int KL_MAX = 16;         // further K rows per wave held in LDS
 constexpr int KR_PACKED_SPEC = 28; // ... in VGPRs in the packed-slot instantiations that keep the speculative look (run_tap)
+#ifndef WNV_TAP_SPEC1
+#define WNV_TAP_SPEC1 1            // the speculative look in the throughput instantiation's tap role (A/B switch, round 6)
+#endif
 #ifndef WNV_PACKED_SPEC
 #define WNV_PACKED_SPEC 0          // experiment (round 5): the speculative look in the packed tap instantiations, four rows moved to LDS -- still 2-4 spilled registers
 #endif
@@ -2445,14 +2448,14 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
     const int free_slots = (p.rstride - p.n_rings) * P;
     if ((int)blockIdx.x >= p.ring_blocks) {
         const int k = free_slots + (int)blockIdx.x - p.ring_blocks;
-        run_tap<(MODE != 2 || WNV_PACKED_SPEC != 0) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
+        run_tap<(MODE == 0 || (MODE == 1 && WNV_TAP_SPEC1 != 0) || (MODE == 2 && WNV_PACKED_SPEC != 0)) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
         return;
     }
     const int ring = blockIdx.x % p.rstride;
     const int pos = blockIdx.x / p.rstride;
     if (ring >= p.n_rings) {
         const int k = pos * (p.rstride - p.n_rings) + (ring - p.n_rings);
-        if (k < p.tap_parts * p.L) run_tap<(MODE != 2 || WNV_PACKED_SPEC != 0) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
+        if (k < p.tap_parts * p.L) run_tap<(MODE == 0 || (MODE == 1 && WNV_TAP_SPEC1 != 0) || (MODE == 2 && WNV_PACKED_SPEC != 0)) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
         return;
     }
     if (L0 && pos == 0) return;                   // layer 0 is evaluated by the head (run_head)
