@@ -709,12 +709,17 @@ __device__ __forceinline__ size_t pre_rec(const RingParams& p, int b, int l, int
 // pre_l[t+1] back the same way; both trips have a whole step of slack.  The workgroup also owns the history rings.
 constexpr int KR_MAX = 32;         // K rows per lane slice held in VGPRs (32 float4 = 128 registers)
 constexpr int KL_MAX = 16;         // further K rows per wave held in LDS
-constexpr int KR_PACKED_SPEC = 28; // ... in VGPRs in the packed-slot instantiations that keep the speculative look (run_tap)
+#ifndef WNV_KR_PACKED_SPEC
+#define WNV_KR_PACKED_SPEC 32      // (28: round 5's form -- four rows in LDS to make room for the look's registers: 20-40 % slower, profiles/r06_tap_zlds_ab.txt)
+#endif
+constexpr int KR_PACKED_SPEC = WNV_KR_PACKED_SPEC; // ... in VGPRs in the packed-slot instantiations that keep the speculative look (run_tap; an experiment build)
 #ifndef WNV_TAP_SPEC1
 #define WNV_TAP_SPEC1 1            // the speculative look in the throughput instantiation's tap role (A/B switch, round 6)
 #endif
 #ifndef WNV_PACKED_SPEC
-#define WNV_PACKED_SPEC 0          // experiment (round 5): the speculative look in the packed tap instantiations, four rows moved to LDS -- still 2-4 spilled registers
+#define WNV_PACKED_SPEC 1          // the speculative look in the PACKED tap instantiations too (round 6: with the bias rows handed over through LDS -- WNV_TAP_ZLDS --
+                                   // the look's four registers fit next to all 32 register rows, no spill: every packed job +2.5-3.5 %; round 5 had to move four
+                                   // rows to LDS for it and still spilled)
 #endif
 constexpr int TB = 8;              // utterances per pass (one polling wave each; their latencies overlap)
 struct TapLds {
@@ -743,10 +748,10 @@ __host__ __device__ inline size_t tap_lds_floats(int kper, int klds_rows) {
 #ifndef WNV_EXP_NOPRE
 #define WNV_EXP_NOPRE 0
 #endif
-// (SPEC: a speculative look at the next pass's h record, issued with the gather -- four registers live across the mat-vec.  Instantiated
-//  with SPEC = false since the packed-slot masks took the last registers of the capped kernels: it saved one poll round trip per pass
-//  while the tap passes bound the step; now the stages' occupancy does.)
-// (PACKED: the launch runs packed slots -- RingParams::seg_start; a compile-time switch like SPEC: together they spill)
+// (SPEC: a speculative look at the next pass's h record, issued with the gather -- four registers live across the mat-vec: it saves one
+//  poll round trip per pass (+3 % at 40-64 utterances, A/B switch WNV_TAP_SPEC1).  On everywhere but the 256-skip-channel kernels since
+//  round 6; rounds 4-5 had it off in the packed instantiations, where the slot masks and the bias loads had taken the last registers.)
+// (PACKED: the launch runs packed slots -- RingParams::seg_start; a compile-time switch like SPEC)
 // (DEFER: the throughput and packed instantiations hold a pass's last publish back -- see the pass loop; a compile-time switch: the
 //  single-utterance-per-ring kernels never run two passes per workgroup and step at their batch sizes that matter, and the code alone moved
 //  the headline kernel's tap role by 1.4 %)
