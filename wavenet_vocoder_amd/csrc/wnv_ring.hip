@@ -1006,6 +1006,11 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
                 }
             } else
             if (pub) {
+                // (throughput instantiation: these two global loads per lane and round stay.  Round 6 measured both alternatives on one box --
+                //  the row fetched with the pass's inputs and handed over through LDS: egs/mol +0.4 %, mu-law -1.9 %, cfg4 -4 %; ONE copy in LDS
+                //  for the whole launch where no global conditioning makes the row a constant: -3.2 % at 40-64 utterances.  The loads' wait at
+                //  the end of a round is where this wave's earlier write-through publish gets drained, under the other waves' FMAs; without
+                //  it the drain moves into the open in front of the next pass's barrier: profiles/r06_tap_zlds_ab.txt)
                 // (packed slots: the bias row of the utterance that occupies the slot at step tp -- its speaker.  Read here, ahead of the
                 //  FMAs; parked in LDS a pass ahead it cost the packed instantiations 2-4 spilled registers and 3 % -- round 5, measured)
                 const float* zrow = zbase + (size_t)((PACKED && p.seg_gid) ? p.seg_gid[(size_t)rb * p.T + tp] : rb) * p.zbias_bstride;
