@@ -71,3 +71,24 @@ def test_segment_maps_name_the_running_utterance(lengths, n_slots, with_speakers
             assert torch.all(gid[s, off:off + lengths[k]] == speakers[ids[k]])
     t = torch.arange(T).unsqueeze(0)
     assert torch.all(start <= t) and int((start == t).sum()) == len(lengths)
+
+
+def test_the_bench_jobs_fit_one_packed_launch_under_the_default_byte_bound():
+    """Round 6: the honest byte count of a packed launch (conditioning + the upsampler's output of the utterance being placed + output + maps:
+    652 bytes per slot-step for egs/mol) under round 5's 12-GiB bound split bench.py's 200-utterance job into two launches -- 7.6 % padding
+    instead of 2.5 %, 5 % slower.  The default bound is 32 GiB of the GPU's 288 GB: that job, and a 400-utterance one, are ONE launch of 48
+    slots; what bounds a launch then is max_slot_steps (2^20 steps per slot)."""
+    import inspect
+    from wavenet_vocoder_amd import sharding
+    sig = inspect.signature(sharding.synthesize_packed)
+    max_bytes, max_steps = sig.parameters["max_launch_bytes"].default, sig.parameters["max_slot_steps"].default
+    assert max_bytes == 32 << 30 and max_steps == 1 << 20
+    step_bytes = 4 * (2 * 80 + 1 + 2)                                     # egs/mol: scalar output, no speaker map (sharding.synthesize_packed)
+    for n_utts, want_launches in ((200, 1), (400, 1)):
+        gen = torch.Generator().manual_seed(2024)                          # bench.py job_inputs: 1.0 .. 8.0 s at 24 kHz, hop 256
+        lengths = [f * 256 for f in torch.randint(94, 751, (n_utts,), generator=gen).tolist()]
+        cap = max(256, min(max_steps, max_bytes // (48 * step_bytes)))
+        launches = sharding.plan_launches(lengths, 48, cap)
+        assert len(launches) == want_launches
+        worst = max(sum(lengths[m[k]] for k in b) for m in launches for b in sharding.plan_slots([lengths[k] for k in m], 48))
+        assert worst <= cap and 48 * worst * step_bytes <= max_bytes
