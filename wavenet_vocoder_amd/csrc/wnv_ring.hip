@@ -492,6 +492,9 @@ __device__ __forceinline__ void ts_flush(const RingParams& p, int b, int t, int 
 #ifndef WNV_TRACE_TAP_LAYER
 #define WNV_TRACE_TAP_LAYER 6           // the tap workgroup whose passes are stamped (6: dilation 1 in the 24-layer models)
 #endif
+#ifndef WNV_TRACE_TAP_WAVE
+#define WNV_TRACE_TAP_WAVE 0            // ... and the wave of it that stamps (round 6: the waves of a SIMD do not finish a round together)
+#endif
 #define WNV_TS(k) (tsv[k] = __builtin_amdgcn_s_memrealtime())
 // the less important stamps: every live stamp is an SGPR pair in a kernel that has none to spare (with all of them the trace build
 // spills vector registers in its hot loops and runs 25 % slower than the product): -DWNV_FINE_TRACE=2 turns them on
@@ -891,7 +894,7 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
     }
 #ifdef WNV_FINE_TRACE
 #define TAP_STAMP(k) do { const int pk_ = (b0 - bfirst) / pstride; \
-                          if (p.trace_tap && l == WNV_TRACE_TAP_LAYER && part == 0 && pk_ < 3 && (k) < 5 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
+                          if (p.trace_tap && l == WNV_TRACE_TAP_LAYER && part == 0 && pk_ < 3 && (k) < 5 && tid == 64 * WNV_TRACE_TAP_WAVE && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
                               p.trace_tap[(size_t)(t - p.trace_t0) * TRW + 5 * pk_ + (k)] = wall_clock64(); } while (0)
 #else
 #define TAP_STAMP(k) ((void)0)
@@ -926,6 +929,9 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
             if (tf_ >= 0) {
                 const unsigned htag = p.tag_base + (unsigned)tf_ + 1u;
                 float hv[2] = {__uint_as_float((unsigned)hx0), __uint_as_float((unsigned)hx1)};         // channels 2 lane, 2 lane + 1
+#ifdef WNV_FINE_TRACE
+                if (lane == 0) s.flags[24 + wave] = 0;                 // (trace: how this wave got its record -- 0 look, 1 direct look, 2 patient receive)
+#endif
                 if (!__all((unsigned)(hx0 >> 32) == htag && (unsigned)(hx1 >> 32) == htag)) {
                     // (round 6) ONE direct look at the whole record first: while the stages pace the passes the record lands during the pass
                     // before -- behind the speculative look, ahead of this one -- and the patient receive (first granule at a relaxed cadence,
@@ -934,6 +940,9 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
                     const u64* rec = p.fmail + h_rec(p, b, l, tf_);
                     const u4v x = ld16_sc1(rec + 2 * lane);
                     hv[0] = __uint_as_float(x.x); hv[1] = __uint_as_float(x.z);
+#ifdef WNV_FINE_TRACE
+                    if (lane == 0) s.flags[24 + wave] = __all(x.y == htag && x.w == htag) ? 1 : 2;
+#endif
                     if (!__all(x.y == htag && x.w == htag)) {
                         if (!rec_recv<1>(rec, htag, hv, p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
                     }
@@ -972,6 +981,17 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
         __syncthreads();                                             // the inputs of pass (t, b0) are complete in buffer cur
         if (s.flags[0]) return;
         TAP_STAMP(2);
+#ifdef WNV_FINE_TRACE
+        {   // slot 15 of the row: two bits per wave and pass -- how each wave got its record
+            const int pk_ = (b0 - bfirst) / pstride;
+            if (p.trace_tap && l == WNV_TRACE_TAP_LAYER && part == 0 && pk_ < 3 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) {
+                unsigned long long m = 0;
+                for (int w = 0; w < 8; ++w) m |= (unsigned long long)(s.flags[24 + w] & 3) << (2 * w);
+                unsigned long long* q = p.trace_tap + (size_t)(t - p.trace_t0) * TRW + 15;
+                *q = (pk_ == 0 ? 0ull : *q) | (m << (16 * pk_));
+            }
+        }
+#endif
         if (dbase >= 0 && du0 + pu < dnb) {                             // the deferred publish of the pass before (see above the loop)
             const float2 dvv = s.dv[tid];
             st_granule2(p.pmail + pre_rec(p, dbase + du0 + pu, l, dtp) + po, p.tag_base + (unsigned)dtp + 1u, dvv.x, dvv.y, false);
@@ -3180,6 +3200,8 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
                 fprintf(f, "#tap %d", p.trace_t0 + tt);
                 for (int k = 0; k < TRW; ++k) {
                     const unsigned long long v = tr[(size_t)trace_n * upr * (st->S + 1) * TRW + (size_t)tt * TRW + k];
+                    if (k == 15) fprintf(f, " %lld", (long long)v);      // (not a stamp: two bits per wave and pass -- how each wave got its h record)
+                    else
                     fprintf(f, " %lld", v ? (long long)(v - t00) * 10 : -1LL);
                 }
                 fprintf(f, "\n");
