@@ -290,6 +290,96 @@ void run_mf() {
     printf("\n");
 }
 
+// ---- VAR 11: a PASS OF SIXTEEN utterances on the matrix pipe.  v_mfma_f32_16x16x4_f32: A[i = lane % 16][k = lane / 16], B[k = lane / 16][j = lane % 16],
+// D register v of a lane = D[i = 4 (lane / 16) + v][j = lane % 16].  A wave's 32 output rows = two tiles; K = 336 = 21 groups of 16: lane (n, kq)
+// reads x[n][16 J + 4 kq .. + 3] with ONE ds_read_b128 and feeds four MFMAs per tile with it (MFMA (J, i) sums k = 16 J + 4 kq' + i over kq').
+// Weights: 16 groups in registers (128), 5 groups as 10 float4 per lane in LDS -- the legacy form's split.  Per wave and pass of 16 utterances:
+// 168 MFMAs (32 clocks each) + 31 ds_read_b128, against 4 x (352 v_pk_fma_f32 + 56 ds_read_b128) for the same sixteen utterances today.
+constexpr int NJ = 21, NJR = 16, KX16 = 388;
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(244))) kmf16(const float* Wkm, const float* x, float* out, u64* cyc, int passes) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xin = smem;                                           // [16][KX16]
+    float4* wl = reinterpret_cast<float4*>(smem + 16 * KX16);   // [8 waves][(NJ - NJR) * 2][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < 16 * KX16; i += blockDim.x) xin[i] = (i % KX16) < 336 ? x[((i / KX16) & 7) * 336 + (i % KX16)] * (1.f + (float)((i / KX16) >> 3)) : 0.f;
+    float A[NJR][2][4];
+    auto wk = [&](int J, int tile, int i) { return Wkm[(size_t)(16 * J + 4 * kq + i) * 256 + 32 * wave + 16 * tile + n]; };
+#pragma unroll
+    for (int J = 0; J < NJR; ++J)
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[J][tl][i] = wk(J, tl, i);
+    for (int J = NJR; J < NJ; ++J)
+        for (int tl = 0; tl < 2; ++tl) wl[((size_t)wave * (NJ - NJR) * 2 + (J - NJR) * 2 + tl) * 64 + lane] = make_float4(wk(J, tl, 0), wk(J, tl, 1), wk(J, tl, 2), wk(J, tl, 3));
+    __syncthreads();
+    float sink = 0.f;
+    f4 first[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const u64 t0 = wall_clock64();
+    for (int it = 0; it < passes; ++it) {
+        const float* xr = xin + (size_t)n * KX16 + 4 * kq;
+        f4 d[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        float4 xv = *reinterpret_cast<const float4*>(xr), w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+#pragma unroll
+        for (int J = 0; J < NJ; ++J) {
+            float4 xn = xv, n0 = w0, n1 = w1;
+            if (J + 1 < NJ) {
+                xn = *reinterpret_cast<const float4*>(xr + 16 * (J + 1));
+                if (J + 1 >= NJR) { n0 = wl[((size_t)wave * (NJ - NJR) * 2 + (J + 1 - NJR) * 2) * 64 + lane]; n1 = wl[((size_t)wave * (NJ - NJR) * 2 + (J + 1 - NJR) * 2 + 1) * 64 + lane]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const float a0[4] = {J < NJR ? A[J < NJR ? J : 0][0][0] : w0.x, J < NJR ? A[J < NJR ? J : 0][0][1] : w0.y, J < NJR ? A[J < NJR ? J : 0][0][2] : w0.z, J < NJR ? A[J < NJR ? J : 0][0][3] : w0.w};
+            const float a1[4] = {J < NJR ? A[J < NJR ? J : 0][1][0] : w1.x, J < NJR ? A[J < NJR ? J : 0][1][1] : w1.y, J < NJR ? A[J < NJR ? J : 0][1][2] : w1.z, J < NJR ? A[J < NJR ? J : 0][1][3] : w1.w};
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i], xs[i], d[0], 0, 0, 0);
+                d[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i], xs[i], d[1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            xv = xn; w0 = n0; w1 = n1;
+        }
+        if (it == 0) { first[0] = d[0]; first[1] = d[1]; }
+        sink += d[0].x + d[0].w + d[1].y + d[1].z;
+        asm volatile("" : "+v"(sink));
+    }
+    const u64 t1 = wall_clock64();
+    for (int tl = 0; tl < 2; ++tl) for (int v = 0; v < 4; ++v) out[n * 256 + 32 * wave + 16 * tl + 4 * kq + v] = first[tl][v];
+    out[16 * 256 + tid] = sink;
+    if (lane == 0) cyc[wave] = t1 - t0;
+}
+void run_mf16() {
+    std::vector<float> W((size_t)336 * 256), x((size_t)8 * 336);
+    for (size_t i = 0; i < W.size(); ++i) W[i] = 0.01f * (float)((i * 2654435761u) % 101) - 0.5f;
+    for (size_t i = 0; i < x.size(); ++i) x[i] = 0.02f * (float)((i * 40503u) % 89) - 0.8f;
+    float *dW, *dx, *out; u64* cyc;
+    CK(hipMalloc(&dW, W.size() * 4)); CK(hipMalloc(&dx, x.size() * 4)); CK(hipMalloc(&out, 8192 * 4)); CK(hipMalloc(&cyc, 64));
+    CK(hipMemcpy(dW, W.data(), W.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice));
+    const size_t lds = ((size_t)16 * KX16 + (size_t)8 * (NJ - NJR) * 2 * 64 * 4) * sizeof(float);
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kmf16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    printf("VAR 11 (v_mfma_f32_16x16x4_f32, a pass of SIXTEEN utterances: 168 MFMAs + 31 ds_read_b128 per wave):");
+    const int passes = 1000;
+    for (int nw : {4, 8}) {
+        CK(hipMemset(out, 0, 8192 * 4));
+        hipLaunchKernelGGL(kmf16, dim3(1), dim3(64 * nw), lds, 0, dW, dx, out, cyc, passes);
+        CK(hipDeviceSynchronize());
+        u64 c[8]; CK(hipMemcpy(c, cyc, sizeof c, hipMemcpyDeviceToHost));
+        u64 mx = 0, mn = ~0ull; for (int w = 0; w < nw; ++w) { mx = c[w] > mx ? c[w] : mx; mn = c[w] < mn ? c[w] : mn; }
+        printf("   %d waves: %.0f ns per pass of 16 = %.0f per 4 utterances (fastest wave %.0f)", nw, 10.0 * mx / passes, 2.5 * mx / passes, 10.0 * mn / passes);
+        if (nw == 8) {
+            std::vector<float> o(16 * 256); CK(hipMemcpy(o.data(), out, o.size() * 4, hipMemcpyDeviceToHost));
+            double worst = 0;
+            for (int j = 0; j < 16; ++j) for (int r = 0; r < 256; ++r) {
+                double ref = 0; for (int k = 0; k < 336; ++k) ref += (double)W[(size_t)k * 256 + r] * x[(size_t)(j & 7) * 336 + k] * (1.0 + (j >> 3));
+                worst = std::max(worst, std::abs(ref - o[j * 256 + r]));
+            }
+            printf("   max |err| vs double %.3g", worst);
+        }
+    }
+    printf("\n");
+}
+
 int main() {
     std::vector<float> h((size_t)(KR + KL) * 512 * 4);
     for (size_t i = 0; i < h.size(); ++i) h[i] = 0.01f * (float)((i * 2654435761u) % 101) - 0.5f;
@@ -306,5 +396,6 @@ int main() {
     run<6>(W, out, cyc, "reads 3 chunks ahead");
     run<7>(W, out, cyc, "reads 4 chunks ahead");
     run_mf();
+    run_mf16();
     return 0;
 }
