@@ -105,6 +105,7 @@ struct RingParams {
     unsigned long long* trace;         // optional [T_trace][upr][S+1][16] wall-clock stamps of ring 0's utterances (debug)
     unsigned long long* trace_tap;     // optional [T_trace][16] stamps of the first pass of layer 0's tap workgroup, part 0
     int trace_t0, trace_n;
+    int tap_mfma, tap_nj;              // (round 6) the tap role on the matrix pipe (run_tap_mf: the _mf kernels): K groups of 16 rows (<= TAP_NJR + TAP_NJL)
 };
 
 using u64 = unsigned long long;
@@ -1113,6 +1114,702 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
 #undef TAP_STAMP
         if (!more) break;
         t = tn; b0 = bn; cur ^= 1;
+        st_cur = st_next; st_next = st_nn;
+    }
+}
+
+constexpr int TAP_NJR = 16;        // (round 6, matrix-pipe tap role, run_tap_mf) K groups of 16 rows whose weights a lane holds in registers (2 tiles x 4 each: 128) ...
+constexpr int TAP_NJL = 6;         // ... and at most this many more in LDS (two float4 per lane and group: TapLds::wl): K = (kw - 1) 128 + cin <= 352
+constexpr int TAP_XPAD = 4;        // the pad of a mat-vec input row in LDS: the sixteen utterances of a multiplication then sit on sixteen different bank quads
+constexpr int TAP_XBUF = 4;        // input buffers (two units of two passes)
+__device__ __forceinline__ TapLds carve_tap_mf(float* smem, const RingParams& p) {
+    TapLds s;
+    s.xin = smem;
+    s.flags = reinterpret_cast<int*>(smem + (size_t)TAP_XBUF * TB * (RW * p.kper + TAP_XPAD));
+    s.dv = reinterpret_cast<float2*>(s.flags + 32);
+    s.zl = reinterpret_cast<float*>(s.dv + 4 * RT);                  // (dv: 8 floats per thread -- a unit's four stores held back)
+    s.wl = reinterpret_cast<float4*>(s.zl + 2 * TB * GC);
+    return s;
+}
+__host__ __device__ inline size_t tap_lds_floats_mf(int kper, int klds_rows) {
+    return (size_t)TAP_XBUF * TB * (RW * kper + TAP_XPAD) + 32 + 8 * RT + (size_t)2 * TB * GC + (size_t)RW * klds_rows * 64 * 4;
+}
+
+// (MF, round 6: the mat-vec on the MATRIX pipe, SIXTEEN utterances at a time -- v_mfma_f32_16x16x4_f32: A[i = lane % 16][k = lane / 16],
+//  B[k = lane / 16][j = lane % 16], result register v of a lane = D[4 (lane / 16) + v][lane % 16].  A wave's 32 output rows are two tiles; K runs
+//  in groups of 16: lane (n = lane & 15, kq = lane >> 4) reads x[utterance n][16 J + 4 kq .. + 3] with ONE 16-byte LDS read and feeds four MFMAs
+//  per tile with it (MFMA i of group J sums k = 16 J + 4 kq' + i over kq'); its weights W[16 J + 4 kq + i][row n of the tile] live in registers
+//  for J < TAP_NJR (128) and as two float4 per group in LDS beyond.  The sixteen columns are the utterances of TWO consecutive passes of this
+//  workgroup: every pass still finishes its own eight inputs ([B], barrier, [C]), an even pass then stops there and the odd pass after it
+//  multiplies both passes' rows -- they lie in adjacent input buffers -- and publishes both; a workgroup with a single pass per step
+//  multiplies every pass on its own (eight columns idle: at those batch sizes the tap workgroups are far off the critical path).
+//  Why: the legacy form -- 4 utterances per round, inputs broadcast from LDS to every lane group of every wave -- is issue-bound at 41 % of
+//  the CU's FMA peak (4.7 clocks per v_pk_fma_f32 + 16 per ds_read_b128, the two waves of a SIMD do not hide each other) and was the step's
+//  cadence beyond 32 utterances; this form reads an input once per sixteen columns and runs at 98 % of the matrix pipe in isolation:
+//  1.14 us per four utterances against 1.71 (profiles/r06_tap_waves.txt, scripts/ubench_tapmv.hip VAR 11).  EVERY instantiation uses it when
+//  the model fits (RingParams::tap_mfma): pre_l must not depend on the batch size -- a column's arithmetic does not depend on its neighbours.)
+template <bool SPEC, bool PACKED, bool DEFER>
+__device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, int l, int part, float* smem) {
+    constexpr bool MF = true;                                      // (this function began as a switch inside run_tap: the legacy branches below are dead)
+    if (WNV_EXP_NOPRE >= 2) return;
+    const TapLds s = carve_tap_mf(smem, p);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = p.lay_dil[l];
+    const int rows = (p.kw - 1) * d;
+    const int hoff = (p.kw - 1) * RC;
+    const int kx = RW * p.kper + (MF ? TAP_XPAD : 0);              // padded K = the stride of a mat-vec input row in LDS (MF: 4 x odd mod 64)
+    // MAT-VEC MAPPING (round 4): the eight WAVES split the 256 outputs (wave w: outputs [32 w, 32 w + 32)), the eight lanes ks = lane & 7 of
+    // a lane group og = lane >> 3 split K (slice ks: rows [ks kper, ks kper + kper)) for the four outputs 32 w + 4 og .. + 3: the K slices meet
+    // in three DPP steps inside the wave and every lane publishes from its registers.  (Until round 4 the WAVES split K: partial sums of four
+    // utterances through 32 KB of LDS, a barrier, a reduce that waited for its bias loads, another barrier -- 3.1-3.8 us per round of four
+    // utterances for 1.1 us of FMAs, profiles/r04_tap_pass_timeline.txt; the passes of the tap workgroups are what bounds the throughput
+    // beyond 32 utterances per GPU.)
+    const int ks = lane & 7, og = lane >> 3;
+    const int ob = 32 * wave + 4 * og;                             // this lane's four outputs
+    const int k0 = ks * p.kper;                                    // this lane's K rows: [k0, k0 + kper) of the padded matrix
+    const float* Wt = p.wpre + (size_t)l * p.kpre * GC;           // K-major [kpre][256]
+    // REDUCE-SCATTER WITHOUT SELECTS (as group_matvec8): after the FMAs a lane holds 16 partial sums -- 4 utterances x 4 outputs -- and
+    // lane ks is to end up with outputs ob + 2 (ks & 1), + 1 of utterance ks >> 1.  Which utterance an accumulator GROUP g means and which
+    // output pair comes first depend on the lane, so that every step adds the partner's "sent" registers to the own "kept" ones:
+    //   step 1, row_half_mirror (ks <-> 7 - ks; the partner has the other parity, so pairs cross): groups 2, 3 are sent, 0, 1 kept;  step 2, ks <-> ks ^ 2: group 1 sent, 0 kept;
+    //   step 3, ks <-> ks ^ 1: pair 1 sent, pair 0 kept.                                             14 DPP adds instead of 48.
+    // Group g of lane ks = utterance ug[g]:  ug[0] = ks >> 1, ug[1] = (ks >> 1) ^ 1, ug[2], ug[3] = what lane 7 - ks keeps in groups 0, 1;
+    // odd lanes hold their weights as (outputs 2, 3, 0, 1).
+    const bool odd = (ks & 1) != 0;
+    auto wload = [&](int k) {
+        if (k >= p.kpre) return make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 w = *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + ob);
+        return odd ? make_float4(w.z, w.w, w.x, w.y) : w;
+    };
+    // (packed slots WITH the speculative look at the next pass's record: four rows less in registers -- they live in LDS --, which is what
+    //  the look's four registers and the packed masks need: with 32 rows that combination spilled 6-8 registers; the host sets kreg_rows)
+    constexpr int KR = (PACKED && SPEC) ? KR_PACKED_SPEC : KR_MAX;
+    float4 wreg[KR];                                                // resident rows (registers), then LDS rows, then whatever streams
+    if constexpr (!MF) {
+#pragma unroll
+        for (int r = 0; r < KR; ++r) wreg[r] = r < p.kreg_rows ? wload(k0 + r) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int r = 0; r < p.klds_rows; ++r) s.wl[((size_t)wave * p.klds_rows + r) * 64 + lane] = wload(k0 + p.kreg_rows + r);
+    }
+    // MF: column / row-in-tile mn = lane & 15, K quarter mkq = lane >> 4; wa[(2 J + tile) 4 + i] = W[16 J + 4 mkq + i][32 wave + 16 tile + mn]
+    const int mn = lane & 15, mkq = lane >> 4;
+    const int nj = p.tap_nj;
+    // (rsplit -- see the pass sequence below: this part multiplies ONE tile of every wave's two, tile = part; it sits in slot 0)
+    const bool rsplit0 = MF && p.tap_parts == 2 && (p.B + p.tb - 1) / p.tb <= 4;
+    const int tile0 = rsplit0 ? part : 0;                           // the tile whose weights / results are slot 0's (slot 1: the other one)
+    float wa[TAP_NJR * 8];
+    if constexpr (MF) {
+        auto wk = [&](int J, int slot, int i_) { const int k = 16 * J + 4 * mkq + i_; return k < p.kpre ? Wt[(size_t)k * GC + 32 * wave + 16 * (slot ^ tile0) + mn] : 0.f; };
+#pragma unroll
+        for (int J = 0; J < TAP_NJR; ++J)
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl)
+#pragma unroll
+                for (int i_ = 0; i_ < 4; ++i_) wa[(2 * J + tl) * 4 + i_] = wk(J, tl, i_);
+        for (int J = TAP_NJR; J < nj; ++J)
+            for (int tl = 0; tl < 2; ++tl)
+                s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR) + tl) * 64 + lane] = make_float4(wk(J, tl, 0), wk(J, tl, 1), wk(J, tl, 2), wk(J, tl, 3));
+    }
+    const int uq = ks >> 1, uqm = 3 - uq;                            // (7 - ks) >> 1 = 3 - (ks >> 1)
+    const int ug[4] = {uq, uq ^ 1, uqm, uqm ^ 1};
+    const int xo0 = ug[0] * kx + k0, xo1 = ug[1] * kx + k0, xo2 = ug[2] * kx + k0, xo3 = ug[3] * kx + k0;   // input of group g: xin[...][ug[g]][k0 ..]
+    // what a lane publishes: after the all-reduce over ks every lane of a group holds all 16 sums (4 utterances x 4 outputs); lane ks sends
+    // outputs ob + 2 (ks & 1), + 1 of utterance ks >> 1 of the round -- with their addends: c_l (a constant of the lane) and the effective
+    // conv bias (per utterance when the model has a speaker embedding).  The bias rows are the MODEL's gate rows (tanh rows [0, G/2),
+    // sigmoid rows [G/2, G)); this kernel's 256 outputs are tanh channels 0..127 then sigmoid channels 0..127, zero beyond G/2
+    const int pu = uq, po = ob + 2 * (ks & 1);                     // utterance of the round, first of the two outputs (legacy form; MF: see [D])
+    const int zhalf = po >> 7, zch = po & 127;
+    const float2 cvl = *reinterpret_cast<const float2*>(p.cvec + (size_t)l * GC + po);
+    const float* zbase = p.zbias + (size_t)l * p.zb_ld + (size_t)zhalf * p.gh + zch;
+    const bool z0 = zch < p.gh, z1 = zch + 1 < p.gh;
+    const float zsc = WNV_PHASE2 ? (zhalf ? GATE_SCALE_SIGM : GATE_SCALE_TANH) : 1.0f;
+    for (int i = tid; i < (MF ? TAP_XBUF : 2) * TB * kx; i += RT) s.xin[i] = 0.f;
+    if (tid == 0) s.flags[0] = 0;
+    __syncthreads();
+    const int kres = p.kreg_rows + p.klds_rows;                    // rows of this wave that never touch memory again
+
+    // A layer with dilation >= 2 needs NOTHING of this step's h for pre[t + 1] (its taps are h[t+1-d], h[t+1-2d], ...): its pass does not
+    // wait for h[t] -- the row is waited for and filed by the NEXT pass of the utterance (tf = t - 1), a whole step later --, so the rings
+    // never wait for this layer's taps (pre_rec: why the records come in two slots).  With d = 2 the youngest tap of step t + 1 is h[t-1],
+    // the row that pass files: taken from the record, as a dilation-1 layer takes h[t].
+    // slot of a step in the history ring: rows = (kw - 1) d is a power of two for every kernel size 3 model (d = 2^i): a mask, not the
+    // ~40-instruction integer division the general case costs every lane of every gather (uniform: one compare)
+    const int rmask = rows > 0 && (rows & (rows - 1)) == 0 ? rows - 1 : -1;
+    auto ring_slot = [&](int step) -> int { return rmask >= 0 ? (step & rmask) : step % rows; };
+    const bool early = d >= 2 && rows > 0;
+    const int ntap4 = hoff / 4, ncin4 = (p.cin & 3) == 0 ? p.cin / 4 : 0;      // float4s of a mat-vec input: tap rows, conditioning row
+    constexpr int GQ = 2;                                          // ... per lane ((kw - 1) 128 + cin <= 512 floats: why_not)
+    // this workgroup's passes of a step: utterances [b0, b0 + tb).  Legacy: part q serves passes q, q + parts, ...: b0 = bfirst, + pstride, ... < B.
+    // MF: passes are multiplied in PAIRS of neighbours (2 m, 2 m + 1) -- the partner of a pass is the next token of every ring -- and the
+    // pairs are dealt to the parts alternately: part q serves pairs q, q + parts, ...  Up to four passes per step (32 utterances) BOTH parts
+    // serve ALL passes with half the output rows each (rsplit: one tile per wave, 2.3 us per multiplication): the tap path's latency is within
+    // 1-2 us of the critical path at every batch size, and a lone sixteen-column multiplication of all rows (4.6 us) cost the headline 1.2 %.
+    const int npass_all = (p.B + p.tb - 1) / p.tb;
+    const bool rsplit = MF && p.tap_parts == 2 && npass_all <= 4;
+    const int eparts = rsplit ? 1 : p.tap_parts, epart = rsplit ? 0 : part;       // parts that share the passes, this one's index among them
+    const int pstride = MF ? 2 * eparts * p.tb : p.tap_parts * p.tb;
+    const int bfirst = MF ? 2 * epart * p.tb : part * p.tb;
+    // the pass after (t_, b_) of this workgroup
+    auto advance = [&](int& t_, int& b_) {
+        if constexpr (MF) {
+            const int pi = b_ / p.tb;
+            if (!(pi & 1) && b_ + p.tb < p.B) { b_ += p.tb; return; }                // the partner
+            b_ = (pi & ~1) * p.tb + pstride;                                       // the next pair of this part
+        } else b_ += pstride;
+        if (b_ >= p.B) { b_ = bfirst; t_ += 1; }
+    };
+    if (bfirst >= p.B) return;
+    auto fresh_tap = [&](int tf_) { return ((d == 1 || early) && d <= 2 && tf_ >= 0 && rows > 0) ? p.kw - 2 : -1; };   // the tap that is h[tf] itself
+
+    // ---- SOFTWARE PIPELINE (round 4).  A pass = [B] finish the inputs (wave w = utterance b0 + w: gathered rows -> LDS, h_l[tf] from its
+    //      record -> history ring and LDS), barrier, [C] ISSUE the next pass's gather, [D] mat-vec + reduce + publish.  The gather -- the
+    //      kw-1 older taps (one contiguous 512-byte history row each; zeros before t = 0: the rings start zeroed) and c[t + 1], 16-byte
+    //      loads, two per lane -- is ~1.5 us of global-load latency; issued at [C] it lands under the mat-vec of the pass before (until
+    //      round 4 it was paid in front of every pass: beyond 32 utterances per GPU the passes of the tap workgroups bound the
+    //      throughput, profiles/r04_tap_bound_experiment.txt).  The next pass's h record is looked at speculatively in the same
+    //      breath (two granules per lane): when the utterance's stage has filed it already -- the rule in that regime -- [B] takes it
+    //      without a poll round trip.  What the next pass gathers was filed by THIS wave at the latest in [B] of this pass (a
+    //      dilation-1 layer: h[t], one step back; in order in this CU's L1); the row the next pass files itself is never gathered.
+    // The gathered rows go global -> LDS by DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land at base + 16 lane; no staging
+    // registers -- next to 128 weight registers there are none to spare: the register-staged form spilled 27) into the OTHER input
+    // buffer; the issuing wave waits for its own DMAs (vmcnt) in [B] of the pass that uses them, in front of the barrier.
+    u64 hxa0 = 0, hxa1 = 0, hxb0 = 0, hxb1 = 0;                      // the speculative looks in flight (legacy: one pass; MF: the two passes of a unit)
+    // packed slots: seg_start of (utterance b0_ + wave, step t_ + 1) -- a scalar load (no vector register held across the DMA issue),
+    // asked for ONE PASS AHEAD of the gather that needs it (round 5: read at the top of gather_issue, every pass began its mat-vec behind
+    // a scalar-load round trip -- the packed instantiations ran 12-20 % below the padded ones at the same number of rows)
+    auto seg_at = [&](int t_, int b0_) -> int {
+        if (!PACKED || wave >= min(p.tb, p.B - b0_) || t_ + 1 >= p.T) return INT_MIN;
+        return uniform_ld(p.seg_start + (size_t)__builtin_amdgcn_readfirstlane(b0_ + wave) * p.T + t_ + 1);
+    };
+    auto gather_issue = [&](int t_, int b, float* xu, int buf, int st_, u64& hx0, u64& hx1) {
+        const int tp_ = t_ + 1, tf_ = early ? t_ - 1 : t_, kf = fresh_tap(tf_);
+        const float* hb = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
+        const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
+        // packed slots: the utterance that occupies the slot at step tp_ began at step st_; what lies before reads as zeros (conv.py:34-36)
+        // (the lane-constant pieces of the addresses are formed HERE, from a copy of the lane id the compiler cannot see through: kept live
+        //  across the pass they were the registers that spilled once the deferred publish joined the loop -- a reload per pass against
+        //  three VALU instructions)
+        int lane_l = lane;
+        if constexpr (DEFER) asm volatile("" : "+v"(lane_l));
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            const int i = 64 * q + lane_l;
+            const float* src = nullptr;
+            if (i < ntap4) {
+                const int k = i >> 5, r4 = i & 31;                   // RC / 4 = 32 float4s per row
+                // (a row from before the utterance's start comes from a row of zeros: a select on the address, no branch -- the tap role has
+                //  no register to spare)
+                if (k != kf) src = tp_ - (p.kw - 1 - k) * d >= st_ ? hb + (size_t)ring_slot(tp_ + k * d) * RC + 4 * r4 : p.zero_row + 4 * r4;
+            } else if (i < ntap4 + ncin4) {
+                src = cb + 4 * (i - ntap4);
+            }
+            const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)(xu + 256 * q));
+            if (src) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(src), "s"(lds) : "memory");
+        }
+        hx0 = hx1 = 0;
+        if (SPEC && tf_ >= 0) {                                     // speculative look at the record (L1-bypassing, not waited for here)
+            const u64* rec = p.fmail + h_rec(p, b, l, tf_) + 2 * lane;
+            hx0 = ld_granule(rec); hx1 = ld_granule(rec + 1);
+        }
+    };
+
+    int t = -1, b0 = bfirst, cur = 0;                              // pass (t, b0) consumes h_l[tf], produces pre_l[t + 1]; its inputs: buffer cur
+    int st_cur = seg_at(t, b0);                                      // ... of the pass about to run, of the next one
+    if (!MF && wave < min(p.tb, p.B - b0)) gather_issue(t, b0 + wave, s.xin + (size_t)wave * kx, 0, st_cur, hxa0, hxa1);
+    int st_next = INT_MIN;
+    {
+        int tn0 = t, bn0 = b0;
+        advance(tn0, bn0);
+        st_next = seg_at(tn0, bn0);
+    }
+#ifdef WNV_FINE_TRACE
+#define TAP_STAMP(k) do { const int pk_ = MF ? (b0 - bfirst) / p.tb : (b0 - bfirst) / pstride; \
+                          if (p.trace_tap && l == WNV_TRACE_TAP_LAYER && part == 0 && pk_ < 3 && (k) < 5 && tid == 64 * WNV_TRACE_TAP_WAVE && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
+                              p.trace_tap[(size_t)(t - p.trace_t0) * TRW + 5 * pk_ + (k)] = wall_clock64(); } while (0)
+#else
+#define TAP_STAMP(k) ((void)0)
+#endif
+    // ---- [B] wave w finishes the mat-vec input of utterance b0_ + w of pass (t_, b0_) in buffer cur_: the h record it waits for (looked at
+    //      speculatively with the gather: hx0, hx1) -> history ring and LDS; then its own DMAs (issued with the gather) have landed -------------
+    auto do_B = [&](int t_, int b0_, int cur_, int st_, u64 hx0, u64 hx1) {
+        const int tp_ = t_ + 1, nb_ = min(p.tb, p.B - b0_);
+        const int tf_ = early ? t_ - 1 : t_;                        // the step whose h this pass waits for and files
+        const int kfresh = fresh_tap(tf_);
+        if (wave < nb_) {
+            const int b = b0_ + wave;
+            float* xu = s.xin + ((size_t)cur_ * TB + wave) * kx;
+            // (round 6, WNV_TAP_ZLDS) the utterance's effective conv bias row -- b_l + W_g g: per utterance when the model has a speaker
+            // embedding -- is fetched HERE, with the inputs, and handed to the rounds through LDS.  It used to be two global loads per lane at
+            // the top of every round: in round 0 they were issued right behind the next pass's gather DMAs, loads return in order, and the
+            // round's publish waited for the whole gather (history rows from the L2, the conditioning row from HBM).  PACKED instantiations
+            // only: there [B] has a record round trip for the fetch to hide under (no speculative look) and a packed job gains 3.6-4.4 %
+            // (egs/mol 100 utterances 2 292 -> 2 375, cfg4 128 utterances 1 166 -> 1 217 kSamples/s, same box); in the throughput
+            // instantiation, whose speculative look usually hits, the fetch sits in the open in front of the pass's barrier: egs/mol
+            // +0.4 %, mu-law -1.9 %, cfg4 -4 % (profiles/r06_tap_zlds_ab.txt) -- so not there.
+            float4 zrow4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PACKED && WNV_TAP_ZLDS != 0) {
+                size_t zr = (size_t)b;
+                if (PACKED && p.seg_gid) zr = (size_t)uniform_ld(p.seg_gid + (size_t)__builtin_amdgcn_readfirstlane(b) * p.T + tp_);
+                if (4 * lane < p.zb_ld) zrow4 = *reinterpret_cast<const float4*>(p.zbias + (size_t)l * p.zb_ld + zr * p.zbias_bstride + 4 * lane);
+            }
+            if (ncin4 == 0) {                                        // cin not a multiple of 4: scalar conditioning row
+                const float* cb = p.c_up + ((size_t)b * p.T + tp_) * p.cin;
+                for (int e = lane; e < p.cin; e += 64) xu[hoff + e] = cb[e];
+            }
+            if (tf_ >= 0) {
+                const unsigned htag = p.tag_base + (unsigned)tf_ + 1u;
+                float hv[2] = {__uint_as_float((unsigned)hx0), __uint_as_float((unsigned)hx1)};         // channels 2 lane, 2 lane + 1
+#ifdef WNV_FINE_TRACE
+                if (lane == 0) s.flags[24 + wave] = 0;                 // (trace: how this wave got its record -- 0 look, 1 direct look, 2 patient receive)
+#endif
+                if (!__all((unsigned)(hx0 >> 32) == htag && (unsigned)(hx1 >> 32) == htag)) {
+                    // (round 6) ONE direct look at the whole record first: while the stages pace the passes the record lands during the pass
+                    // before -- behind the speculative look, ahead of this one -- and the patient receive (first granule at a relaxed cadence,
+                    // then the record: two round trips and a sleep at best) made every pass wait ~1.4 us at its barrier for the one wave
+                    // whose speculative look had missed (profiles/r06_tap_pass_timeline.txt)
+                    const u64* rec = p.fmail + h_rec(p, b, l, tf_);
+                    const u4v x = ld16_sc1(rec + 2 * lane);
+                    hv[0] = __uint_as_float(x.x); hv[1] = __uint_as_float(x.z);
+#ifdef WNV_FINE_TRACE
+                    if (lane == 0) s.flags[24 + wave] = __all(x.y == htag && x.w == htag) ? 1 : 2;
+#endif
+                    if (!__all(x.y == htag && x.w == htag)) {
+                        if (!rec_recv<1>(rec, htag, hv, p.status, 0x600u + (unsigned)l, lane)) s.flags[0] = 1;
+                    }
+                }
+                if (rows > 0) {
+                    float* hist = p.hist + (size_t)b * p.hist_floats + p.lay_histoff[l];
+                    *reinterpret_cast<float2*>(hist + (size_t)ring_slot(tf_) * RC + 2 * lane) = make_float2(hv[0], hv[1]);
+                    if (kfresh >= 0) {
+                        // (packed slots: the row is the previous utterance's when the one at step tp began later than tf)
+                        const bool mine = !PACKED || tf_ >= st_;
+                        *reinterpret_cast<float2*>(xu + kfresh * RC + 2 * lane) = mine ? make_float2(hv[0], hv[1]) : make_float2(0.f, 0.f);
+                    }
+                }
+            }
+            if constexpr (PACKED && WNV_TAP_ZLDS != 0) *reinterpret_cast<float4*>(s.zl + ((size_t)(cur_ & 1) * TB + wave) * GC + 4 * lane) = zrow4;   // (slot = the pass's parity)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs into buffer cur_ (issued with the gather) have landed
+        }
+    };
+    // (round 6) THE LAST PUBLISH OF A PASS IS HELD BACK until the next pass's [B] and barrier are through (dv0, dv1 -> "deferred publish"
+    // below).  A publish is a write-through store (the stage may sit on any XCD), its acknowledgement takes 1.5-2 us, and every wait of
+    // this wave for a LOAD -- the h record's poll, the DMA wait -- waits for it too (vmcnt counts stores): with the last publish right in
+    // front of [B] that drain was paid in the open once per pass -- the "wait for h" of profiles/r04_throughput_bound_final_stages.txt,
+    // 1.6-2.6 us of a 5.9-us pass whatever the stages did (at 40+ utterances per GPU the step was 3 or 4 such passes: 17.6 / 23.5 us).
+    // Now every publish is followed by a round of FMAs before this wave waits for anything.
+    // ONLY where this workgroup runs at least two passes per step: with a single one the next pass is the same utterances' next step, whose
+    // h (a dilation-1 layer's pass waits for it) cannot exist before the publish it would be holding back -- the ring would stop.
+    // With two or more, pass N + 1 waits for h of ANOTHER group, which depends on publishes of pass N - 1 and earlier, all released.
+    const bool defer = DEFER && WNV_TAP_DEFER != 0 && bfirst + pstride < p.B;
+    int dbase = -1, du0 = 0, dnb = 0, dtp = 0;                       // the held publish: its pass's first utterance (-1: nothing held), round, utterances, step
+    // MF: passes of this workgroup per step -- two or more: consecutive passes are multiplied in pairs; three or more: a pair's publish may be
+    // held back (with exactly one pair per step the next pass waits for an h that needs the very publish it would hold)
+    int npps = 0;                                                    // passes of this workgroup per step
+    { int t_ = 0, b_ = bfirst; do { ++npps; advance(t_, b_); } while (t_ == 0); }
+    const bool defer3 = MF && DEFER && WNV_TAP_DEFER != 0 && npps >= 3;
+    int pc = 0, pb0 = 0, pnb = 0, ptp = 0;                           // this workgroup's multiplication counter; the pass before (the low eight columns of a pair)
+    int dlo_b0 = 0, dlo_nb = 0, dlo_tp = 0, dhi_b0 = 0, dhi_nb = 0, dhi_tp = 0;   // the held pair: first utterance / utterances / step of its low and high columns
+    bool dheld = false;
+    typedef float f4m __attribute__((ext_vector_type(4)));
+    // what column mn of a multiplication means: utterance, step, valid
+    auto colmap = [&](int lo_b0, int lo_nb, int lo_tp, int hi_b0, int hi_nb, int hi_tp, int& rb_, int& tp_, bool& pub_) {
+        const bool lowc = mn < 8;
+        rb_ = (lowc ? lo_b0 : hi_b0) + (mn & 7); tp_ = lowc ? lo_tp : hi_tp; pub_ = (mn & 7) < (lowc ? lo_nb : hi_nb);
+    };
+    auto mf_publish = [&](int rb_, int tp_, const f4m& v0_, const f4m& v1_) {          // eight values of one utterance: four 16-byte write-through stores
+        u64* rec = p.pmail + pre_rec(p, rb_, l, tp_) + 32 * wave + 4 * mkq;
+        const unsigned tg = p.tag_base + (unsigned)tp_ + 1u;
+        u64* r0_ = rec + 16 * tile0;
+        st_granule2(r0_, tg, v0_.x, v0_.y, false); st_granule2(r0_ + 2, tg, v0_.z, v0_.w, false);
+        if (!rsplit0) { st_granule2(rec + 16, tg, v1_.x, v1_.y, false); st_granule2(rec + 18, tg, v1_.z, v1_.w, false); }
+    };
+    if constexpr (MF) {
+        // ---- THE UNIT LOOP (v4).  A unit = the two neighbouring passes (2 m, 2 m + 1) of a multiplication, or a last pass without a partner:
+        //      ONE input phase (every wave finishes its utterance of pass A, then of pass B), ONE barrier, the held publish's release, the
+        //      multiplication -- with the NEXT unit's gathers and looks issued from inside the MFMA stream (the matrix pipe runs on while the
+        //      wave forms addresses and issues DMAs) --, publish or hold.
+        auto unit_next = [&](int& t_, int& b_) { b_ = (b_ / (2 * p.tb)) * (2 * p.tb) + pstride; if (b_ >= p.B) { b_ = bfirst; t_ += 1; } };
+        int ups = 0;                                                 // units of this workgroup per step
+        { int t_ = 0, b_ = bfirst; do { ++ups; unit_next(t_, b_); } while (t_ == 0); }
+        const bool hold_ok = DEFER && WNV_TAP_DEFER != 0 && ups >= 2;   // (the unit after a held one must not wait for an h that needs the held publish)
+        int ut = -1, ub = bfirst, upc = 0;
+        int stA = INT_MIN, stB = INT_MIN, stAn = INT_MIN, stBn = INT_MIN;
+        auto issue_unit = [&](int t_, int b_, int base_, int& sa_, int& sb_) {       // the gathers + looks of a unit's passes, into buffers base_, base_ + 1
+            sa_ = seg_at(t_, b_);
+            if (wave < min(p.tb, p.B - b_)) gather_issue(t_, b_ + wave, s.xin + ((size_t)base_ * TB + wave) * kx, base_, sa_, hxa0, hxa1);
+            const int bb = b_ + p.tb;
+            sb_ = INT_MIN;
+            if (bb < p.B) {
+                sb_ = seg_at(t_, bb);
+                if (wave < min(p.tb, p.B - bb)) gather_issue(t_, bb + wave, s.xin + ((size_t)(base_ + 1) * TB + wave) * kx, base_ + 1, sb_, hxb0, hxb1);
+            }
+        };
+        issue_unit(ut, ub, 0, stA, stB);
+        for (;;) {
+            const int t = ut, b0 = ub; (void)t; (void)b0;                // (names the stamps use)
+            const int tp = ut + 1, base = 2 * (upc & 1);
+            const int bA = ub, bB = ub + p.tb;
+            const bool hasB = bB < p.B;
+            const int nbA = min(p.tb, p.B - bA), nbB = hasB ? min(p.tb, p.B - bB) : 0;
+            TAP_STAMP(0);
+            do_B(ut, bA, base, stA, hxa0, hxa1);
+            if (hasB) do_B(ut, bB, base + 1, stB, hxb0, hxb1);
+            TAP_STAMP(1);
+            __syncthreads();                                             // the inputs of the unit are complete in buffers base, base + 1
+            if (s.flags[0]) return;
+            TAP_STAMP(2);
+            if (dheld) {                                                 // the held unit's publish
+                int rb_, tp_; bool pub_;
+                colmap(dlo_b0, dlo_nb, dlo_tp, dhi_b0, dhi_nb, dhi_tp, rb_, tp_, pub_);
+                if (pub_) {
+                    const float4 a = reinterpret_cast<const float4*>(s.dv)[tid], c = reinterpret_cast<const float4*>(s.dv)[RT + tid];
+                    mf_publish(rb_, tp_, f4m{a.x, a.y, a.z, a.w}, f4m{c.x, c.y, c.z, c.w});
+                }
+                dheld = false;
+            }
+            int tn = ut, bn = ub;
+            unit_next(tn, bn);
+            const bool more = tn + 1 < p.T;
+            const int nbase = 2 * ((upc + 1) & 1);
+            int rb, ctp; bool pubc;
+            colmap(bA, nbA, tp, bB, nbB, tp, rb, ctp, pubc);
+            // addends of this lane's outputs (rows 32 wave + 16 tile + 4 mkq + v of utterance rb), asked for ahead of the MFMAs
+            float4 cv[2], zb[2];
+#pragma unroll
+            for (int tl = 0; tl < 2; ++tl) {
+                const int po_ = 32 * wave + 16 * (tl ^ tile0) + 4 * mkq, zh = po_ >> 7, zc = po_ & 127;   // (tl = the slot)
+                cv[tl] = *reinterpret_cast<const float4*>(p.cvec + (size_t)l * GC + po_);
+                float zz[4] = {0.f, 0.f, 0.f, 0.f};
+                if (pubc) {
+                    const float* zq;
+                    if constexpr (PACKED && WNV_TAP_ZLDS != 0) zq = s.zl + ((size_t)(mn < 8 ? 0 : 1) * TB + (mn & 7)) * GC + zh * p.gh + zc;
+                    else zq = p.zbias + (size_t)l * p.zb_ld + (size_t)zh * p.gh + zc + (size_t)((PACKED && p.seg_gid) ? p.seg_gid[(size_t)rb * p.T + ctp] : rb) * p.zbias_bstride;
+#pragma unroll
+                    for (int i_ = 0; i_ < 4; ++i_) if (zc + i_ < p.gh) zz[i_] = zq[i_];
+                }
+                zb[tl] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+            }
+            const int xrow = base * TB + ((hasB || mn < 8) ? mn : (mn & 7));      // (a lone pass repeats its eight columns)
+            const float* xr = s.xin + (size_t)xrow * kx + 4 * mkq;
+            auto xread = [&](int J) { return *reinterpret_cast<const float4*>(xr + 16 * min(J, nj - 1)); };
+            f4m d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+            float4 xv = xread(0);
+            if (!rsplit0) {
+#pragma unroll
+                for (int J = 0; J < TAP_NJR; ++J) {
+                    const float4 xn = xread(J + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int i_ = 0; i_ < 4; ++i_) {
+                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J) * 4 + i_], xs[i_], d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J + 1) * 4 + i_], xs[i_], d1, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    xv = xn;
+                    if (J == 1) { if (more) issue_unit(tn, bn, nbase, stAn, stBn); __builtin_amdgcn_sched_barrier(0); }
+                }
+#pragma unroll 1
+                for (int J = TAP_NJR; J < nj; ++J) {
+                    const float4 w0 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR)) * 64 + lane], w1 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR) + 1) * 64 + lane];
+                    const float4 xn = xread(J + 1);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                    for (int i_ = 0; i_ < 4; ++i_) {
+                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i_], xs[i_], d0, 0, 0, 0);
+                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i_], xs[i_], d1, 0, 0, 0);
+                    }
+                    xv = xn;
+                }
+            } else {                                                 // rsplit: slot 0 only (the same MFMAs in the same order as slot 0's above)
+#pragma unroll
+                for (int J = 0; J < TAP_NJR; ++J) {
+                    const float4 xn = xread(J + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                    for (int i_ = 0; i_ < 4; ++i_) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J) * 4 + i_], xs[i_], d0, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    xv = xn;
+                    if (J == 1) { if (more) issue_unit(tn, bn, nbase, stAn, stBn); __builtin_amdgcn_sched_barrier(0); }
+                }
+#pragma unroll 1
+                for (int J = TAP_NJR; J < nj; ++J) {
+                    const float4 w0 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR)) * 64 + lane];
+                    const float4 xn = xread(J + 1);
+                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w};
+#pragma unroll
+                    for (int i_ = 0; i_ < 4; ++i_) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i_], xs[i_], d0, 0, 0, 0);
+                    xv = xn;
+                }
+            }
+            TAP_STAMP(3);
+            const float zs_ = WNV_PHASE2 ? (wave >= 4 ? GATE_SCALE_SIGM : GATE_SCALE_TANH) : 1.0f;
+            const f4m v0 = {d0.x + fmaf(zb[0].x, zs_, cv[0].x), d0.y + fmaf(zb[0].y, zs_, cv[0].y), d0.z + fmaf(zb[0].z, zs_, cv[0].z), d0.w + fmaf(zb[0].w, zs_, cv[0].w)};
+            const f4m v1 = {d1.x + fmaf(zb[1].x, zs_, cv[1].x), d1.y + fmaf(zb[1].y, zs_, cv[1].y), d1.z + fmaf(zb[1].z, zs_, cv[1].z), d1.w + fmaf(zb[1].w, zs_, cv[1].w)};
+            if (hold_ok && more) {
+                reinterpret_cast<float4*>(s.dv)[tid] = make_float4(v0.x, v0.y, v0.z, v0.w);
+                reinterpret_cast<float4*>(s.dv)[RT + tid] = make_float4(v1.x, v1.y, v1.z, v1.w);
+                dlo_b0 = bA; dlo_nb = nbA; dlo_tp = tp; dhi_b0 = bB; dhi_nb = nbB; dhi_tp = tp; dheld = true;
+            } else if (pubc) mf_publish(rb, ctp, v0, v1);
+            TAP_STAMP(4);
+            if (!more) break;
+            ut = tn; ub = bn; ++upc; stA = stAn; stB = stBn;
+        }
+        return;
+    }
+    for (;;) {
+        const int tp = t + 1;
+        const int nb = min(p.tb, p.B - b0);
+        TAP_STAMP(0);
+        do_B(t, b0, cur, st_cur, hxa0, hxa1);
+        TAP_STAMP(1);                                                // (this wave's h record filed, its DMAs landed)
+        __syncthreads();                                             // the inputs of pass (t, b0) are complete in buffer cur
+        if (s.flags[0]) return;
+        TAP_STAMP(2);
+#ifdef WNV_FINE_TRACE
+        {   // slot 15 of the row: two bits per wave and pass -- how each wave got its record
+            const int pk_ = MF ? (b0 - bfirst) / p.tb : (b0 - bfirst) / pstride;
+            if (p.trace_tap && l == WNV_TRACE_TAP_LAYER && part == 0 && pk_ < 3 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) {
+                unsigned long long m = 0;
+                for (int w = 0; w < 8; ++w) m |= (unsigned long long)(s.flags[24 + w] & 3) << (2 * w);
+                unsigned long long* q = p.trace_tap + (size_t)(t - p.trace_t0) * TRW + 15;
+                *q = (pk_ == 0 ? 0ull : *q) | (m << (16 * pk_));
+            }
+        }
+#endif
+        if constexpr (MF) {
+            if (dheld) {                                                 // the held pair's publish (see [D])
+                int rb_, tp_; bool pub_;
+                colmap(dlo_b0, dlo_nb, dlo_tp, dhi_b0, dhi_nb, dhi_tp, rb_, tp_, pub_);
+                if (pub_) {
+                    const float4 a = reinterpret_cast<const float4*>(s.dv)[tid], c = reinterpret_cast<const float4*>(s.dv)[RT + tid];
+                    mf_publish(rb_, tp_, f4m{a.x, a.y, a.z, a.w}, f4m{c.x, c.y, c.z, c.w});
+                }
+                dheld = false;
+            }
+        }
+        if (dbase >= 0 && du0 + pu < dnb) {                             // the deferred publish of the pass before (see above the loop)
+            const float2 dvv = s.dv[tid];
+            st_granule2(p.pmail + pre_rec(p, dbase + du0 + pu, l, dtp) + po, p.tag_base + (unsigned)dtp + 1u, dvv.x, dvv.y, false);
+        }
+        dbase = -1;
+        // ---- [C] the next pass of this workgroup: its gather is issued now and lands under the mat-vec below -------------------------
+        int tn = t, bn = b0;
+        advance(tn, bn);
+        const bool more = tn + 1 < p.T;
+        // (MF: does THIS pass multiply?  pass k of the step: (2 j, 2 j + 1) are multiplied together by the odd one; the last pass of an odd
+        //  number runs alone -- a pair never straddles two steps: its low half would wait for a token most of a revolution behind, measured
+        //  -19 % at 48 utterances.  The input buffers: a multiplication's passes sit in buffers (2 c, 2 c + 1), c alternating.)
+        const int pidx = b0 / p.tb;                                  // the pass's index in the step (all parts)
+        const bool paired = MF && (pidx & 1);
+        const bool do_mm = paired || b0 + p.tb >= p.B || !more;      // ... the odd pass of a pair, a last pass without a partner, the launch's last pass
+        const int nxt = MF ? 2 * ((pc + (do_mm ? 1 : 0)) & 1) + ((bn / p.tb) & 1) : (cur ^ 1);   // the next pass's input buffer
+        if (more && wave < min(p.tb, p.B - bn)) gather_issue(tn, bn + wave, s.xin + ((size_t)nxt * TB + wave) * kx, nxt, st_next, hxa0, hxa1);
+        int st_nn = INT_MIN;                                         // the pass after the next: asked for now, used a pass from now
+        if (PACKED && more) {
+            int tnn = tn, bnn = bn;
+            advance(tnn, bnn);
+            st_nn = seg_at(tnn, bnn);
+        }
+        // ---- [D] mat-vec for all utterances of the pass, four at a time (accumulators + weights must fit the register file):
+        //      VGPR rows, then LDS rows, then whatever streams; no barrier inside (the inputs are read-only here, the next
+        //      pass's land in the other buffer, and its [B] barrier is behind every wave's last read of this one) -----------
+        if constexpr (MF) {
+            if (do_mm) {
+                const int lo_b0 = paired ? pb0 : b0, lo_nb = paired ? pnb : nb, lo_tp = paired ? ptp : tp, hi_nb = paired ? nb : 0;
+                int rb, ctp; bool pubc;
+                colmap(lo_b0, lo_nb, lo_tp, b0, hi_nb, tp, rb, ctp, pubc);
+                // addends of this lane's eight outputs (rows 32 wave + 16 tile + 4 mkq + v of utterance rb), asked for ahead of the MFMAs:
+                // c_l and the utterance's effective conv bias (packed slots: handed over through LDS by [B], slot = the pass's parity)
+                float4 cv[2], zb[2];
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    const int po_ = 32 * wave + 16 * (tl ^ tile0) + 4 * mkq, zh = po_ >> 7, zc = po_ & 127;   // (tl = the slot)
+                    cv[tl] = *reinterpret_cast<const float4*>(p.cvec + (size_t)l * GC + po_);
+                    float zz[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (pubc) {
+                        const float* zq;
+                        if constexpr (PACKED && WNV_TAP_ZLDS != 0) zq = s.zl + ((size_t)(paired ? (mn < 8 ? 0 : 1) : (cur & 1)) * TB + (mn & 7)) * GC + zh * p.gh + zc;
+                        else zq = p.zbias + (size_t)l * p.zb_ld + (size_t)zh * p.gh + zc + (size_t)((PACKED && p.seg_gid) ? p.seg_gid[(size_t)rb * p.T + ctp] : rb) * p.zbias_bstride;
+#pragma unroll
+                        for (int i_ = 0; i_ < 4; ++i_) if (zc + i_ < p.gh) zz[i_] = zq[i_];
+                    }
+                    zb[tl] = make_float4(zz[0], zz[1], zz[2], zz[3]);
+                }
+                // the sixteen columns' input rows: the pair's two buffers are adjacent (the odd pass's is cur); a lone pass repeats its eight
+                const int xrow = (paired ? cur - 1 : cur) * TB + ((paired || mn < 8) ? mn : (mn & 7));
+                const float* xr = s.xin + (size_t)xrow * kx + 4 * mkq;
+                auto xread = [&](int J) { return *reinterpret_cast<const float4*>(xr + 16 * min(J, nj - 1)); };
+                f4m d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+                float4 xv = xread(0);
+                // (an explicit two-stage pipeline: group J + 1's input is asked for in front of group J's MFMAs; weights beyond this model's K
+                //  are zero and the read is clamped to its last group -- exact zeros)
+                if (!rsplit0) {
+#pragma unroll
+                    for (int J = 0; J < TAP_NJR; ++J) {
+                        const float4 xn = xread(J + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                        for (int i_ = 0; i_ < 4; ++i_) {
+                            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J) * 4 + i_], xs[i_], d0, 0, 0, 0);
+                            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J + 1) * 4 + i_], xs[i_], d1, 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        xv = xn;
+                    }
+#pragma unroll 1
+                    for (int J = TAP_NJR; J < nj; ++J) {
+                        const float4 w0 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR)) * 64 + lane], w1 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR) + 1) * 64 + lane];
+                        const float4 xn = xread(J + 1);
+                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+                        for (int i_ = 0; i_ < 4; ++i_) {
+                            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i_], xs[i_], d0, 0, 0, 0);
+                            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i_], xs[i_], d1, 0, 0, 0);
+                        }
+                        xv = xn;
+                    }
+                } else {                                             // rsplit: slot 0 only (the same MFMAs in the same order as slot 0's above)
+#pragma unroll
+                    for (int J = 0; J < TAP_NJR; ++J) {
+                        const float4 xn = xread(J + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+                        for (int i_ = 0; i_ < 4; ++i_) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J) * 4 + i_], xs[i_], d0, 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        xv = xn;
+                    }
+#pragma unroll 1
+                    for (int J = TAP_NJR; J < nj; ++J) {
+                        const float4 w0 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR)) * 64 + lane];
+                        const float4 xn = xread(J + 1);
+                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w};
+#pragma unroll
+                        for (int i_ = 0; i_ < 4; ++i_) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i_], xs[i_], d0, 0, 0, 0);
+                        xv = xn;
+                    }
+                }
+                TAP_STAMP(3);
+                // (WNV_PHASE2: everything that sums into z carries the gate's exp2 scale -- the matrix and c_l from the host, the bias row here;
+                //  rows [0, 128) of this kernel's 256 outputs are tanh rows, [128, 256) sigmoid rows: waves 0-3 / 4-7)
+                const float zs_ = WNV_PHASE2 ? (wave >= 4 ? GATE_SCALE_SIGM : GATE_SCALE_TANH) : 1.0f;
+                const f4m v0 = {d0.x + fmaf(zb[0].x, zs_, cv[0].x), d0.y + fmaf(zb[0].y, zs_, cv[0].y), d0.z + fmaf(zb[0].z, zs_, cv[0].z), d0.w + fmaf(zb[0].w, zs_, cv[0].w)};
+                const f4m v1 = {d1.x + fmaf(zb[1].x, zs_, cv[1].x), d1.y + fmaf(zb[1].y, zs_, cv[1].y), d1.z + fmaf(zb[1].z, zs_, cv[1].z), d1.w + fmaf(zb[1].w, zs_, cv[1].w)};
+                // pre_l of up to sixteen utterances leaves as tagged granules -- or is held back behind the next pass's [B] and barrier (the
+                // write-through stores' acknowledgement would be drained by that pass's first wait for a load: see above the loop)
+                if (defer3 && more) {
+                    reinterpret_cast<float4*>(s.dv)[tid] = make_float4(v0.x, v0.y, v0.z, v0.w);
+                    reinterpret_cast<float4*>(s.dv)[RT + tid] = make_float4(v1.x, v1.y, v1.z, v1.w);
+                    dlo_b0 = lo_b0; dlo_nb = lo_nb; dlo_tp = lo_tp; dhi_b0 = b0; dhi_nb = hi_nb; dhi_tp = tp; dheld = true;
+                } else if (pubc) mf_publish(rb, ctp, v0, v1);
+                TAP_STAMP(4);
+            }
+        } else
+#pragma unroll 1
+        for (int u0 = 0; u0 < nb; u0 += 4) {
+            // packed FMAs (v_pk_fma_f32: two outputs per instruction, the input broadcast into both halves): this loop is what a
+            // pass costs -- 336 rows x 256 outputs x 8 utterances = 688 k MACs per workgroup
+            const bool pub = u0 + pu < nb;                                   // this lane has something to publish in this round
+            const int rb = b0 + u0 + pu;
+            float zb0 = 0.f, zb1 = 0.f;                                      // the utterance's effective conv bias: requested ahead of the FMAs
+            if constexpr (PACKED && WNV_TAP_ZLDS != 0) {
+                if (pub) {
+                    const float* zq = s.zl + ((size_t)cur * TB + u0 + pu) * GC + zhalf * p.gh + zch;
+                    if (z0) zb0 = zq[0];
+                    if (z1) zb1 = zq[1];
+                }
+            } else
+            if (pub) {
+                // (throughput instantiation: these two global loads per lane and round stay.  Round 6 measured both alternatives on one box --
+                //  the row fetched with the pass's inputs and handed over through LDS: egs/mol +0.4 %, mu-law -1.9 %, cfg4 -4 %; ONE copy in LDS
+                //  for the whole launch where no global conditioning makes the row a constant: -3.2 % at 40-64 utterances.  The loads' wait at
+                //  the end of a round is where this wave's earlier write-through publish gets drained, under the other waves' FMAs; without
+                //  it the drain moves into the open in front of the next pass's barrier: profiles/r06_tap_zlds_ab.txt)
+                // (packed slots: the bias row of the utterance that occupies the slot at step tp -- its speaker.  Read here, ahead of the
+                //  FMAs; parked in LDS a pass ahead it cost the packed instantiations 2-4 spilled registers and 3 % -- round 5, measured)
+                const float* zrow = zbase + (size_t)((PACKED && p.seg_gid) ? p.seg_gid[(size_t)rb * p.T + tp] : rb) * p.zbias_bstride;
+                if (z0) zb0 = zrow[0];
+                if (z1) zb1 = zrow[1];
+            }
+            f2 acc[4][2];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = f2{0.f, 0.f};
+            const float* xr = s.xin + ((size_t)cur * TB + u0) * kx;
+            const float* xg[4] = {xr + xo0, xr + xo1, xr + xo2, xr + xo3};
+            // (loop order: a row's weights against two utterances -- four INDEPENDENT accumulators in a row; with one utterance
+            //  innermost the compiler alternated two and every v_pk_fma_f32 waited for the one before the last: 6.8 clocks per
+            //  instruction instead of 4.7, profiles/r04_tap_pass_timeline.txt; all four at once need 16 input registers: spills)
+#pragma unroll
+            for (int r4 = 0; r4 < KR / 4; ++r4) {
+#pragma unroll
+                for (int gp = 0; gp < 4; gp += 2) {                      // two utterances at a time: four independent accumulators in a row
+                    const float4 xa = *reinterpret_cast<const float4*>(xg[gp] + 4 * r4), xc = *reinterpret_cast<const float4*>(xg[gp + 1] + 4 * r4);
+                    const float xs[2][4] = {{xa.x, xa.y, xa.z, xa.w}, {xc.x, xc.y, xc.z, xc.w}};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float4 w = wreg[4 * r4 + e];
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const f2 xx = f2{xs[g][e], xs[g][e]};
+                            acc[gp + g][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[gp + g][0]);
+                            acc[gp + g][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[gp + g][1]);
+                        }
+                    }
+                }
+            }
+            for (int r = 0; r < p.klds_rows; r += 4) {                     // klds_rows is a multiple of 4: one 16-byte x read per utterance
+                float4 w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = s.wl[((size_t)wave * p.klds_rows + r + e) * 64 + lane];
+#pragma unroll
+                for (int gp = 0; gp < 4; gp += 2) {
+                    const float4 xa = *reinterpret_cast<const float4*>(xg[gp] + p.kreg_rows + r), xc = *reinterpret_cast<const float4*>(xg[gp + 1] + p.kreg_rows + r);
+                    const float xs[2][4] = {{xa.x, xa.y, xa.z, xa.w}, {xc.x, xc.y, xc.z, xc.w}};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            const f2 xx = f2{xs[g][e], xs[g][e]};
+                            acc[gp + g][0] = __builtin_elementwise_fma(f2{w[e].x, w[e].y}, xx, acc[gp + g][0]);
+                            acc[gp + g][1] = __builtin_elementwise_fma(f2{w[e].z, w[e].w}, xx, acc[gp + g][1]);
+                        }
+                }
+            }
+            for (int k = k0 + kres; k < k0 + p.kper && k < p.kpre; ++k) {
+                const float4 w = wload(k);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float xs = xg[g][k - k0];
+                    const f2 xx = f2{xs, xs};
+                    acc[g][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[g][0]);
+                    acc[g][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[g][1]);
+                }
+            }
+            // the K slices meet (see REDUCE-SCATTER above)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+                    acc[g][h] = f2{dpp_fold<0x141>(acc[g][h].x, acc[g + 2][1 - h].x), dpp_fold<0x141>(acc[g][h].y, acc[g + 2][1 - h].y)};   // (the mirror partner has the other parity: its OTHER pair holds these outputs)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[0][h] = f2{dpp_fold<0x4E>(acc[0][h].x, acc[1][h].x), dpp_fold<0x4E>(acc[0][h].y, acc[1][h].y)};
+            // (WNV_PHASE2: everything that sums into z carries the gate's exp2 scale -- the matrix and c_l from the host, the bias row here)
+            const float v0 = dpp_fold<0xB1>(acc[0][0].x, acc[0][1].x) + fmaf(zb0, zsc, cvl.x);
+            const float v1 = dpp_fold<0xB1>(acc[0][0].y, acc[0][1].y) + fmaf(zb1, zsc, cvl.y);
+            // pre_l[tp] of utterance rb leaves as tagged granules (write-through: the stage may sit on any XCD): no drain
+            if (defer && more && u0 + 4 >= nb) {                          // the last round of the pass: held back (see above the loop)
+                s.dv[tid] = make_float2(v0, v1);                         // (read back by this very thread)
+                dbase = b0; du0 = u0; dnb = nb; dtp = tp;
+            } else
+            if (pub) st_granule2(p.pmail + pre_rec(p, rb, l, tp) + po, p.tag_base + (unsigned)tp + 1u, v0, v1, false);
+            TAP_STAMP(min(3 + u0 / 4, 4));
+        }
+#undef TAP_STAMP
+        if (!more) break;
+        if constexpr (MF) { pb0 = b0; pnb = nb; ptp = tp; pc += do_mm ? 1 : 0; }
+        t = tn; b0 = bn; cur = nxt;
         st_cur = st_next; st_next = st_nn;
     }
 }
@@ -2445,7 +3142,7 @@ __device__ __attribute__((always_inline)) void run_head_cat(const RingParams& p,
 }
 
 // MODE: 0 = one to four utterances per ring, 1 = more (the stages' throughput prologue), 2 = packed slots (seg_start; any number)
-template <int NK, bool L0, bool SPLIT, int MODE>
+template <int NK, bool L0, bool SPLIT, int MODE, bool MF = false>
 __device__ __forceinline__ void ring_body(const RingParams& p) {
     constexpr bool MULTI = MODE >= 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2478,14 +3175,20 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
     const int free_slots = (p.rstride - p.n_rings) * P;
     if ((int)blockIdx.x >= p.ring_blocks) {
         const int k = free_slots + (int)blockIdx.x - p.ring_blocks;
-        run_tap<(MODE == 0 || (MODE == 1 && WNV_TAP_SPEC1 != 0) || (MODE == 2 && WNV_PACKED_SPEC != 0)) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
+        {
+            if constexpr (MF) run_tap_mf<(MODE == 0 || (MODE == 1 && WNV_TAP_SPEC1 != 0) || (MODE == 2 && WNV_PACKED_SPEC != 0)) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
+            else run_tap<(MODE == 0 || (MODE == 1 && WNV_TAP_SPEC1 != 0) || (MODE == 2 && WNV_PACKED_SPEC != 0)) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
+        }
         return;
     }
     const int ring = blockIdx.x % p.rstride;
     const int pos = blockIdx.x / p.rstride;
     if (ring >= p.n_rings) {
         const int k = pos * (p.rstride - p.n_rings) + (ring - p.n_rings);
-        if (k < p.tap_parts * p.L) run_tap<(MODE == 0 || (MODE == 1 && WNV_TAP_SPEC1 != 0) || (MODE == 2 && WNV_PACKED_SPEC != 0)) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
+        if (k < p.tap_parts * p.L) {
+            if constexpr (MF) run_tap_mf<(MODE == 0 || (MODE == 1 && WNV_TAP_SPEC1 != 0) || (MODE == 2 && WNV_PACKED_SPEC != 0)) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
+            else run_tap<(MODE == 0 || (MODE == 1 && WNV_TAP_SPEC1 != 0) || (MODE == 2 && WNV_PACKED_SPEC != 0)) && NK != 2, MODE == 2, MODE != 0>(p, k % p.L, k / p.L, smem);
+        }
         return;
     }
     if (L0 && pos == 0) return;                   // layer 0 is evaluated by the head (run_head)
@@ -2510,6 +3213,10 @@ __device__ __forceinline__ void ring_body(const RingParams& p) {
 // NK <= 2: capped at 244 VGPRs -- v244 .. v255 are the poll slots (see "POLLS IN RESERVED REGISTERS")
 template <int NK, bool L0, int MODE>
 __global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel(const RingParams p) { ring_body<NK, L0, false, MODE>(p); }
+// (round 6) the same kernels with the tap role on the matrix pipe (run_tap_mf) -- separate instantiations, so that the kernels above compile
+// from exactly the code they had: every role of a kernel is inlined into one function and a change in one moves the others' registers
+template <int NK, bool L0, int MODE>
+__global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel_mf(const RingParams p) { ring_body<NK, L0, false, MODE, true>(p); }
 // split rings: two CUs per layer (scalar-input models with 128 skip channels, up to 8 utterances)
 __global__ void __launch_bounds__(RT) __attribute__((amdgpu_num_vgpr(244))) wnv_ring_kernel_split(const RingParams p) { ring_body<1, true, true, 0>(p); }
 // K = 512: capped like the others since round 4 (two spilled registers in the MODE 0 instantiation, none in the others): its polls used to
@@ -2984,14 +3691,24 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     bool head_l0 = st->cin1 == 1 && NK == 1 && st->S >= 2;
     { const char* e = wnv_knob("WNV_RING_L0"); if (e && e[0] == '0') head_l0 = false; }
     const int Plive = P - (head_l0 ? 1 : 0);
-    auto rings_that_fit = [&](int parts) {
-        for (int n = std::min(B, 8); n >= 1; --n) {
+    auto rings_that_fit_of = [&](int parts, int B_) {
+        for (int n = std::min(B_, 8); n >= 1; --n) {
             const int free_slots = (8 - n) * P;
             const int extra = std::max(0, parts * st->L - free_slots);
             if (Plive + (extra + 7) / 8 <= cus_per_xcd) return n;
         }
         return 0;
     };
+    auto rings_that_fit = [&](int parts) { return rings_that_fit_of(parts, B); };
+    // (round 6) THE TAP ROLE ON THE MATRIX PIPE (run_tap_mf, the _mf kernels) for the models whose layout has ONE tap workgroup per layer at
+    // EVERY batch size -- rings too long for eight of them next to two parts: more than 24 stages --: there the single workgroup's passes are the
+    // step's cadence beyond 16 utterances (up to 8 passes of 5.7 us per step): the 30-layer models gain 5 % at 32 utterances, 14-15 % at 48 / 64
+    // and 24 % on BASELINE configs[3]'s 64-utterance job.  The choice depends on the MODEL, never on the batch size: pre_l is the same bits in
+    // every launch of a model (seed determinism).  NOT the 24-layer models (two parts: every form of it measured slower at 40 / 48 utterances
+    // and on the packed jobs), NOT K = 512 (one part too, but its stages' skip passes bound it as much: measured slower):
+    // profiles/r06_tap_waves.txt #7, profiles/r06_tap_mfg_raw.txt.
+    const bool mf_model = (st->kpre + 15) / 16 <= TAP_NJR + TAP_NJL && NK != 4
+                          && rings_that_fit_of(2, 64) < 8 && rings_that_fit_of(1, 64) > rings_that_fit_of(2, 64);
     int tap_parts = B > TB ? 2 : 1;
     int tb = TB;                                                   // utterances per tap pass
     // WNV_RING_TAP=<parts>,<utterances per pass>: measurement knob (profiles/r04_tap_parts.txt)
@@ -3101,8 +3818,15 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     p.kreg_rows = std::min(p.kper, (ga.seg_start && NK != 2 && WNV_PACKED_SPEC) ? KR_PACKED_SPEC : KR_MAX);      // (= run_tap's KR for the instantiation launched below)
     p.klds_rows = std::min(p.kper - p.kreg_rows, KL_MAX);                      // multiples of 4 (kper is one)
     while (p.klds_rows > 0 && tap_lds_floats(p.kper, p.klds_rows) * sizeof(float) > 158 * 1024) p.klds_rows -= 4;
+    p.tap_nj = (st->kpre + 15) / 16;                                          // K groups of 16 rows (16 tap_nj <= 8 kper: the zero-padded input row)
+    p.tap_mfma = (mf_model && !split && tap_parts == 1) ? 1 : 0;
+    if (p.tap_mfma) {                                                          // (two float4 per lane and K group beyond the registers' sixteen, in LDS)
+        const int rows = 2 * std::max(p.tap_nj - TAP_NJR, 0);
+        if (tap_lds_floats_mf(p.kper, rows) * sizeof(float) <= 158 * 1024) p.klds_rows = rows;   // (= the stride of a wave's block of TapLds::wl)
+        else p.tap_mfma = 0;
+    }
     p.ring_blocks = split ? 8 * max_slots : rstride * P;
-    const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), tap_lds_floats(p.kper, p.klds_rows)),
+    const size_t lds = std::max(std::max(std::max(stage_lds_floats(NK), head_lds_floats(NK)), p.tap_mfma ? tap_lds_floats_mf(p.kper, p.klds_rows) : tap_lds_floats(p.kper, p.klds_rows)),
                                 st->cin1 > 1 ? cat_lds_floats(NK) : (size_t)0) * sizeof(float);
     if (lds > 160 * 1024) { err = "ring kernel needs too much LDS"; return WNV_ERR_UNSUPPORTED; }
     // more than four utterances per ring (40+ per GPU): the stages' occupancy per utterance bounds the step -> their throughput
@@ -3114,11 +3838,14 @@ wnv_status wnv_ring_generate(WnvRingState** pst, int device, const wnv_config& c
     if (const char* e = wnv_knob("WNV_RING_MODE")) { if (mode != 2 && (e[0] == '0' || e[0] == '1')) mode = e[0] - '0'; }   // measurement knob
     if (split && mode == 2) { err = "ring kernel: packed slots and split rings do not combine"; return WNV_ERR_UNSUPPORTED; }
 #define WNV_PICK(NKV, L0V) (mode == 2 ? (const void*)wnv_ring_kernel<NKV, L0V, 2> : mode == 1 ? (const void*)wnv_ring_kernel<NKV, L0V, 1> : (const void*)wnv_ring_kernel<NKV, L0V, 0>)
+#define WNV_PICK_MF(NKV, L0V) (mode == 2 ? (const void*)wnv_ring_kernel_mf<NKV, L0V, 2> : mode == 1 ? (const void*)wnv_ring_kernel_mf<NKV, L0V, 1> : (const void*)wnv_ring_kernel_mf<NKV, L0V, 0>)
     const void* kfn = split ? (const void*)wnv_ring_kernel_split
+                    : p.tap_mfma ? (NK == 1 ? (head_l0 ? WNV_PICK_MF(1, true) : WNV_PICK_MF(1, false)) : WNV_PICK_MF(2, false))
                     : NK == 1 ? (head_l0 ? WNV_PICK(1, true) : WNV_PICK(1, false))
                     : NK == 2 ? WNV_PICK(2, false)
                               : (mode == 2 ? (const void*)wnv_ring_kernel_k512<2> : mode == 1 ? (const void*)wnv_ring_kernel_k512<1> : (const void*)wnv_ring_kernel_k512<0>);
 #undef WNV_PICK
+#undef WNV_PICK_MF
     RING_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     p.tap_parts = tap_parts; p.tb = tb;
     const int grid = split ? p.ring_blocks + tap_parts * st->L : p.ring_blocks + std::max(0, tap_parts * st->L - (8 - n_rings) * P);
