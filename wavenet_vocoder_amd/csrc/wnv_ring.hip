@@ -1150,55 +1150,20 @@ __host__ __device__ inline size_t tap_lds_floats_mf(int kper, int klds_rows) {
 //  the model fits (RingParams::tap_mfma): pre_l must not depend on the batch size -- a column's arithmetic does not depend on its neighbours.)
 template <bool SPEC, bool PACKED, bool DEFER>
 __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, int l, int part, float* smem) {
-    constexpr bool MF = true;                                      // (this function began as a switch inside run_tap: the legacy branches below are dead)
     if (WNV_EXP_NOPRE >= 2) return;
     const TapLds s = carve_tap_mf(smem, p);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = p.lay_dil[l];
     const int rows = (p.kw - 1) * d;
     const int hoff = (p.kw - 1) * RC;
-    const int kx = RW * p.kper + (MF ? TAP_XPAD : 0);              // padded K = the stride of a mat-vec input row in LDS (MF: 4 x odd mod 64)
-    // MAT-VEC MAPPING (round 4): the eight WAVES split the 256 outputs (wave w: outputs [32 w, 32 w + 32)), the eight lanes ks = lane & 7 of
-    // a lane group og = lane >> 3 split K (slice ks: rows [ks kper, ks kper + kper)) for the four outputs 32 w + 4 og .. + 3: the K slices meet
-    // in three DPP steps inside the wave and every lane publishes from its registers.  (Until round 4 the WAVES split K: partial sums of four
-    // utterances through 32 KB of LDS, a barrier, a reduce that waited for its bias loads, another barrier -- 3.1-3.8 us per round of four
-    // utterances for 1.1 us of FMAs, profiles/r04_tap_pass_timeline.txt; the passes of the tap workgroups are what bounds the throughput
-    // beyond 32 utterances per GPU.)
-    const int ks = lane & 7, og = lane >> 3;
-    const int ob = 32 * wave + 4 * og;                             // this lane's four outputs
-    const int k0 = ks * p.kper;                                    // this lane's K rows: [k0, k0 + kper) of the padded matrix
+    const int kx = RW * p.kper + TAP_XPAD;                         // the stride of a mat-vec input row in LDS (4 x odd mod 64: sixteen rows, sixteen bank quads)
     const float* Wt = p.wpre + (size_t)l * p.kpre * GC;           // K-major [kpre][256]
-    // REDUCE-SCATTER WITHOUT SELECTS (as group_matvec8): after the FMAs a lane holds 16 partial sums -- 4 utterances x 4 outputs -- and
-    // lane ks is to end up with outputs ob + 2 (ks & 1), + 1 of utterance ks >> 1.  Which utterance an accumulator GROUP g means and which
-    // output pair comes first depend on the lane, so that every step adds the partner's "sent" registers to the own "kept" ones:
-    //   step 1, row_half_mirror (ks <-> 7 - ks; the partner has the other parity, so pairs cross): groups 2, 3 are sent, 0, 1 kept;  step 2, ks <-> ks ^ 2: group 1 sent, 0 kept;
-    //   step 3, ks <-> ks ^ 1: pair 1 sent, pair 0 kept.                                             14 DPP adds instead of 48.
-    // Group g of lane ks = utterance ug[g]:  ug[0] = ks >> 1, ug[1] = (ks >> 1) ^ 1, ug[2], ug[3] = what lane 7 - ks keeps in groups 0, 1;
-    // odd lanes hold their weights as (outputs 2, 3, 0, 1).
-    const bool odd = (ks & 1) != 0;
-    auto wload = [&](int k) {
-        if (k >= p.kpre) return make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 w = *reinterpret_cast<const float4*>(Wt + (size_t)k * GC + ob);
-        return odd ? make_float4(w.z, w.w, w.x, w.y) : w;
-    };
-    // (packed slots WITH the speculative look at the next pass's record: four rows less in registers -- they live in LDS --, which is what
-    //  the look's four registers and the packed masks need: with 32 rows that combination spilled 6-8 registers; the host sets kreg_rows)
-    constexpr int KR = (PACKED && SPEC) ? KR_PACKED_SPEC : KR_MAX;
-    float4 wreg[KR];                                                // resident rows (registers), then LDS rows, then whatever streams
-    if constexpr (!MF) {
-#pragma unroll
-        for (int r = 0; r < KR; ++r) wreg[r] = r < p.kreg_rows ? wload(k0 + r) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int r = 0; r < p.klds_rows; ++r) s.wl[((size_t)wave * p.klds_rows + r) * 64 + lane] = wload(k0 + p.kreg_rows + r);
-    }
-    // MF: column / row-in-tile mn = lane & 15, K quarter mkq = lane >> 4; wa[(2 J + tile) 4 + i] = W[16 J + 4 mkq + i][32 wave + 16 tile + mn]
+    // column (an utterance) / row of a tile mn = lane & 15, K quarter mkq = lane >> 4; wa[(2 J + tile) 4 + i] = W[16 J + 4 mkq + i][32 wave + 16 tile + mn]
     const int mn = lane & 15, mkq = lane >> 4;
     const int nj = p.tap_nj;
-    // (rsplit -- see the pass sequence below: this part multiplies ONE tile of every wave's two, tile = part; it sits in slot 0)
-    const bool rsplit0 = MF && p.tap_parts == 2 && (p.B + p.tb - 1) / p.tb <= 4;
-    const int tile0 = rsplit0 ? part : 0;                           // the tile whose weights / results are slot 0's (slot 1: the other one)
     float wa[TAP_NJR * 8];
-    if constexpr (MF) {
-        auto wk = [&](int J, int slot, int i_) { const int k = 16 * J + 4 * mkq + i_; return k < p.kpre ? Wt[(size_t)k * GC + 32 * wave + 16 * (slot ^ tile0) + mn] : 0.f; };
+    {
+        auto wk = [&](int J, int tl, int i_) { const int k = 16 * J + 4 * mkq + i_; return k < p.kpre ? Wt[(size_t)k * GC + 32 * wave + 16 * tl + mn] : 0.f; };
 #pragma unroll
         for (int J = 0; J < TAP_NJR; ++J)
 #pragma unroll
@@ -1209,23 +1174,11 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
             for (int tl = 0; tl < 2; ++tl)
                 s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR) + tl) * 64 + lane] = make_float4(wk(J, tl, 0), wk(J, tl, 1), wk(J, tl, 2), wk(J, tl, 3));
     }
-    const int uq = ks >> 1, uqm = 3 - uq;                            // (7 - ks) >> 1 = 3 - (ks >> 1)
-    const int ug[4] = {uq, uq ^ 1, uqm, uqm ^ 1};
-    const int xo0 = ug[0] * kx + k0, xo1 = ug[1] * kx + k0, xo2 = ug[2] * kx + k0, xo3 = ug[3] * kx + k0;   // input of group g: xin[...][ug[g]][k0 ..]
-    // what a lane publishes: after the all-reduce over ks every lane of a group holds all 16 sums (4 utterances x 4 outputs); lane ks sends
-    // outputs ob + 2 (ks & 1), + 1 of utterance ks >> 1 of the round -- with their addends: c_l (a constant of the lane) and the effective
-    // conv bias (per utterance when the model has a speaker embedding).  The bias rows are the MODEL's gate rows (tanh rows [0, G/2),
-    // sigmoid rows [G/2, G)); this kernel's 256 outputs are tanh channels 0..127 then sigmoid channels 0..127, zero beyond G/2
-    const int pu = uq, po = ob + 2 * (ks & 1);                     // utterance of the round, first of the two outputs (legacy form; MF: see [D])
-    const int zhalf = po >> 7, zch = po & 127;
-    const float2 cvl = *reinterpret_cast<const float2*>(p.cvec + (size_t)l * GC + po);
-    const float* zbase = p.zbias + (size_t)l * p.zb_ld + (size_t)zhalf * p.gh + zch;
-    const bool z0 = zch < p.gh, z1 = zch + 1 < p.gh;
-    const float zsc = WNV_PHASE2 ? (zhalf ? GATE_SCALE_SIGM : GATE_SCALE_TANH) : 1.0f;
-    for (int i = tid; i < (MF ? TAP_XBUF : 2) * TB * kx; i += RT) s.xin[i] = 0.f;
+    // (the bias rows are the MODEL's gate rows -- tanh rows [0, G/2), sigmoid rows [G/2, G) --; this kernel's 256 outputs are tanh channels 0..127
+    //  then sigmoid channels 0..127, zero beyond G/2)
+    for (int i = tid; i < TAP_XBUF * TB * kx; i += RT) s.xin[i] = 0.f;
     if (tid == 0) s.flags[0] = 0;
     __syncthreads();
-    const int kres = p.kreg_rows + p.klds_rows;                    // rows of this wave that never touch memory again
 
     // A layer with dilation >= 2 needs NOTHING of this step's h for pre[t + 1] (its taps are h[t+1-d], h[t+1-2d], ...): its pass does not
     // wait for h[t] -- the row is waited for and filed by the NEXT pass of the utterance (tf = t - 1), a whole step later --, so the rings
@@ -1238,25 +1191,11 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
     const bool early = d >= 2 && rows > 0;
     const int ntap4 = hoff / 4, ncin4 = (p.cin & 3) == 0 ? p.cin / 4 : 0;      // float4s of a mat-vec input: tap rows, conditioning row
     constexpr int GQ = 2;                                          // ... per lane ((kw - 1) 128 + cin <= 512 floats: why_not)
-    // this workgroup's passes of a step: utterances [b0, b0 + tb).  Legacy: part q serves passes q, q + parts, ...: b0 = bfirst, + pstride, ... < B.
-    // MF: passes are multiplied in PAIRS of neighbours (2 m, 2 m + 1) -- the partner of a pass is the next token of every ring -- and the
-    // pairs are dealt to the parts alternately: part q serves pairs q, q + parts, ...  Up to four passes per step (32 utterances) BOTH parts
-    // serve ALL passes with half the output rows each (rsplit: one tile per wave, 2.3 us per multiplication): the tap path's latency is within
-    // 1-2 us of the critical path at every batch size, and a lone sixteen-column multiplication of all rows (4.6 us) cost the headline 1.2 %.
-    const int npass_all = (p.B + p.tb - 1) / p.tb;
-    const bool rsplit = MF && p.tap_parts == 2 && npass_all <= 4;
-    const int eparts = rsplit ? 1 : p.tap_parts, epart = rsplit ? 0 : part;       // parts that share the passes, this one's index among them
-    const int pstride = MF ? 2 * eparts * p.tb : p.tap_parts * p.tb;
-    const int bfirst = MF ? 2 * epart * p.tb : part * p.tb;
-    // the pass after (t_, b_) of this workgroup
-    auto advance = [&](int& t_, int& b_) {
-        if constexpr (MF) {
-            const int pi = b_ / p.tb;
-            if (!(pi & 1) && b_ + p.tb < p.B) { b_ += p.tb; return; }                // the partner
-            b_ = (pi & ~1) * p.tb + pstride;                                       // the next pair of this part
-        } else b_ += pstride;
-        if (b_ >= p.B) { b_ = bfirst; t_ += 1; }
-    };
+    // this workgroup's UNITS of a step: the two neighbouring passes (2 m, 2 m + 1) -- utterances [b, b + tb) and [b + tb, b + 2 tb): the partner of
+    // a pass is the next token of every ring -- are multiplied together; the units are dealt to the layer's parts alternately: b = bfirst,
+    // + pstride, ... < B.  (The host launches these kernels for models with ONE part per layer.)
+    const int pstride = 2 * p.tap_parts * p.tb;
+    const int bfirst = 2 * part * p.tb;
     if (bfirst >= p.B) return;
     auto fresh_tap = [&](int tf_) { return ((d == 1 || early) && d <= 2 && tf_ >= 0 && rows > 0) ? p.kw - 2 : -1; };   // the tap that is h[tf] itself
 
@@ -1312,17 +1251,8 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
         }
     };
 
-    int t = -1, b0 = bfirst, cur = 0;                              // pass (t, b0) consumes h_l[tf], produces pre_l[t + 1]; its inputs: buffer cur
-    int st_cur = seg_at(t, b0);                                      // ... of the pass about to run, of the next one
-    if (!MF && wave < min(p.tb, p.B - b0)) gather_issue(t, b0 + wave, s.xin + (size_t)wave * kx, 0, st_cur, hxa0, hxa1);
-    int st_next = INT_MIN;
-    {
-        int tn0 = t, bn0 = b0;
-        advance(tn0, bn0);
-        st_next = seg_at(tn0, bn0);
-    }
 #ifdef WNV_FINE_TRACE
-#define TAP_STAMP(k) do { const int pk_ = MF ? (b0 - bfirst) / p.tb : (b0 - bfirst) / pstride; \
+#define TAP_STAMP(k) do { const int pk_ = (b0 - bfirst) / p.tb; \
                           if (p.trace_tap && l == WNV_TRACE_TAP_LAYER && part == 0 && pk_ < 3 && (k) < 5 && tid == 64 * WNV_TRACE_TAP_WAVE && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) \
                               p.trace_tap[(size_t)(t - p.trace_t0) * TRW + 5 * pk_ + (k)] = wall_clock64(); } while (0)
 #else
@@ -1390,23 +1320,10 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's DMAs into buffer cur_ (issued with the gather) have landed
         }
     };
-    // (round 6) THE LAST PUBLISH OF A PASS IS HELD BACK until the next pass's [B] and barrier are through (dv0, dv1 -> "deferred publish"
-    // below).  A publish is a write-through store (the stage may sit on any XCD), its acknowledgement takes 1.5-2 us, and every wait of
-    // this wave for a LOAD -- the h record's poll, the DMA wait -- waits for it too (vmcnt counts stores): with the last publish right in
-    // front of [B] that drain was paid in the open once per pass -- the "wait for h" of profiles/r04_throughput_bound_final_stages.txt,
-    // 1.6-2.6 us of a 5.9-us pass whatever the stages did (at 40+ utterances per GPU the step was 3 or 4 such passes: 17.6 / 23.5 us).
-    // Now every publish is followed by a round of FMAs before this wave waits for anything.
-    // ONLY where this workgroup runs at least two passes per step: with a single one the next pass is the same utterances' next step, whose
-    // h (a dilation-1 layer's pass waits for it) cannot exist before the publish it would be holding back -- the ring would stop.
-    // With two or more, pass N + 1 waits for h of ANOTHER group, which depends on publishes of pass N - 1 and earlier, all released.
-    const bool defer = DEFER && WNV_TAP_DEFER != 0 && bfirst + pstride < p.B;
-    int dbase = -1, du0 = 0, dnb = 0, dtp = 0;                       // the held publish: its pass's first utterance (-1: nothing held), round, utterances, step
-    // MF: passes of this workgroup per step -- two or more: consecutive passes are multiplied in pairs; three or more: a pair's publish may be
-    // held back (with exactly one pair per step the next pass waits for an h that needs the very publish it would hold)
-    int npps = 0;                                                    // passes of this workgroup per step
-    { int t_ = 0, b_ = bfirst; do { ++npps; advance(t_, b_); } while (t_ == 0); }
-    const bool defer3 = MF && DEFER && WNV_TAP_DEFER != 0 && npps >= 3;
-    int pc = 0, pb0 = 0, pnb = 0, ptp = 0;                           // this workgroup's multiplication counter; the pass before (the low eight columns of a pair)
+    // A UNIT'S PUBLISH IS HELD BACK until the next unit's input phase and barrier are through (parked in LDS: TapLds::dv).  A publish is a
+    // write-through store (the stage may sit on any XCD), its acknowledgement takes 1.5-2 us, and every wait of the wave for a LOAD -- the h
+    // record's poll, the DMA wait -- waits for it too (vmcnt counts stores).  ONLY where this workgroup runs at least two units per step: with
+    // a single one the next unit is the same utterances' next step, whose h cannot exist before the publish it would be holding back.
     int dlo_b0 = 0, dlo_nb = 0, dlo_tp = 0, dhi_b0 = 0, dhi_nb = 0, dhi_tp = 0;   // the held pair: first utterance / utterances / step of its low and high columns
     bool dheld = false;
     typedef float f4m __attribute__((ext_vector_type(4)));
@@ -1418,12 +1335,11 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
     auto mf_publish = [&](int rb_, int tp_, const f4m& v0_, const f4m& v1_) {          // eight values of one utterance: four 16-byte write-through stores
         u64* rec = p.pmail + pre_rec(p, rb_, l, tp_) + 32 * wave + 4 * mkq;
         const unsigned tg = p.tag_base + (unsigned)tp_ + 1u;
-        u64* r0_ = rec + 16 * tile0;
-        st_granule2(r0_, tg, v0_.x, v0_.y, false); st_granule2(r0_ + 2, tg, v0_.z, v0_.w, false);
-        if (!rsplit0) { st_granule2(rec + 16, tg, v1_.x, v1_.y, false); st_granule2(rec + 18, tg, v1_.z, v1_.w, false); }
+        st_granule2(rec, tg, v0_.x, v0_.y, false); st_granule2(rec + 2, tg, v0_.z, v0_.w, false);
+        st_granule2(rec + 16, tg, v1_.x, v1_.y, false); st_granule2(rec + 18, tg, v1_.z, v1_.w, false);
     };
-    if constexpr (MF) {
-        // ---- THE UNIT LOOP (v4).  A unit = the two neighbouring passes (2 m, 2 m + 1) of a multiplication, or a last pass without a partner:
+    {
+        // ---- THE UNIT LOOP.  A unit = the two neighbouring passes (2 m, 2 m + 1) of a multiplication, or a last pass without a partner:
         //      ONE input phase (every wave finishes its utterance of pass A, then of pass B), ONE barrier, the held publish's release, the
         //      multiplication -- with the NEXT unit's gathers and looks issued from inside the MFMA stream (the matrix pipe runs on while the
         //      wave forms addresses and issues DMAs) --, publish or hold.
@@ -1476,7 +1392,7 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
             float4 cv[2], zb[2];
 #pragma unroll
             for (int tl = 0; tl < 2; ++tl) {
-                const int po_ = 32 * wave + 16 * (tl ^ tile0) + 4 * mkq, zh = po_ >> 7, zc = po_ & 127;   // (tl = the slot)
+                const int po_ = 32 * wave + 16 * tl + 4 * mkq, zh = po_ >> 7, zc = po_ & 127;
                 cv[tl] = *reinterpret_cast<const float4*>(p.cvec + (size_t)l * GC + po_);
                 float zz[4] = {0.f, 0.f, 0.f, 0.f};
                 if (pubc) {
@@ -1493,54 +1409,31 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
             auto xread = [&](int J) { return *reinterpret_cast<const float4*>(xr + 16 * min(J, nj - 1)); };
             f4m d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
             float4 xv = xread(0);
-            if (!rsplit0) {
 #pragma unroll
-                for (int J = 0; J < TAP_NJR; ++J) {
-                    const float4 xn = xread(J + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+            for (int J = 0; J < TAP_NJR; ++J) {
+                const float4 xn = xread(J + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
-                    for (int i_ = 0; i_ < 4; ++i_) {
-                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J) * 4 + i_], xs[i_], d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J + 1) * 4 + i_], xs[i_], d1, 0, 0, 0);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    xv = xn;
-                    if (J == 1) { if (more) issue_unit(tn, bn, nbase, stAn, stBn); __builtin_amdgcn_sched_barrier(0); }
+                for (int i_ = 0; i_ < 4; ++i_) {
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J) * 4 + i_], xs[i_], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J + 1) * 4 + i_], xs[i_], d1, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                xv = xn;
+                if (J == 1) { if (more) issue_unit(tn, bn, nbase, stAn, stBn); __builtin_amdgcn_sched_barrier(0); }
+            }
 #pragma unroll 1
-                for (int J = TAP_NJR; J < nj; ++J) {
-                    const float4 w0 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR)) * 64 + lane], w1 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR) + 1) * 64 + lane];
-                    const float4 xn = xread(J + 1);
-                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
+            for (int J = TAP_NJR; J < nj; ++J) {
+                const float4 w0 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR)) * 64 + lane], w1 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR) + 1) * 64 + lane];
+                const float4 xn = xread(J + 1);
+                const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
-                    for (int i_ = 0; i_ < 4; ++i_) {
-                        d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i_], xs[i_], d0, 0, 0, 0);
-                        d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i_], xs[i_], d1, 0, 0, 0);
-                    }
-                    xv = xn;
+                for (int i_ = 0; i_ < 4; ++i_) {
+                    d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i_], xs[i_], d0, 0, 0, 0);
+                    d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i_], xs[i_], d1, 0, 0, 0);
                 }
-            } else {                                                 // rsplit: slot 0 only (the same MFMAs in the same order as slot 0's above)
-#pragma unroll
-                for (int J = 0; J < TAP_NJR; ++J) {
-                    const float4 xn = xread(J + 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                    for (int i_ = 0; i_ < 4; ++i_) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J) * 4 + i_], xs[i_], d0, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    xv = xn;
-                    if (J == 1) { if (more) issue_unit(tn, bn, nbase, stAn, stBn); __builtin_amdgcn_sched_barrier(0); }
-                }
-#pragma unroll 1
-                for (int J = TAP_NJR; J < nj; ++J) {
-                    const float4 w0 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR)) * 64 + lane];
-                    const float4 xn = xread(J + 1);
-                    const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w};
-#pragma unroll
-                    for (int i_ = 0; i_ < 4; ++i_) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i_], xs[i_], d0, 0, 0, 0);
-                    xv = xn;
-                }
+                xv = xn;
             }
             TAP_STAMP(3);
             const float zs_ = WNV_PHASE2 ? (wave >= 4 ? GATE_SCALE_SIGM : GATE_SCALE_TANH) : 1.0f;
@@ -1555,263 +1448,8 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
             if (!more) break;
             ut = tn; ub = bn; ++upc; stA = stAn; stB = stBn;
         }
-        return;
     }
-    for (;;) {
-        const int tp = t + 1;
-        const int nb = min(p.tb, p.B - b0);
-        TAP_STAMP(0);
-        do_B(t, b0, cur, st_cur, hxa0, hxa1);
-        TAP_STAMP(1);                                                // (this wave's h record filed, its DMAs landed)
-        __syncthreads();                                             // the inputs of pass (t, b0) are complete in buffer cur
-        if (s.flags[0]) return;
-        TAP_STAMP(2);
-#ifdef WNV_FINE_TRACE
-        {   // slot 15 of the row: two bits per wave and pass -- how each wave got its record
-            const int pk_ = MF ? (b0 - bfirst) / p.tb : (b0 - bfirst) / pstride;
-            if (p.trace_tap && l == WNV_TRACE_TAP_LAYER && part == 0 && pk_ < 3 && tid == 0 && t >= p.trace_t0 && t < p.trace_t0 + p.trace_n) {
-                unsigned long long m = 0;
-                for (int w = 0; w < 8; ++w) m |= (unsigned long long)(s.flags[24 + w] & 3) << (2 * w);
-                unsigned long long* q = p.trace_tap + (size_t)(t - p.trace_t0) * TRW + 15;
-                *q = (pk_ == 0 ? 0ull : *q) | (m << (16 * pk_));
-            }
-        }
-#endif
-        if constexpr (MF) {
-            if (dheld) {                                                 // the held pair's publish (see [D])
-                int rb_, tp_; bool pub_;
-                colmap(dlo_b0, dlo_nb, dlo_tp, dhi_b0, dhi_nb, dhi_tp, rb_, tp_, pub_);
-                if (pub_) {
-                    const float4 a = reinterpret_cast<const float4*>(s.dv)[tid], c = reinterpret_cast<const float4*>(s.dv)[RT + tid];
-                    mf_publish(rb_, tp_, f4m{a.x, a.y, a.z, a.w}, f4m{c.x, c.y, c.z, c.w});
-                }
-                dheld = false;
-            }
-        }
-        if (dbase >= 0 && du0 + pu < dnb) {                             // the deferred publish of the pass before (see above the loop)
-            const float2 dvv = s.dv[tid];
-            st_granule2(p.pmail + pre_rec(p, dbase + du0 + pu, l, dtp) + po, p.tag_base + (unsigned)dtp + 1u, dvv.x, dvv.y, false);
-        }
-        dbase = -1;
-        // ---- [C] the next pass of this workgroup: its gather is issued now and lands under the mat-vec below -------------------------
-        int tn = t, bn = b0;
-        advance(tn, bn);
-        const bool more = tn + 1 < p.T;
-        // (MF: does THIS pass multiply?  pass k of the step: (2 j, 2 j + 1) are multiplied together by the odd one; the last pass of an odd
-        //  number runs alone -- a pair never straddles two steps: its low half would wait for a token most of a revolution behind, measured
-        //  -19 % at 48 utterances.  The input buffers: a multiplication's passes sit in buffers (2 c, 2 c + 1), c alternating.)
-        const int pidx = b0 / p.tb;                                  // the pass's index in the step (all parts)
-        const bool paired = MF && (pidx & 1);
-        const bool do_mm = paired || b0 + p.tb >= p.B || !more;      // ... the odd pass of a pair, a last pass without a partner, the launch's last pass
-        const int nxt = MF ? 2 * ((pc + (do_mm ? 1 : 0)) & 1) + ((bn / p.tb) & 1) : (cur ^ 1);   // the next pass's input buffer
-        if (more && wave < min(p.tb, p.B - bn)) gather_issue(tn, bn + wave, s.xin + ((size_t)nxt * TB + wave) * kx, nxt, st_next, hxa0, hxa1);
-        int st_nn = INT_MIN;                                         // the pass after the next: asked for now, used a pass from now
-        if (PACKED && more) {
-            int tnn = tn, bnn = bn;
-            advance(tnn, bnn);
-            st_nn = seg_at(tnn, bnn);
-        }
-        // ---- [D] mat-vec for all utterances of the pass, four at a time (accumulators + weights must fit the register file):
-        //      VGPR rows, then LDS rows, then whatever streams; no barrier inside (the inputs are read-only here, the next
-        //      pass's land in the other buffer, and its [B] barrier is behind every wave's last read of this one) -----------
-        if constexpr (MF) {
-            if (do_mm) {
-                const int lo_b0 = paired ? pb0 : b0, lo_nb = paired ? pnb : nb, lo_tp = paired ? ptp : tp, hi_nb = paired ? nb : 0;
-                int rb, ctp; bool pubc;
-                colmap(lo_b0, lo_nb, lo_tp, b0, hi_nb, tp, rb, ctp, pubc);
-                // addends of this lane's eight outputs (rows 32 wave + 16 tile + 4 mkq + v of utterance rb), asked for ahead of the MFMAs:
-                // c_l and the utterance's effective conv bias (packed slots: handed over through LDS by [B], slot = the pass's parity)
-                float4 cv[2], zb[2];
-#pragma unroll
-                for (int tl = 0; tl < 2; ++tl) {
-                    const int po_ = 32 * wave + 16 * (tl ^ tile0) + 4 * mkq, zh = po_ >> 7, zc = po_ & 127;   // (tl = the slot)
-                    cv[tl] = *reinterpret_cast<const float4*>(p.cvec + (size_t)l * GC + po_);
-                    float zz[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (pubc) {
-                        const float* zq;
-                        if constexpr (PACKED && WNV_TAP_ZLDS != 0) zq = s.zl + ((size_t)(paired ? (mn < 8 ? 0 : 1) : (cur & 1)) * TB + (mn & 7)) * GC + zh * p.gh + zc;
-                        else zq = p.zbias + (size_t)l * p.zb_ld + (size_t)zh * p.gh + zc + (size_t)((PACKED && p.seg_gid) ? p.seg_gid[(size_t)rb * p.T + ctp] : rb) * p.zbias_bstride;
-#pragma unroll
-                        for (int i_ = 0; i_ < 4; ++i_) if (zc + i_ < p.gh) zz[i_] = zq[i_];
-                    }
-                    zb[tl] = make_float4(zz[0], zz[1], zz[2], zz[3]);
-                }
-                // the sixteen columns' input rows: the pair's two buffers are adjacent (the odd pass's is cur); a lone pass repeats its eight
-                const int xrow = (paired ? cur - 1 : cur) * TB + ((paired || mn < 8) ? mn : (mn & 7));
-                const float* xr = s.xin + (size_t)xrow * kx + 4 * mkq;
-                auto xread = [&](int J) { return *reinterpret_cast<const float4*>(xr + 16 * min(J, nj - 1)); };
-                f4m d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
-                float4 xv = xread(0);
-                // (an explicit two-stage pipeline: group J + 1's input is asked for in front of group J's MFMAs; weights beyond this model's K
-                //  are zero and the read is clamped to its last group -- exact zeros)
-                if (!rsplit0) {
-#pragma unroll
-                    for (int J = 0; J < TAP_NJR; ++J) {
-                        const float4 xn = xread(J + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                        for (int i_ = 0; i_ < 4; ++i_) {
-                            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J) * 4 + i_], xs[i_], d0, 0, 0, 0);
-                            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J + 1) * 4 + i_], xs[i_], d1, 0, 0, 0);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        xv = xn;
-                    }
-#pragma unroll 1
-                    for (int J = TAP_NJR; J < nj; ++J) {
-                        const float4 w0 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR)) * 64 + lane], w1 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR) + 1) * 64 + lane];
-                        const float4 xn = xread(J + 1);
-                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w}, a1[4] = {w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-                        for (int i_ = 0; i_ < 4; ++i_) {
-                            d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i_], xs[i_], d0, 0, 0, 0);
-                            d1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[i_], xs[i_], d1, 0, 0, 0);
-                        }
-                        xv = xn;
-                    }
-                } else {                                             // rsplit: slot 0 only (the same MFMAs in the same order as slot 0's above)
-#pragma unroll
-                    for (int J = 0; J < TAP_NJR; ++J) {
-                        const float4 xn = xread(J + 1);
-                        __builtin_amdgcn_sched_barrier(0);
-                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
-#pragma unroll
-                        for (int i_ = 0; i_ < 4; ++i_) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[(2 * J) * 4 + i_], xs[i_], d0, 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        xv = xn;
-                    }
-#pragma unroll 1
-                    for (int J = TAP_NJR; J < nj; ++J) {
-                        const float4 w0 = s.wl[((size_t)wave * p.klds_rows + 2 * (J - TAP_NJR)) * 64 + lane];
-                        const float4 xn = xread(J + 1);
-                        const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, a0[4] = {w0.x, w0.y, w0.z, w0.w};
-#pragma unroll
-                        for (int i_ = 0; i_ < 4; ++i_) d0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[i_], xs[i_], d0, 0, 0, 0);
-                        xv = xn;
-                    }
-                }
-                TAP_STAMP(3);
-                // (WNV_PHASE2: everything that sums into z carries the gate's exp2 scale -- the matrix and c_l from the host, the bias row here;
-                //  rows [0, 128) of this kernel's 256 outputs are tanh rows, [128, 256) sigmoid rows: waves 0-3 / 4-7)
-                const float zs_ = WNV_PHASE2 ? (wave >= 4 ? GATE_SCALE_SIGM : GATE_SCALE_TANH) : 1.0f;
-                const f4m v0 = {d0.x + fmaf(zb[0].x, zs_, cv[0].x), d0.y + fmaf(zb[0].y, zs_, cv[0].y), d0.z + fmaf(zb[0].z, zs_, cv[0].z), d0.w + fmaf(zb[0].w, zs_, cv[0].w)};
-                const f4m v1 = {d1.x + fmaf(zb[1].x, zs_, cv[1].x), d1.y + fmaf(zb[1].y, zs_, cv[1].y), d1.z + fmaf(zb[1].z, zs_, cv[1].z), d1.w + fmaf(zb[1].w, zs_, cv[1].w)};
-                // pre_l of up to sixteen utterances leaves as tagged granules -- or is held back behind the next pass's [B] and barrier (the
-                // write-through stores' acknowledgement would be drained by that pass's first wait for a load: see above the loop)
-                if (defer3 && more) {
-                    reinterpret_cast<float4*>(s.dv)[tid] = make_float4(v0.x, v0.y, v0.z, v0.w);
-                    reinterpret_cast<float4*>(s.dv)[RT + tid] = make_float4(v1.x, v1.y, v1.z, v1.w);
-                    dlo_b0 = lo_b0; dlo_nb = lo_nb; dlo_tp = lo_tp; dhi_b0 = b0; dhi_nb = hi_nb; dhi_tp = tp; dheld = true;
-                } else if (pubc) mf_publish(rb, ctp, v0, v1);
-                TAP_STAMP(4);
-            }
-        } else
-#pragma unroll 1
-        for (int u0 = 0; u0 < nb; u0 += 4) {
-            // packed FMAs (v_pk_fma_f32: two outputs per instruction, the input broadcast into both halves): this loop is what a
-            // pass costs -- 336 rows x 256 outputs x 8 utterances = 688 k MACs per workgroup
-            const bool pub = u0 + pu < nb;                                   // this lane has something to publish in this round
-            const int rb = b0 + u0 + pu;
-            float zb0 = 0.f, zb1 = 0.f;                                      // the utterance's effective conv bias: requested ahead of the FMAs
-            if constexpr (PACKED && WNV_TAP_ZLDS != 0) {
-                if (pub) {
-                    const float* zq = s.zl + ((size_t)cur * TB + u0 + pu) * GC + zhalf * p.gh + zch;
-                    if (z0) zb0 = zq[0];
-                    if (z1) zb1 = zq[1];
-                }
-            } else
-            if (pub) {
-                // (throughput instantiation: these two global loads per lane and round stay.  Round 6 measured both alternatives on one box --
-                //  the row fetched with the pass's inputs and handed over through LDS: egs/mol +0.4 %, mu-law -1.9 %, cfg4 -4 %; ONE copy in LDS
-                //  for the whole launch where no global conditioning makes the row a constant: -3.2 % at 40-64 utterances.  The loads' wait at
-                //  the end of a round is where this wave's earlier write-through publish gets drained, under the other waves' FMAs; without
-                //  it the drain moves into the open in front of the next pass's barrier: profiles/r06_tap_zlds_ab.txt)
-                // (packed slots: the bias row of the utterance that occupies the slot at step tp -- its speaker.  Read here, ahead of the
-                //  FMAs; parked in LDS a pass ahead it cost the packed instantiations 2-4 spilled registers and 3 % -- round 5, measured)
-                const float* zrow = zbase + (size_t)((PACKED && p.seg_gid) ? p.seg_gid[(size_t)rb * p.T + tp] : rb) * p.zbias_bstride;
-                if (z0) zb0 = zrow[0];
-                if (z1) zb1 = zrow[1];
-            }
-            f2 acc[4][2];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = f2{0.f, 0.f};
-            const float* xr = s.xin + ((size_t)cur * TB + u0) * kx;
-            const float* xg[4] = {xr + xo0, xr + xo1, xr + xo2, xr + xo3};
-            // (loop order: a row's weights against two utterances -- four INDEPENDENT accumulators in a row; with one utterance
-            //  innermost the compiler alternated two and every v_pk_fma_f32 waited for the one before the last: 6.8 clocks per
-            //  instruction instead of 4.7, profiles/r04_tap_pass_timeline.txt; all four at once need 16 input registers: spills)
-#pragma unroll
-            for (int r4 = 0; r4 < KR / 4; ++r4) {
-#pragma unroll
-                for (int gp = 0; gp < 4; gp += 2) {                      // two utterances at a time: four independent accumulators in a row
-                    const float4 xa = *reinterpret_cast<const float4*>(xg[gp] + 4 * r4), xc = *reinterpret_cast<const float4*>(xg[gp + 1] + 4 * r4);
-                    const float xs[2][4] = {{xa.x, xa.y, xa.z, xa.w}, {xc.x, xc.y, xc.z, xc.w}};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float4 w = wreg[4 * r4 + e];
-#pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            const f2 xx = f2{xs[g][e], xs[g][e]};
-                            acc[gp + g][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[gp + g][0]);
-                            acc[gp + g][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[gp + g][1]);
-                        }
-                    }
-                }
-            }
-            for (int r = 0; r < p.klds_rows; r += 4) {                     // klds_rows is a multiple of 4: one 16-byte x read per utterance
-                float4 w[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) w[e] = s.wl[((size_t)wave * p.klds_rows + r + e) * 64 + lane];
-#pragma unroll
-                for (int gp = 0; gp < 4; gp += 2) {
-                    const float4 xa = *reinterpret_cast<const float4*>(xg[gp] + p.kreg_rows + r), xc = *reinterpret_cast<const float4*>(xg[gp + 1] + p.kreg_rows + r);
-                    const float xs[2][4] = {{xa.x, xa.y, xa.z, xa.w}, {xc.x, xc.y, xc.z, xc.w}};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            const f2 xx = f2{xs[g][e], xs[g][e]};
-                            acc[gp + g][0] = __builtin_elementwise_fma(f2{w[e].x, w[e].y}, xx, acc[gp + g][0]);
-                            acc[gp + g][1] = __builtin_elementwise_fma(f2{w[e].z, w[e].w}, xx, acc[gp + g][1]);
-                        }
-                }
-            }
-            for (int k = k0 + kres; k < k0 + p.kper && k < p.kpre; ++k) {
-                const float4 w = wload(k);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float xs = xg[g][k - k0];
-                    const f2 xx = f2{xs, xs};
-                    acc[g][0] = __builtin_elementwise_fma(f2{w.x, w.y}, xx, acc[g][0]);
-                    acc[g][1] = __builtin_elementwise_fma(f2{w.z, w.w}, xx, acc[g][1]);
-                }
-            }
-            // the K slices meet (see REDUCE-SCATTER above)
-#pragma unroll
-            for (int g = 0; g < 2; ++g)
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-                    acc[g][h] = f2{dpp_fold<0x141>(acc[g][h].x, acc[g + 2][1 - h].x), dpp_fold<0x141>(acc[g][h].y, acc[g + 2][1 - h].y)};   // (the mirror partner has the other parity: its OTHER pair holds these outputs)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) acc[0][h] = f2{dpp_fold<0x4E>(acc[0][h].x, acc[1][h].x), dpp_fold<0x4E>(acc[0][h].y, acc[1][h].y)};
-            // (WNV_PHASE2: everything that sums into z carries the gate's exp2 scale -- the matrix and c_l from the host, the bias row here)
-            const float v0 = dpp_fold<0xB1>(acc[0][0].x, acc[0][1].x) + fmaf(zb0, zsc, cvl.x);
-            const float v1 = dpp_fold<0xB1>(acc[0][0].y, acc[0][1].y) + fmaf(zb1, zsc, cvl.y);
-            // pre_l[tp] of utterance rb leaves as tagged granules (write-through: the stage may sit on any XCD): no drain
-            if (defer && more && u0 + 4 >= nb) {                          // the last round of the pass: held back (see above the loop)
-                s.dv[tid] = make_float2(v0, v1);                         // (read back by this very thread)
-                dbase = b0; du0 = u0; dnb = nb; dtp = tp;
-            } else
-            if (pub) st_granule2(p.pmail + pre_rec(p, rb, l, tp) + po, p.tag_base + (unsigned)tp + 1u, v0, v1, false);
-            TAP_STAMP(min(3 + u0 / 4, 4));
-        }
 #undef TAP_STAMP
-        if (!more) break;
-        if constexpr (MF) { pb0 = b0; pnb = nb; ptp = tp; pc += do_mm ? 1 : 0; }
-        t = tn; b0 = bn; cur = nxt;
-        st_cur = st_next; st_next = st_nn;
-    }
 }
 
 // ---- the 256-row mat-vec of a WAVE GROUP (four waves = one wave per SIMD) -------------------------------------------------
