@@ -28,7 +28,10 @@ def _ring_rows(eng, B, T, c_up, seed, want_params=False):
     return index, params
 
 
-@pytest.mark.parametrize("name,T", [("cfg1_mulaw256", 32768), ("cfg0_mulaw256_small", 32768)])
+@pytest.mark.parametrize("name,T", [("cfg1_mulaw256", 32768), ("cfg0_mulaw256_small", 32768),
+                                    # (round 6, last) a 30-layer model: its tap role runs on the matrix pipe, sixteen utterances (two passes) per
+                                    # multiplication -- a lone pass at B = 8, pairs + a lone pass at B = 40, the packed kernel: same bits
+                                    ("cfg1b_mulaw256_intree", 16384)])
 def test_one_hot_classes_do_not_depend_on_the_batch_size_or_the_packing(name, T):
     """8 utterances x 32 768 steps = 2^18 utterance-steps x 256 draws: 2^26 draws of the stream -- four times the period at which the old
     uniform hit 1.0 -- compared class for class across the three instantiations."""
