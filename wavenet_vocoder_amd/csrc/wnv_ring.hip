@@ -1118,6 +1118,9 @@ __device__ __attribute__((always_inline)) void run_tap(const RingParams& p, int 
     }
 }
 
+#ifndef WNV_MF_GATHER_AT
+#define WNV_MF_GATHER_AT 1         // the K group of a unit's multiplication behind which the next unit's gathers and looks are issued (-1: in front of it)
+#endif
 constexpr int TAP_NJR = 16;        // (round 6, matrix-pipe tap role, run_tap_mf) K groups of 16 rows whose weights a lane holds in registers (2 tiles x 4 each: 128) ...
 constexpr int TAP_NJL = 6;         // ... and at most this many more in LDS (two float4 per lane and group: TapLds::wl): K = (kw - 1) 128 + cin <= 352
 constexpr int TAP_XPAD = 4;        // the pad of a mat-vec input row in LDS: the sixteen utterances of a multiplication then sit on sixteen different bank quads
@@ -1408,6 +1411,9 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
             const float* xr = s.xin + (size_t)xrow * kx + 4 * mkq;
             auto xread = [&](int J) { return *reinterpret_cast<const float4*>(xr + 16 * min(J, nj - 1)); };
             f4m d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+#if WNV_MF_GATHER_AT < 0
+            if (more) issue_unit(tn, bn, nbase, stAn, stBn);         // (in front of the multiplication)
+#endif
             float4 xv = xread(0);
 #pragma unroll
             for (int J = 0; J < TAP_NJR; ++J) {
@@ -1421,7 +1427,9 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 xv = xn;
-                if (J == 1) { if (more) issue_unit(tn, bn, nbase, stAn, stBn); __builtin_amdgcn_sched_barrier(0); }
+#if WNV_MF_GATHER_AT >= 0
+                if (J == WNV_MF_GATHER_AT) { if (more) issue_unit(tn, bn, nbase, stAn, stBn); __builtin_amdgcn_sched_barrier(0); }
+#endif
             }
 #pragma unroll 1
             for (int J = TAP_NJR; J < nj; ++J) {
