@@ -1138,19 +1138,22 @@ __host__ __device__ inline size_t tap_lds_floats_mf(int kper, int klds_rows) {
     return (size_t)TAP_XBUF * TB * (RW * kper + TAP_XPAD) + 32 + 8 * RT + (size_t)2 * TB * GC + (size_t)RW * klds_rows * 64 * 4;
 }
 
-// (MF, round 6: the mat-vec on the MATRIX pipe, SIXTEEN utterances at a time -- v_mfma_f32_16x16x4_f32: A[i = lane % 16][k = lane / 16],
-//  B[k = lane / 16][j = lane % 16], result register v of a lane = D[4 (lane / 16) + v][lane % 16].  A wave's 32 output rows are two tiles; K runs
-//  in groups of 16: lane (n = lane & 15, kq = lane >> 4) reads x[utterance n][16 J + 4 kq .. + 3] with ONE 16-byte LDS read and feeds four MFMAs
-//  per tile with it (MFMA i of group J sums k = 16 J + 4 kq' + i over kq'); its weights W[16 J + 4 kq + i][row n of the tile] live in registers
-//  for J < TAP_NJR (128) and as two float4 per group in LDS beyond.  The sixteen columns are the utterances of TWO consecutive passes of this
-//  workgroup: every pass still finishes its own eight inputs ([B], barrier, [C]), an even pass then stops there and the odd pass after it
-//  multiplies both passes' rows -- they lie in adjacent input buffers -- and publishes both; a workgroup with a single pass per step
-//  multiplies every pass on its own (eight columns idle: at those batch sizes the tap workgroups are far off the critical path).
-//  Why: the legacy form -- 4 utterances per round, inputs broadcast from LDS to every lane group of every wave -- is issue-bound at 41 % of
-//  the CU's FMA peak (4.7 clocks per v_pk_fma_f32 + 16 per ds_read_b128, the two waves of a SIMD do not hide each other) and was the step's
-//  cadence beyond 32 utterances; this form reads an input once per sixteen columns and runs at 98 % of the matrix pipe in isolation:
-//  1.14 us per four utterances against 1.71 (profiles/r06_tap_waves.txt, scripts/ubench_tapmv.hip VAR 11).  EVERY instantiation uses it when
-//  the model fits (RingParams::tap_mfma): pre_l must not depend on the batch size -- a column's arithmetic does not depend on its neighbours.)
+// ---- THE TAP ROLE ON THE MATRIX PIPE (round 6; kernels wnv_ring_kernel_mf, chosen by the host for models with ONE tap workgroup per layer at
+// every batch size: the 30-layer models -- see "THE TAP ROLE ON THE MATRIX PIPE" in the host code).  Same inputs, records, history rings and
+// publish format as run_tap; what differs is the mat-vec and the pass structure around it:
+//  * v_mfma_f32_16x16x4_f32: A[i = lane % 16][k = lane / 16], B[k = lane / 16][j = lane % 16], result register v of a lane = D[4 (lane / 16) + v][lane % 16].
+//    A wave's 32 output rows are two tiles; K runs in groups of 16: lane (n = lane & 15, kq = lane >> 4) reads x[utterance n][16 J + 4 kq .. + 3]
+//    with ONE 16-byte LDS read and feeds four MFMAs per tile with it (MFMA i of group J sums k = 16 J + 4 kq' + i over kq'); its weights
+//    W[16 J + 4 kq + i][row n of the tile] live in registers for J < TAP_NJR (128) and as two float4 per group in LDS beyond.
+//  * The sixteen columns are the utterances of a UNIT: two neighbouring passes (2 m, 2 m + 1) of eight -- or a last pass without a partner
+//    (its eight columns repeated).  One input phase (every wave finishes its utterance of pass A, then of pass B: [B] of run_tap twice), one
+//    barrier, the held publish's release, the multiplication with the next unit's gathers and looks issued from inside the MFMA stream, four
+//    16-byte stores per lane -- held back behind the next unit's barrier where the workgroup runs two or more units per step.
+//  * Why: run_tap's mat-vec -- 4 utterances per round, inputs broadcast from LDS to every lane group of every wave -- is issue-bound at 41 % of
+//    the CU's FMA peak (4.7 clocks per v_pk_fma_f32 + 16 per ds_read_b128, the two waves of a SIMD do not hide each other); this form reads an
+//    input once per sixteen columns and multiplies at 98 % of the matrix pipe in isolation (1.14 us per four utterances against 1.71:
+//    profiles/r06_tap_waves.txt, scripts/ubench_tapmv.hip VAR 11).  A column's arithmetic does not depend on its neighbours, the choice of the
+//    kernel depends on the model only: pre_l is the same bits whatever the batch size or the packing (tests/test_gpu_seed_determinism.py).
 template <bool SPEC, bool PACKED, bool DEFER>
 __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, int l, int part, float* smem) {
     if (WNV_EXP_NOPRE >= 2) return;
@@ -1214,7 +1217,7 @@ __device__ __attribute__((always_inline)) void run_tap_mf(const RingParams& p, i
     // The gathered rows go global -> LDS by DMA (global_load_lds_dwordx4: 64 lanes x 16 bytes land at base + 16 lane; no staging
     // registers -- next to 128 weight registers there are none to spare: the register-staged form spilled 27) into the OTHER input
     // buffer; the issuing wave waits for its own DMAs (vmcnt) in [B] of the pass that uses them, in front of the barrier.
-    u64 hxa0 = 0, hxa1 = 0, hxb0 = 0, hxb1 = 0;                      // the speculative looks in flight (legacy: one pass; MF: the two passes of a unit)
+    u64 hxa0 = 0, hxa1 = 0, hxb0 = 0, hxb1 = 0;                      // the speculative looks in flight: the two passes of a unit
     // packed slots: seg_start of (utterance b0_ + wave, step t_ + 1) -- a scalar load (no vector register held across the DMA issue),
     // asked for ONE PASS AHEAD of the gather that needs it (round 5: read at the top of gather_issue, every pass began its mat-vec behind
     // a scalar-load round trip -- the packed instantiations ran 12-20 % below the padded ones at the same number of rows)
